@@ -1,0 +1,274 @@
+/*
+ * pmx.h — C ABI of libpmx_hip.so: MI355X-native batched PK/PD prediction
+ * (pharmsol's `Equation::estimate_predictions` hot path, subject x support-point).
+ *
+ * The reference (LAPKB/pharmsol, Rust) has no FFI on this path; the seam this
+ * library replaces is the `Equation` trait surface:
+ *   - Equation::estimate_predictions        src/simulator/equation/mod.rs:526-532
+ *   - Equation::estimate_predictions_dense  src/simulator/equation/mod.rs:459-465
+ *   - the population double loop            src/simulator/likelihood/matrix.rs:79-98
+ * A pharmsol maintainer binds these entry points from an `extern "C"` block
+ * (INTEGRATION.md shows the Rust stub).  Plain pointers and sizes only.
+ *
+ * Ownership: the caller owns every buffer it passes in; the library copies what
+ * it needs at *_create time and owns the device mirrors behind opaque handles.
+ * Handles are immutable after creation and may be shared by host threads
+ * (the reference's `Equation: Sync` bound, equation/mod.rs:377).
+ * Every function returns a pmx_status (0 = OK); pmx_last_error() returns the
+ * message of the last failing call made by the calling thread.
+ */
+#ifndef PMX_H
+#define PMX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PMX_ABI_VERSION 1
+
+/* ---- limits (fixed-size descriptor arrays) ------------------------------- */
+#define PMX_MAX_STATES 8
+#define PMX_MAX_INPUTS 8
+#define PMX_MAX_OUT 4
+#define PMX_MAX_KPARAMS 8
+#define PMX_MAX_DERIVED 4
+#define PMX_MAX_FACTORS 2
+#define PMX_MAX_PARAMS 16
+#define PMX_MAX_COVARIATES 8
+
+/* ---- status codes --------------------------------------------------------- */
+/* Call-level errors mirror PharmsolError variants (src/error/mod.rs:13-49). */
+typedef enum pmx_status {
+  PMX_OK = 0,
+  PMX_ERR_INVALID_ARGUMENT = 1,
+  PMX_ERR_INPUT_OUT_OF_RANGE = 2,  /* PharmsolError::InputOutOfRange  (error/mod.rs:43; equation/mod.rs:322-327) */
+  PMX_ERR_OUTEQ_OUT_OF_RANGE = 3,  /* PharmsolError::OuteqOutOfRange  (error/mod.rs:45) */
+  PMX_ERR_UNSUPPORTED = 4,         /* feature not available on the device path yet */
+  PMX_ERR_NO_DEVICE = 5,           /* no HIP device / kernel image: the library never falls back to a CPU path */
+  PMX_ERR_HIP = 6,                 /* a HIP runtime call failed (message has the hipError string) */
+  PMX_ERR_OUT_OF_MEMORY = 7,
+  PMX_ERR_PAIR_FAILED = 8          /* at least one (subject, support point) pair failed; see the status array.
+                                      Mirrors log_likelihood_matrix aborting on the first error (matrix.rs:83,104);
+                                      predictions of the healthy pairs are still written. */
+} pmx_status;
+
+/* Per-(subject, support point) status byte written beside the predictions. */
+enum {
+  PMX_PAIR_OK = 0,
+  PMX_PAIR_COMPLEX_ROOTS = 1, /* reference panics: two_compartment_models.rs:20-22, three_compartment_models.rs:32-34 */
+  PMX_PAIR_NONFINITE = 2      /* a prediction is NaN/inf (PharmsolError::NonFiniteLikelihood-style guard) */
+};
+
+/* ---- events ---------------------------------------------------------------- */
+/* Numeric value == the reference's sort rank at equal times
+ * (Observation < Bolus < Infusion, src/data/event.rs:292-304). */
+enum { PMX_EV_OBSERVATION = 0, PMX_EV_BOLUS = 1, PMX_EV_INFUSION = 2 };
+
+/*
+ * Flattened Data -> Subject -> Occasion -> Event (src/data/structs.rs:352-355,556-560;
+ * src/data/event.rs:107-114) as structure-of-arrays with CSR offsets.  Labels are
+ * already resolved to dense indices (equation/mod.rs:247-273 does this per
+ * (subject, theta) in the reference; here it happens once on the host).
+ */
+typedef struct pmx_population_desc {
+  int64_t n_subjects;
+  int64_t n_occasions;            /* total over all subjects */
+  int64_t n_events;               /* total over all occasions */
+  const int64_t* subj_occ_off;    /* [n_subjects+1]  subject  -> occasions */
+  const int64_t* occ_ev_off;      /* [n_occasions+1] occasion -> events */
+  const int32_t* occ_index;       /* [n_occasions] Occasion::index (init runs only for index 0,
+                                     analytical/mod.rs:417); NULL = position within the subject */
+  const double* ev_time;          /* [n_events] */
+  const double* ev_value;         /* [n_events] dose amount; observed value for observations (NaN = missing; unused here) */
+  const double* ev_duration;      /* [n_events] infusion duration, 0 otherwise */
+  const uint8_t* ev_kind;         /* [n_events] PMX_EV_* */
+  const uint16_t* ev_io;          /* [n_events] dense input index (doses) / output-equation index (observations) */
+  int32_t n_covariates;           /* dense covariate columns in model order */
+  int32_t presorted;              /* 0: the library sorts each occasion like Occasion::sort (structs.rs:669-671) */
+  const int64_t* cov_knot_off;    /* [n_occasions*n_covariates+1] (occasion, covariate) -> knots; NULL iff n_covariates==0 */
+  const double* cov_knot_time;    /* covariate observations (src/data/covariate.rs:189-214) */
+  const double* cov_knot_value;
+  const uint8_t* cov_fixed;       /* [n_occasions*n_covariates] 1 = carry-forward only; NULL = all interpolated */
+} pmx_population_desc;
+
+/* ---- models ---------------------------------------------------------------- */
+/* EqnKind, src/simulator/equation/mod.rs:580-586 */
+enum { PMX_EQ_ODE = 0, PMX_EQ_ANALYTICAL = 1 };
+
+/* AnalyticalKernel, pharmsol-dsl/src/analysis.rs:187-200 (same order). */
+enum {
+  PMX_K_ONE_COMPARTMENT = 0,                        /* p = [ke]                       one_compartment_models.rs:12-19 */
+  PMX_K_ONE_COMPARTMENT_CL = 1,                     /* p = [cl, v]                    one_compartment_cl_models.rs:16-22 */
+  PMX_K_ONE_COMPARTMENT_CL_WITH_ABSORPTION = 2,     /* p = [ka, cl, v]                one_compartment_cl_models.rs:38-45 */
+  PMX_K_ONE_COMPARTMENT_WITH_ABSORPTION = 3,        /* p = [ka, ke]                   one_compartment_models.rs:32-44 */
+  PMX_K_TWO_COMPARTMENTS = 4,                       /* p = [ke, kcp, kpc]             two_compartment_models.rs:14-48 */
+  PMX_K_TWO_COMPARTMENTS_CL = 5,                    /* p = [cl, q, vc, vp]            two_compartment_cl_models.rs:16-26 */
+  PMX_K_TWO_COMPARTMENTS_CL_WITH_ABSORPTION = 6,    /* p = [ka, cl, q, vc, vp]        two_compartment_cl_models.rs:41-53 */
+  PMX_K_TWO_COMPARTMENTS_WITH_ABSORPTION = 7,       /* p = [ke, ka, kcp, kpc]         two_compartment_models.rs:61-112 */
+  PMX_K_THREE_COMPARTMENTS = 8,                     /* p = [k10,k12,k13,k21,k31]      three_compartment_models.rs:17-109 */
+  PMX_K_THREE_COMPARTMENTS_CL = 9,                  /* p = [cl,q2,q3,vc,v2,v3]        three_compartment_cl_models.rs:16-31 */
+  PMX_K_THREE_COMPARTMENTS_CL_WITH_ABSORPTION = 10, /* p = [ka,cl,q2,q3,vc,v2,v3]     three_compartment_cl_models.rs:46-67 */
+  PMX_K_THREE_COMPARTMENTS_WITH_ABSORPTION = 11,    /* p = [ka,k10,k12,k13,k21,k31]   three_compartment_models.rs:126-240 */
+  PMX_K_ANALYTICAL_COUNT = 12
+};
+
+/* Built-in `diffeq` bodies for the ODE back-end (device functor registry; the
+ * reference takes a Rust closure, src/simulator/mod.rs:41).  Route injection
+ * follows the `ode!` lowering: dx[dest] += rateiv[i] per infusion route
+ * (pharmsol-macros/src/expand/ode.rs:380-406). */
+enum {
+  PMX_ODE_ONE_CMT_IV = 0,     /* dx0 = -ke x0 + r0                         p=[ke,...]   examples/ode_readme.rs:9-23 */
+  PMX_ODE_ONE_CMT_ORAL = 1,   /* dx0 = -ka x0; dx1 = ka x0 - ke x1 + r0    p=[ka,ke,...] */
+  PMX_ODE_TWO_CMT_IV = 2,     /* two_compartment_models.rs:131-136 test ODE p=[ke,kcp,kpc,...] */
+  PMX_ODE_TWO_CMT_ORAL = 3,   /* two_compartment_models.rs:188-194 test ODE p=[ke,ka,kcp,kpc,...] */
+  PMX_ODE_THREE_CMT_IV = 4,   /* three_compartment_models.rs test ODE      p=[k10,k12,k13,k21,k31,...] */
+  PMX_ODE_THREE_CMT_ORAL = 5, /* p=[ka,k10,k12,k13,k21,k31,...] */
+  PMX_ODE_ONE_CMT_MM = 6,     /* nonlinear: dx0 = -vmax*(x0/v)/(km + x0/v) + r0   p=[vmax,km,v] */
+  PMX_ODE_MODEL_COUNT = 7
+};
+
+/* Where a value is read from. */
+enum { PMX_SRC_NONE = 0, PMX_SRC_PRIMARY = 1 /* theta[index] */, PMX_SRC_DERIVED = 2 /* derived[index] */ };
+
+/* One multiplicative covariate factor of a derived parameter. */
+enum { PMX_F_NONE = 0, PMX_F_POW = 1 /* (cov/ref)^coef */, PMX_F_LIN = 2 /* 1 + coef*(cov-ref) */ };
+typedef struct pmx_factor {
+  int32_t op;
+  int32_t cov;  /* dense covariate index */
+  double ref;
+  double coef;
+} pmx_factor;
+
+/* derived[d] = ((theta[src_param] * f[0]) * f[1])  — the `derive:` block of
+ * analytical!/ode! restricted to allometric form
+ * (examples/analytical_readme.rs:18-20: ke = ke0 * (wt/70)^0.75). */
+typedef struct pmx_derived {
+  int32_t src_param;
+  int32_t n_factors;
+  pmx_factor f[PMX_MAX_FACTORS];
+} pmx_derived;
+
+/* Kernel-order parameter j <- theta[index] | derived[index]
+ * (the macro's projection wrapper, pharmsol-macros/src/expand/analytical.rs:208-294). */
+typedef struct pmx_bind {
+  int32_t src;
+  int32_t index;
+} pmx_bind;
+
+/* y[o] = x[state] / vol,   vol = theta[vol_index] | derived[vol_index] | 1
+ * (every reference example/bench: y = x[central]/v, e.g. examples/analytical_vs_ode.rs:82-84). */
+typedef struct pmx_out {
+  int32_t state;
+  int32_t vol_src;
+  int32_t vol_index;
+  int32_t reserved;
+} pmx_out;
+
+/* Which time the analytical `derive` block sees:
+ *  SEGMENT_DT      = the macro lowering: derive(p, dt, cov) — covariates at the
+ *                    segment LENGTH (expand/analytical.rs:254,286; analytical/mod.rs:363-364)
+ *  SEGMENT_END_ABS = the DSL runtime: derived refreshed at absolute next_t (src/dsl/native.rs:1907-1916) */
+enum { PMX_COV_TIME_SEGMENT_DT = 0, PMX_COV_TIME_SEGMENT_END_ABS = 1 };
+
+typedef struct pmx_model_desc {
+  int32_t eq_kind;       /* PMX_EQ_ANALYTICAL | PMX_EQ_ODE */
+  int32_t kernel;        /* PMX_K_* or PMX_ODE_* */
+  int32_t nstates;       /* Analytical::with_nstates  analytical/mod.rs:120 */
+  int32_t ndrugs;        /* Analytical::with_ndrugs   analytical/mod.rs:127 */
+  int32_t nout;          /* Analytical::with_nout     analytical/mod.rs:134 */
+  int32_t nparams;       /* length of one support point (Parameters::as_slice, parameters.rs:94) */
+  int32_t n_covariates;
+  int32_t n_derived;
+  pmx_derived derived[PMX_MAX_DERIVED];
+  int32_t n_bind;        /* 0 = identity (kernel param j = theta[j]) */
+  pmx_bind bind[PMX_MAX_KPARAMS];
+  pmx_out out[PMX_MAX_OUT];
+  int32_t cov_time_mode; /* PMX_COV_TIME_* (analytical only; ODE covariates use absolute t, expand/ode.rs:150) */
+  int32_t pmetrics_indexing; /* 1 = pm_* wrapper: state/rateiv slot 0 is a dead pad (analytical/mod.rs:62-90) */
+  /* init: x[i] = theta[init_param[i]] for occasion index 0 only (analytical/mod.rs:409-426); -1 = 0.0 */
+  int32_t init_param[PMX_MAX_STATES];
+  /* lag[input] = theta[lag_param[input]], fa[input] = theta[fa_param[input]]; -1 = absent
+   * (Occasion::process_events, src/data/structs.rs:611-690). */
+  int32_t lag_param[PMX_MAX_INPUTS];
+  int32_t fa_param[PMX_MAX_INPUTS];
+  /* ODE route destinations (`ode!` routes, e.g. bolus(oral) -> gut, infusion(iv) -> central;
+   * pharmsol-macros/src/expand/ode.rs:380-406): the state that receives bolus input i /
+   * infusion input i.  -1 = default (bolus: state i; infusion: the model's central state).
+   * Analytical ignores these: a bolus goes to x[input] and the closed forms read rateiv[0]
+   * only (equation/mod.rs:328; one_compartment_models.rs:16). */
+  int32_t bolus_dest[PMX_MAX_INPUTS];
+  int32_t infusion_dest[PMX_MAX_INPUTS];
+  double rk4_h_max;     /* ODE: fixed-step RK4, h = dt/ceil(dt/h_max) per constant-rate piece */
+} pmx_model_desc;
+
+typedef struct pmx_population pmx_population; /* opaque */
+typedef struct pmx_model pmx_model;           /* opaque */
+
+/* Layout of the prediction tensor written by pmx_predict*:
+ *   pred[(obs_row) * ld_pred + p],  obs_row = running index of the observation over
+ *   all subjects in event order (SubjectPredictions::flat_predictions order,
+ *   likelihood/subject.rs:145-148), p = support point.  ld_pred >= n_support. */
+
+/* ---- entry points ---------------------------------------------------------- */
+
+int32_t pmx_abi_version(void);
+
+/* Number of visible HIP devices (0 when none; never initialises a context). */
+int32_t pmx_device_count(void);
+
+/* Flatten + upload a population.  Replaces Data/Subject construction + the
+ * per-(subject,theta) Occasion::clone/sort of equation/mod.rs:247-273.
+ * `device` = HIP device ordinal the mirrors live on. */
+int32_t pmx_population_create(const pmx_population_desc* desc, int32_t device, pmx_population** out);
+void pmx_population_destroy(pmx_population* pop);
+
+/* Sizes a caller needs to allocate outputs. */
+int64_t pmx_population_n_subjects(const pmx_population* pop);
+int64_t pmx_population_n_observations(const pmx_population* pop); /* rows of pred */
+int64_t pmx_population_n_events(const pmx_population* pop);       /* subject-event-steps per support point */
+/* obs_off[n_subjects+1]: first prediction row of each subject. */
+int32_t pmx_population_observation_offsets(const pmx_population* pop, int64_t* obs_off);
+/* Per prediction row: time / outeq / subject of the observation, in prediction
+ * order (what Observation::to_prediction re-attaches, event.rs:698-711). Any pointer may be NULL. */
+int32_t pmx_population_observation_info(const pmx_population* pop, double* time, int32_t* outeq, int64_t* subject);
+
+/* Replaces Analytical::new(...).with_nstates()... / ODE::new(...) (analytical/mod.rs:102-152, ode/mod.rs:115-166). */
+int32_t pmx_model_create(const pmx_model_desc* desc, pmx_model** out);
+void pmx_model_destroy(pmx_model* model);
+
+/* Population prediction: every subject x every support point.
+ *   theta  [n_support x nparams] row-major (ParameterOrder::matrix rows, matrix.rs:62-65)
+ *   pred   [n_observations x ld_pred]
+ *   status [n_subjects x n_support] bytes (PMX_PAIR_*), may be NULL
+ * Host-pointer form: copies theta in and pred/status out (PCIe inclusive). */
+int32_t pmx_predict(const pmx_model* model, const pmx_population* pop, const double* theta, int64_t n_support,
+                    double* pred, int64_t ld_pred, uint8_t* status);
+
+/* Device-pointer form: theta/pred/status are device pointers on the population's
+ * device; the launch is enqueued on `stream` (a hipStream_t, NULL = default
+ * stream) and NOT synchronised.  This is the form bench.py times. */
+int32_t pmx_predict_device(const pmx_model* model, const pmx_population* pop, const double* d_theta,
+                           int64_t n_support, double* d_pred, int64_t ld_pred, uint8_t* d_status, void* stream);
+
+/* "Batch" form (log_likelihood_batch shape, likelihood/mod.rs:119-177): subject s
+ * is simulated with its own row theta[s] only.  pred is [n_observations] (ld 1),
+ * status [n_subjects]. */
+int32_t pmx_predict_batch(const pmx_model* model, const pmx_population* pop, const double* theta, double* pred,
+                          uint8_t* status);
+int32_t pmx_predict_batch_device(const pmx_model* model, const pmx_population* pop, const double* d_theta,
+                                 double* d_pred, uint8_t* d_status, void* stream);
+
+/* Name of the device kernel the last pmx_predict* call on this thread launched
+ * (for matching rocprofv3 rows), and its launch geometry. */
+const char* pmx_last_kernel_name(void);
+
+/* Message of the last failing call made by this thread ("" if none). */
+const char* pmx_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PMX_H */

@@ -1,0 +1,67 @@
+/*
+ * pmx_oracle.h — CPU ORACLE for the pharmsol prediction hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under pharmsol_amd/ (the product) may
+ * include, link or call this.  Allowed callers: tests/, __graft_entry__.smoke(),
+ * and bench.py's cpu_baseline leg.
+ *
+ * It is a plain-C restatement of the reference algorithm (LAPKB/pharmsol
+ * v0.28.8, Rust), one (subject, support point) at a time, in the reference's
+ * operation order; every function cites the reference file:line it follows.
+ * The reference is Rust and cannot be compiled here (no cargo/rustc), and it
+ * holds no golden prediction vectors; this oracle is pinned by the reference's
+ * own known-answer tests (tests/test_oracle_known_answers.py) and by
+ * independent mathematics (scipy expm / closed forms, tests/golden/).
+ * ODE integration in the reference is the un-vendored crate diffsol =0.16.1;
+ * step-level parity with it is UNPINNED (results pinned to closed forms only).
+ */
+#ifndef PMX_ORACLE_H
+#define PMX_ORACLE_H
+
+#include "../include/pmx.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Oracle-only analytical "kernels" that reproduce the closures of the
+ * reference's known-answer tests (not pharmacometric models):
+ *  100: eq x0 += p0*dt, seq_eq p0 += 1      analytical/mod.rs:493-527  (expects 2.5)
+ *  101: eq x0 += rateiv[3]*dt               analytical/mod.rs:530-560  (expects 4.0)
+ */
+#define PMX_ORACLE_K_TEST_SEQ_ACCUM 100
+#define PMX_ORACLE_K_TEST_RATEIV3 101
+
+/* Same contract as pmx_predict (include/pmx.h), computed on the CPU.
+ * Loop nest = log_likelihood_matrix (likelihood/matrix.rs:79-98): parallel over
+ * subjects (OpenMP, schedule(dynamic)), serial over support points.
+ * nthreads <= 0 -> omp default. Returns a pmx_status. */
+int32_t pmx_oracle_predict(const pmx_model_desc* model, const pmx_population_desc* pop, const double* theta,
+                           int64_t n_support, double* pred, int64_t ld_pred, uint8_t* status, int32_t nthreads);
+
+/* Batch shape (likelihood/mod.rs:119-177): subject s with theta row s. */
+int32_t pmx_oracle_predict_batch(const pmx_model_desc* model, const pmx_population_desc* pop, const double* theta,
+                                 double* pred, uint8_t* status, int32_t nthreads);
+
+/* One call of a closed-form kernel: xout = kernel(x, p, t, rateiv)
+ * (AnalyticalEq, src/simulator/mod.rs:54).  pm != 0 selects the pm_* wrapper
+ * (analytical/mod.rs:78-90).  Returns 0, or PMX_PAIR_COMPLEX_ROOTS. */
+int32_t pmx_oracle_kernel(int32_t kernel, int32_t pm, const double* x, const double* p, double t,
+                          const double* rateiv, double* xout);
+
+/* Covariate::interpolate (src/data/covariate.rs:216-241) on one knot list. */
+int32_t pmx_oracle_cov_interpolate(const double* knot_time, const double* knot_value, int64_t n_knots, int32_t fixed,
+                                   double t, double* value);
+
+/* Number of subject-event-steps in a population (events per subject summed). */
+int64_t pmx_oracle_n_observations(const pmx_population_desc* pop);
+
+const char* pmx_oracle_last_error(void);
+int64_t pmx_oracle_sizeof_model_desc(void);
+int64_t pmx_oracle_sizeof_population_desc(void);
+int32_t pmx_oracle_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

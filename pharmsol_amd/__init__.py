@@ -1,0 +1,22 @@
+"""pharmsol_amd — MI355X-native batched PK/PD prediction (pharmsol's
+``Equation::estimate_predictions`` hot path, subject x support-point).
+
+Host-side mirror of the reference interface for that path (``Subject`` builder,
+``Parameters``, ``Analytical`` / ``ODE`` equations) over the C ABI of
+``libpmx_hip.so`` (``include/pmx.h``).  All compute is hand-written HIP for
+gfx950; there is no CPU fallback (the CPU oracle lives under ``oracle/`` and is
+test infrastructure only).
+"""
+from .data import Bolus, Covariates, Data, Event, Infusion, Observation, Occasion, Subject, SubjectBuilder
+from .equation import (ODE, Analytical, Equation, LabelError, Lin, Pow, Ratio, Route, Scaled, analytical, bolus,
+                       infusion, ode)
+from .flatten import FlatPopulation, flatten
+from .parameters import Parameters
+from .predictions import Prediction, SubjectPredictions
+from ._abi import PmxError
+
+__all__ = [
+    "Bolus", "Covariates", "Data", "Event", "Infusion", "Observation", "Occasion", "Subject", "SubjectBuilder",
+    "ODE", "Analytical", "Equation", "LabelError", "Lin", "Pow", "Ratio", "Route", "Scaled", "analytical", "bolus",
+    "infusion", "ode", "FlatPopulation", "flatten", "Parameters", "Prediction", "SubjectPredictions", "PmxError",
+]

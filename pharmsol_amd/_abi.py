@@ -1,0 +1,199 @@
+"""ctypes mirror of ``include/pmx.h`` (struct layouts and enum values).
+
+Shared by the product binding (``_ffi.py`` -> libpmx_hip.so) and by the test
+oracle's binding (``oracle/__init__.py`` -> libpmx_oracle.so); it holds no
+compute.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+PMX_ABI_VERSION = 1
+
+PMX_MAX_STATES = 8
+PMX_MAX_INPUTS = 8
+PMX_MAX_OUT = 4
+PMX_MAX_KPARAMS = 8
+PMX_MAX_DERIVED = 4
+PMX_MAX_FACTORS = 2
+PMX_MAX_PARAMS = 16
+PMX_MAX_COVARIATES = 8
+
+# pmx_status
+PMX_OK = 0
+PMX_ERR_INVALID_ARGUMENT = 1
+PMX_ERR_INPUT_OUT_OF_RANGE = 2
+PMX_ERR_OUTEQ_OUT_OF_RANGE = 3
+PMX_ERR_UNSUPPORTED = 4
+PMX_ERR_NO_DEVICE = 5
+PMX_ERR_HIP = 6
+PMX_ERR_OUT_OF_MEMORY = 7
+PMX_ERR_PAIR_FAILED = 8
+
+PMX_PAIR_OK = 0
+PMX_PAIR_COMPLEX_ROOTS = 1
+PMX_PAIR_NONFINITE = 2
+
+PMX_EV_OBSERVATION = 0
+PMX_EV_BOLUS = 1
+PMX_EV_INFUSION = 2
+
+PMX_EQ_ODE = 0
+PMX_EQ_ANALYTICAL = 1
+
+# AnalyticalKernel (pharmsol-dsl/src/analysis.rs:187-200), name -> id
+ANALYTICAL_KERNELS = {
+    "one_compartment": 0,
+    "one_compartment_cl": 1,
+    "one_compartment_cl_with_absorption": 2,
+    "one_compartment_with_absorption": 3,
+    "two_compartments": 4,
+    "two_compartments_cl": 5,
+    "two_compartments_cl_with_absorption": 6,
+    "two_compartments_with_absorption": 7,
+    "three_compartments": 8,
+    "three_compartments_cl": 9,
+    "three_compartments_cl_with_absorption": 10,
+    "three_compartments_with_absorption": 11,
+}
+
+# AnalyticalKernel::required_parameter_names (analysis.rs:240-255)
+KERNEL_PARAMETER_NAMES = {
+    "one_compartment": ["ke"],
+    "one_compartment_cl": ["cl", "v"],
+    "one_compartment_cl_with_absorption": ["ka", "cl", "v"],
+    "one_compartment_with_absorption": ["ka", "ke"],
+    "two_compartments": ["ke", "kcp", "kpc"],
+    "two_compartments_cl": ["cl", "q", "vc", "vp"],
+    "two_compartments_cl_with_absorption": ["ka", "cl", "q", "vc", "vp"],
+    "two_compartments_with_absorption": ["ke", "ka", "kcp", "kpc"],
+    "three_compartments": ["k10", "k12", "k13", "k21", "k31"],
+    "three_compartments_cl": ["cl", "q2", "q3", "vc", "v2", "v3"],
+    "three_compartments_cl_with_absorption": ["ka", "cl", "q2", "q3", "vc", "v2", "v3"],
+    "three_compartments_with_absorption": ["ka", "k10", "k12", "k13", "k21", "k31"],
+}
+
+# AnalyticalKernel::state_count (analysis.rs:259-270)
+KERNEL_STATE_COUNT = {
+    "one_compartment": 1,
+    "one_compartment_cl": 1,
+    "one_compartment_cl_with_absorption": 2,
+    "one_compartment_with_absorption": 2,
+    "two_compartments": 2,
+    "two_compartments_cl": 2,
+    "two_compartments_cl_with_absorption": 3,
+    "two_compartments_with_absorption": 3,
+    "three_compartments": 3,
+    "three_compartments_cl": 3,
+    "three_compartments_cl_with_absorption": 4,
+    "three_compartments_with_absorption": 4,
+}
+
+ODE_MODELS = {
+    "one_cmt_iv": 0,
+    "one_cmt_oral": 1,
+    "two_cmt_iv": 2,
+    "two_cmt_oral": 3,
+    "three_cmt_iv": 4,
+    "three_cmt_oral": 5,
+    "one_cmt_mm": 6,
+}
+ODE_STATE_COUNT = {"one_cmt_iv": 1, "one_cmt_oral": 2, "two_cmt_iv": 2, "two_cmt_oral": 3, "three_cmt_iv": 3,
+                   "three_cmt_oral": 4, "one_cmt_mm": 1}
+ODE_PARAM_COUNT = {"one_cmt_iv": 1, "one_cmt_oral": 2, "two_cmt_iv": 3, "two_cmt_oral": 4, "three_cmt_iv": 5,
+                   "three_cmt_oral": 6, "one_cmt_mm": 3}
+
+PMX_SRC_NONE = 0
+PMX_SRC_PRIMARY = 1
+PMX_SRC_DERIVED = 2
+
+PMX_F_NONE = 0
+PMX_F_POW = 1
+PMX_F_LIN = 2
+
+PMX_COV_TIME_SEGMENT_DT = 0
+PMX_COV_TIME_SEGMENT_END_ABS = 1
+
+STATUS_NAMES = {
+    PMX_OK: "OK",
+    PMX_ERR_INVALID_ARGUMENT: "InvalidArgument",
+    PMX_ERR_INPUT_OUT_OF_RANGE: "InputOutOfRange",
+    PMX_ERR_OUTEQ_OUT_OF_RANGE: "OuteqOutOfRange",
+    PMX_ERR_UNSUPPORTED: "Unsupported",
+    PMX_ERR_NO_DEVICE: "NoDevice",
+    PMX_ERR_HIP: "HipError",
+    PMX_ERR_OUT_OF_MEMORY: "OutOfMemory",
+    PMX_ERR_PAIR_FAILED: "PairFailed",
+}
+
+
+class pmx_population_desc(C.Structure):
+    _fields_ = [
+        ("n_subjects", C.c_int64),
+        ("n_occasions", C.c_int64),
+        ("n_events", C.c_int64),
+        ("subj_occ_off", C.POINTER(C.c_int64)),
+        ("occ_ev_off", C.POINTER(C.c_int64)),
+        ("occ_index", C.POINTER(C.c_int32)),
+        ("ev_time", C.POINTER(C.c_double)),
+        ("ev_value", C.POINTER(C.c_double)),
+        ("ev_duration", C.POINTER(C.c_double)),
+        ("ev_kind", C.POINTER(C.c_uint8)),
+        ("ev_io", C.POINTER(C.c_uint16)),
+        ("n_covariates", C.c_int32),
+        ("presorted", C.c_int32),
+        ("cov_knot_off", C.POINTER(C.c_int64)),
+        ("cov_knot_time", C.POINTER(C.c_double)),
+        ("cov_knot_value", C.POINTER(C.c_double)),
+        ("cov_fixed", C.POINTER(C.c_uint8)),
+    ]
+
+
+class pmx_factor(C.Structure):
+    _fields_ = [("op", C.c_int32), ("cov", C.c_int32), ("ref", C.c_double), ("coef", C.c_double)]
+
+
+class pmx_derived(C.Structure):
+    _fields_ = [("src_param", C.c_int32), ("n_factors", C.c_int32), ("f", pmx_factor * PMX_MAX_FACTORS)]
+
+
+class pmx_bind(C.Structure):
+    _fields_ = [("src", C.c_int32), ("index", C.c_int32)]
+
+
+class pmx_out(C.Structure):
+    _fields_ = [("state", C.c_int32), ("vol_src", C.c_int32), ("vol_index", C.c_int32), ("reserved", C.c_int32)]
+
+
+class pmx_model_desc(C.Structure):
+    _fields_ = [
+        ("eq_kind", C.c_int32),
+        ("kernel", C.c_int32),
+        ("nstates", C.c_int32),
+        ("ndrugs", C.c_int32),
+        ("nout", C.c_int32),
+        ("nparams", C.c_int32),
+        ("n_covariates", C.c_int32),
+        ("n_derived", C.c_int32),
+        ("derived", pmx_derived * PMX_MAX_DERIVED),
+        ("n_bind", C.c_int32),
+        ("bind", pmx_bind * PMX_MAX_KPARAMS),
+        ("out", pmx_out * PMX_MAX_OUT),
+        ("cov_time_mode", C.c_int32),
+        ("pmetrics_indexing", C.c_int32),
+        ("init_param", C.c_int32 * PMX_MAX_STATES),
+        ("lag_param", C.c_int32 * PMX_MAX_INPUTS),
+        ("fa_param", C.c_int32 * PMX_MAX_INPUTS),
+        ("bolus_dest", C.c_int32 * PMX_MAX_INPUTS),
+        ("infusion_dest", C.c_int32 * PMX_MAX_INPUTS),
+        ("rk4_h_max", C.c_double),
+    ]
+
+
+class PmxError(RuntimeError):
+    """A failed C-ABI call (the Python face of ``PharmsolError``, src/error/mod.rs:13-49)."""
+
+    def __init__(self, status: int, message: str):
+        self.status = status
+        self.status_name = STATUS_NAMES.get(status, str(status))
+        super().__init__(f"{self.status_name}: {message}")

@@ -1,0 +1,422 @@
+"""``Equation`` surface: ``Analytical`` and ``ODE`` models + ``estimate_predictions``.
+
+Python mirror of the reference's model-authoring and simulation entry points:
+
+* ``analytical(...)`` / ``ode(...)``  ~ the ``analytical!`` / ``ode!`` declarations
+  (pharmsol-macros/src/expand/analytical.rs:31-135, expand/ode.rs:126-185)
+* ``Analytical.new(...)`` / ``ODE.new(...)`` + ``with_nstates/ndrugs/nout``
+  ~ src/simulator/equation/analytical/mod.rs:102-152, ode/mod.rs:115-166
+* ``Equation.estimate_predictions(subject, parameters)`` ~ equation/mod.rs:526-532
+* ``Equation.estimate_predictions_matrix(data, theta)`` ~ the subjects x support
+  points loop nest of likelihood/matrix.rs:79-98 (one HIP launch here)
+
+The reference takes Rust closures for eq/derive/out/init/lag/fa.  The device needs
+closed descriptions, so closures are restricted to the declarative forms of
+``include/pmx.h`` (built-in structures, allometric ``derive``, ``x[state]/v`` outputs).
+
+All compute goes through ``libpmx_hip.so`` (``_ffi``); there is no CPU fallback.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import _abi
+from .data import Data, Subject
+from .flatten import FlatPopulation, flatten
+from .parameters import Parameters
+from .predictions import SubjectPredictions, Prediction
+
+
+# ---------------------------------------------------------------------------
+# declarative closure forms
+# ---------------------------------------------------------------------------
+@dataclass(frozen=True)
+class Pow:
+    """``(cov / ref).powf(coef)``"""
+    cov: str
+    ref: float
+    coef: float
+
+
+@dataclass(frozen=True)
+class Lin:
+    """``1.0 + coef * (cov - ref)``"""
+    cov: str
+    ref: float
+    coef: float
+
+
+@dataclass(frozen=True)
+class Scaled:
+    """``derived = param * f0 * f1`` — one line of a ``derive:`` block."""
+    param: str
+    factors: Tuple[Union[Pow, Lin], ...] = ()
+
+
+@dataclass(frozen=True)
+class Ratio:
+    """``y[out] = x[state] / vol`` — one line of an ``out:`` block (vol None = 1)."""
+    state: Union[str, int]
+    vol: Optional[Union[str, int]] = None
+
+
+@dataclass(frozen=True)
+class Route:
+    """``bolus(oral) -> gut`` / ``infusion(iv) -> central`` (equation/metadata.rs Route)."""
+    kind: str  # "bolus" | "infusion"
+    name: str
+    dest: Union[str, int]
+
+
+def bolus(name: str, dest) -> Route:
+    return Route("bolus", name, dest)
+
+
+def infusion(name: str, dest) -> Route:
+    return Route("infusion", name, dest)
+
+
+class LabelError(KeyError):
+    """PharmsolError::UnknownInputLabel / UnknownOutputLabel / UnsupportedInputRouteKind."""
+
+
+def _is_bare_numeric(label: str) -> bool:
+    return label.isdigit()
+
+
+class Equation:
+    """Common model state + the simulation entry points."""
+
+    eq_kind: int = -1
+
+    def __init__(self):
+        self.name = ""
+        self.params: List[str] = []
+        self.derived: Dict[str, Scaled] = {}
+        self.covariates: List[str] = []
+        self.states: List[str] = []
+        self.outputs: List[str] = []
+        self.routes: List[Route] = []
+        self.out: Dict[Union[str, int], Ratio] = {}
+        self.init: Dict[Union[str, int], str] = {}
+        self.lag: Dict[str, str] = {}
+        self.fa: Dict[str, str] = {}
+        self.has_metadata = False
+        self.nstates = 5  # Neqs::default(): all sizes = 5 (analytical/mod.rs:93)
+        self.ndrugs = 5
+        self.nout = 5
+        self.nparams: Optional[int] = None
+        self.kernel_name = ""
+        self.cov_time = "segment_dt"
+        self.pmetrics = False
+        self.rk4_h_max = 0.02
+        self._handle = None  # lazily created pmx_model*
+
+    # -- builder methods (analytical/mod.rs:120-138) ---------------------------
+    def with_nstates(self, n: int):
+        self.nstates = int(n)
+        self._handle = None
+        return self
+
+    def with_ndrugs(self, n: int):
+        self.ndrugs = int(n)
+        self._handle = None
+        return self
+
+    def with_nout(self, n: int):
+        self.nout = int(n)
+        self._handle = None
+        return self
+
+    # -- metadata lookups ------------------------------------------------------
+    def parameter_index(self, name: str) -> Optional[int]:
+        return self.params.index(name) if name in self.params else None
+
+    def state_index(self, name) -> Optional[int]:
+        if isinstance(name, int):
+            return name
+        return self.states.index(name) if name in self.states else None
+
+    def covariate_index(self, name: str) -> Optional[int]:
+        return self.covariates.index(name) if name in self.covariates else None
+
+    def _route_inputs(self) -> List[Tuple[Route, int]]:
+        # bolus and infusion routes are numbered independently, in declaration order
+        # (metadata.rs:926-946; symbols.rs:189-211)
+        nb = ni = 0
+        out = []
+        for r in self.routes:
+            if r.kind == "bolus":
+                out.append((r, nb))
+                nb += 1
+            else:
+                out.append((r, ni))
+                ni += 1
+        return out
+
+    def resolve_input_label(self, label, kind: str) -> int:
+        """``EquationPriv::resolve_input_label`` (equation/mod.rs:195-233)."""
+        s = str(label)
+        if self.has_metadata:
+            routes = self._route_inputs()
+            for r, idx in routes:
+                if r.kind == kind and r.name == s:
+                    return idx
+            if _is_bare_numeric(s):  # canonical alias input_<n> (metadata.rs:248-262)
+                for r, idx in routes:
+                    if r.kind == kind and r.name == f"input_{s}":
+                        return idx
+            for r, idx in routes:
+                if r.kind != kind and (r.name == s or (_is_bare_numeric(s) and r.name == f"input_{s}")):
+                    raise LabelError(f"UnsupportedInputRouteKind: input {idx} is not a {kind} route")
+            raise LabelError(f"unknown input label '{s}'; available: {[r.name for r in self.routes]}")
+        if not s.isdigit():
+            raise LabelError(f"unknown input label '{s}' (no metadata: labels must be dense indices)")
+        return int(s)
+
+    def resolve_output_label(self, label) -> int:
+        """``EquationPriv::resolve_output_label`` (equation/mod.rs:235-245)."""
+        s = str(label)
+        if self.has_metadata:
+            if s in self.outputs:
+                return self.outputs.index(s)
+            if _is_bare_numeric(s) and f"outeq_{s}" in self.outputs:
+                return self.outputs.index(f"outeq_{s}")
+            raise LabelError(f"unknown output label '{s}'; available: {self.outputs}")
+        if not s.isdigit():
+            raise LabelError(f"unknown output label '{s}' (no metadata: labels must be dense indices)")
+        return int(s)
+
+    # -- lowering to the C descriptor -----------------------------------------
+    def _value_src(self, name) -> Tuple[int, int]:
+        if isinstance(name, int):
+            return (_abi.PMX_SRC_PRIMARY, name)
+        if name in self.params:
+            return (_abi.PMX_SRC_PRIMARY, self.params.index(name))
+        if name in self.derived:
+            return (_abi.PMX_SRC_DERIVED, list(self.derived).index(name))
+        raise KeyError(f"'{name}' is neither a parameter nor a derived value")
+
+    def _required_names(self) -> List[str]:
+        raise NotImplementedError
+
+    def desc(self) -> _abi.pmx_model_desc:
+        d = _abi.pmx_model_desc()
+        d.eq_kind = self.eq_kind
+        d.kernel = self._kernel_id()
+        d.nstates, d.ndrugs, d.nout = self.nstates, self.ndrugs, self.nout
+        nparams = self.nparams if self.nparams is not None else len(self.params)
+        d.nparams = nparams
+        d.n_covariates = len(self.covariates)
+        if len(self.derived) > _abi.PMX_MAX_DERIVED:
+            raise ValueError("too many derived values")
+        d.n_derived = len(self.derived)
+        for i, (name, sc) in enumerate(self.derived.items()):
+            dd = d.derived[i]
+            dd.src_param = self.params.index(sc.param)
+            dd.n_factors = len(sc.factors)
+            if len(sc.factors) > _abi.PMX_MAX_FACTORS:
+                raise ValueError("too many covariate factors in one derived value")
+            for k, f in enumerate(sc.factors):
+                dd.f[k].op = _abi.PMX_F_POW if isinstance(f, Pow) else _abi.PMX_F_LIN
+                dd.f[k].cov = self.covariates.index(f.cov)
+                dd.f[k].ref = f.ref
+                dd.f[k].coef = f.coef
+        # kernel-order binding (expand/analytical.rs:208-294): identity when the
+        # required names are the leading params in kernel order.
+        req = self._required_names()
+        d.n_bind = 0
+        if req and self.params:
+            binds = [self._value_src(n) for n in req]
+            identity = all(src == _abi.PMX_SRC_PRIMARY and idx == j for j, (src, idx) in enumerate(binds))
+            if not identity:
+                d.n_bind = len(binds)
+                for j, (src, idx) in enumerate(binds):
+                    d.bind[j].src, d.bind[j].index = src, idx
+        # outputs
+        for o in range(_abi.PMX_MAX_OUT):
+            d.out[o].state, d.out[o].vol_src, d.out[o].vol_index = 0, _abi.PMX_SRC_NONE, 0
+        for key, r in self.out.items():
+            o = self.outputs.index(key) if isinstance(key, str) else int(key)
+            st = self.state_index(r.state)
+            if st is None:
+                raise KeyError(f"unknown state {r.state}")
+            d.out[o].state = st
+            if r.vol is None:
+                d.out[o].vol_src = _abi.PMX_SRC_NONE
+            else:
+                d.out[o].vol_src, d.out[o].vol_index = self._value_src(r.vol)
+        d.cov_time_mode = (_abi.PMX_COV_TIME_SEGMENT_DT if self.cov_time == "segment_dt" else
+                           _abi.PMX_COV_TIME_SEGMENT_END_ABS)
+        d.pmetrics_indexing = 1 if self.pmetrics else 0
+        for i in range(_abi.PMX_MAX_STATES):
+            d.init_param[i] = -1
+        for key, pname in self.init.items():
+            d.init_param[self.state_index(key)] = self.params.index(pname) if isinstance(pname, str) else int(pname)
+        for i in range(_abi.PMX_MAX_INPUTS):
+            d.lag_param[i] = d.fa_param[i] = -1
+            d.bolus_dest[i] = d.infusion_dest[i] = -1
+        for label, pname in self.lag.items():
+            d.lag_param[self.resolve_input_label(label, "bolus")] = (
+                self.params.index(pname) if isinstance(pname, str) else int(pname))
+        for label, pname in self.fa.items():
+            d.fa_param[self.resolve_input_label(label, "bolus")] = (
+                self.params.index(pname) if isinstance(pname, str) else int(pname))
+        for r, idx in self._route_inputs():
+            dest = self.state_index(r.dest)
+            if r.kind == "bolus":
+                d.bolus_dest[idx] = dest
+            else:
+                d.infusion_dest[idx] = dest
+        d.rk4_h_max = self.rk4_h_max
+        return d
+
+    def _kernel_id(self) -> int:
+        raise NotImplementedError
+
+    # -- simulation -------------------------------------------------------------
+    def flatten(self, data) -> FlatPopulation:
+        return flatten(self, data)
+
+    def estimate_predictions(self, subject: Subject, parameters) -> SubjectPredictions:
+        """``Equation::estimate_predictions`` (equation/mod.rs:526-532) for one subject and one
+        support point, on the GPU."""
+        theta = parameters.as_slice() if isinstance(parameters, Parameters) else np.asarray(parameters, dtype=np.float64)
+        flat = self.flatten(subject)
+        from . import runtime
+        pred, status = runtime.predict_host(self, flat, theta.reshape(1, -1))
+        return SubjectPredictions.from_flat(subject, self, pred[:, 0])
+
+    def estimate_predictions_matrix(self, data, theta: np.ndarray):
+        """All subjects x all support points (likelihood/matrix.rs:79-98 loop nest).
+
+        Returns ``(pred[n_observations, n_support], status[n_subjects, n_support])`` as numpy arrays
+        (host-pointer ABI form).  Use ``runtime.DevicePopulation`` for the resident form.
+        """
+        flat = data if isinstance(data, FlatPopulation) else self.flatten(data)
+        from . import runtime
+        return runtime.predict_host(self, flat, np.ascontiguousarray(theta, dtype=np.float64))
+
+
+class Analytical(Equation):
+    """Closed-form model (src/simulator/equation/analytical/mod.rs:48-59)."""
+
+    eq_kind = _abi.PMX_EQ_ANALYTICAL
+
+    @staticmethod
+    def new(eq: str, out: Dict[int, Ratio], *, nparams: int, init: Optional[Dict[int, int]] = None,
+            lag: Optional[Dict[int, int]] = None, fa: Optional[Dict[int, int]] = None) -> "Analytical":
+        """``Analytical::new(eq, seq_eq, lag, fa, init, out)`` with a built-in ``eq`` (by name; a ``pm_``
+        prefix selects the Pmetrics 1-indexed wrapper) and index-based closures.  No metadata:
+        data labels must be dense numeric indices."""
+        m = Analytical()
+        if eq.startswith("pm_"):
+            m.pmetrics = True
+            eq = eq[3:]
+        if eq not in _abi.ANALYTICAL_KERNELS:
+            raise KeyError(f"unknown analytical structure '{eq}'")
+        m.kernel_name = eq
+        m.out = dict(out)
+        m.nparams = int(nparams)
+        m.init = dict(init or {})
+        m.lag = {str(k): v for k, v in (lag or {}).items()}
+        m.fa = {str(k): v for k, v in (fa or {}).items()}
+        return m
+
+    def _kernel_id(self) -> int:
+        return _abi.ANALYTICAL_KERNELS[self.kernel_name]
+
+    def _required_names(self) -> List[str]:
+        return _abi.KERNEL_PARAMETER_NAMES[self.kernel_name] if self.has_metadata else []
+
+
+class ODE(Equation):
+    """ODE model integrated with fixed-step RK4 on the device (src/simulator/equation/ode/mod.rs:98-132;
+    the reference's diffsol solvers are replaced)."""
+
+    eq_kind = _abi.PMX_EQ_ODE
+
+    @staticmethod
+    def new(diffeq: str, out: Dict[int, Ratio], *, nparams: int, init: Optional[Dict[int, int]] = None,
+            h_max: float = 0.02) -> "ODE":
+        m = ODE()
+        if diffeq not in _abi.ODE_MODELS:
+            raise KeyError(f"unknown built-in diffeq '{diffeq}'")
+        m.kernel_name = diffeq
+        m.out = dict(out)
+        m.nparams = int(nparams)
+        m.init = dict(init or {})
+        m.rk4_h_max = float(h_max)
+        return m
+
+    def with_step(self, h_max: float) -> "ODE":
+        self.rk4_h_max = float(h_max)
+        self._handle = None
+        return self
+
+    def _kernel_id(self) -> int:
+        return _abi.ODE_MODELS[self.kernel_name]
+
+    def _required_names(self) -> List[str]:
+        return []
+
+
+def _declare(m: Equation, name, params, derived, covariates, states, outputs, routes, out, init, lag, fa):
+    m.name = name
+    m.params = list(params)
+    m.derived = dict(derived or {})
+    m.covariates = list(covariates or [])
+    m.states = list(states)
+    m.outputs = list(outputs)
+    m.routes = list(routes or [])
+    m.out = dict(out or {})
+    m.init = dict(init or {})
+    m.lag = dict(lag or {})
+    m.fa = dict(fa or {})
+    m.has_metadata = True
+    m.nstates = len(m.states)
+    m.nout = len(m.outputs)
+    nb = sum(1 for r in m.routes if r.kind == "bolus")
+    ni = sum(1 for r in m.routes if r.kind == "infusion")
+    m.ndrugs = max(nb, ni, 1)  # validate_routes returns max(bolus_inputs, infusion_inputs) (metadata.rs:926-946)
+    return m
+
+
+def analytical(*, name: str, params: Sequence[str], structure: str, states: Sequence[str], outputs: Sequence[str],
+               routes: Sequence[Route], out: Dict[str, Ratio], derived: Optional[Dict[str, Scaled]] = None,
+               covariates: Optional[Sequence[str]] = None, init=None, lag=None, fa=None,
+               cov_time: str = "segment_dt") -> Analytical:
+    """The ``analytical!`` declaration (e.g. examples/analytical_readme.rs:7-24)."""
+    m = Analytical()
+    if structure not in _abi.ANALYTICAL_KERNELS:
+        raise KeyError(f"unknown analytical structure '{structure}'")
+    m.kernel_name = structure
+    _declare(m, name, params, derived, covariates, states, outputs, routes, out, init, lag, fa)
+    if len(m.states) != _abi.KERNEL_STATE_COUNT[structure]:
+        raise ValueError(f"structure {structure} has {_abi.KERNEL_STATE_COUNT[structure]} states, "
+                         f"{len(m.states)} declared")
+    for n in _abi.KERNEL_PARAMETER_NAMES[structure]:
+        if n not in m.params and n not in m.derived:
+            raise KeyError(f"structure {structure} requires '{n}' in params or derived")
+    if cov_time not in ("segment_dt", "segment_end_abs"):
+        raise ValueError("cov_time must be 'segment_dt' or 'segment_end_abs'")
+    m.cov_time = cov_time
+    return m
+
+
+def ode(*, name: str, params: Sequence[str], diffeq: str, states: Sequence[str], outputs: Sequence[str],
+        routes: Sequence[Route], out: Dict[str, Ratio], derived=None, covariates=None, init=None,
+        h_max: float = 0.02) -> ODE:
+    """The ``ode!`` declaration with a built-in ``diffeq`` body (e.g. examples/ode_readme.rs:9-23)."""
+    m = ODE()
+    if diffeq not in _abi.ODE_MODELS:
+        raise KeyError(f"unknown built-in diffeq '{diffeq}'")
+    m.kernel_name = diffeq
+    _declare(m, name, params, derived, covariates, states, outputs, routes, out, init, None, None)
+    if len(m.states) != _abi.ODE_STATE_COUNT[diffeq]:
+        raise ValueError(f"diffeq {diffeq} has {_abi.ODE_STATE_COUNT[diffeq]} states, {len(m.states)} declared")
+    m.rk4_h_max = float(h_max)
+    return m
