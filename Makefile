@@ -1,0 +1,36 @@
+# Build libpmx_hip.so (HIP kernels + C ABI) for gfx950, and the CPU oracle (test infrastructure).
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+CSRC := pharmsol_amd/csrc
+LIB := pharmsol_amd/lib/libpmx_hip.so
+# -ffp-contract=off on the HOST side: the population compiler must evaluate covariate
+# lines (slope*t + intercept) exactly like the reference; device code keeps FMA contraction.
+HOSTFLAGS := -O2 -std=c++17 -fPIC -Wall -Wextra -ffp-contract=off
+DEVFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-parameter
+OBJ := $(CSRC)/build/pmx_compile.o $(CSRC)/build/pmx_api.o $(CSRC)/build/pmx_kernels.o
+
+all: $(LIB) oracle
+
+$(CSRC)/build/pmx_compile.o: $(CSRC)/pmx_compile.cpp $(CSRC)/pmx_compile.hpp include/pmx.h
+	@mkdir -p $(CSRC)/build
+	g++ $(HOSTFLAGS) -c $< -o $@
+
+$(CSRC)/build/pmx_api.o: $(CSRC)/pmx_api.cpp $(CSRC)/pmx_compile.hpp $(CSRC)/pmx_kernels.hpp $(CSRC)/pmx_structures.hpp include/pmx.h
+	@mkdir -p $(CSRC)/build
+	$(HIPCC) $(DEVFLAGS) -ffp-contract=off -x hip -c $< -o $@
+
+$(CSRC)/build/pmx_kernels.o: $(CSRC)/pmx_kernels.hip $(CSRC)/pmx_kernels.hpp $(CSRC)/pmx_structures.hpp $(CSRC)/pmx_compile.hpp include/pmx.h
+	@mkdir -p $(CSRC)/build
+	$(HIPCC) $(DEVFLAGS) -c $< -o $@
+
+$(LIB): $(OBJ)
+	@mkdir -p pharmsol_amd/lib
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJ)
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf $(CSRC)/build pharmsol_amd/lib oracle/_build
+
+.PHONY: all oracle clean

@@ -216,7 +216,11 @@ typedef struct pmx_model pmx_model;           /* opaque */
 
 int32_t pmx_abi_version(void);
 
-/* Number of visible HIP devices (0 when none; never initialises a context). */
+/* sizeof() of the descriptor structs as the library was built (binding layout check). */
+int64_t pmx_sizeof_model_desc(void);
+int64_t pmx_sizeof_population_desc(void);
+
+/* Number of visible HIP devices (0 when none). */
 int32_t pmx_device_count(void);
 
 /* Flatten + upload a population.  Replaces Data/Subject construction + the
@@ -261,12 +265,35 @@ int32_t pmx_predict_batch(const pmx_model* model, const pmx_population* pop, con
 int32_t pmx_predict_batch_device(const pmx_model* model, const pmx_population* pop, const double* d_theta,
                                  double* d_pred, uint8_t* d_status, void* stream);
 
-/* Name of the device kernel the last pmx_predict* call on this thread launched
- * (for matching rocprofv3 rows), and its launch geometry. */
+/* Name of the device kernel family the last pmx_predict* call on this thread launched
+ * (for matching rocprofv3 rows). */
 const char* pmx_last_kernel_name(void);
 
 /* Message of the last failing call made by this thread ("" if none). */
 const char* pmx_last_error(void);
+
+/* ---- host-side introspection (needs no device) ------------------------------ */
+/* The flattened op stream the device walks for (population, model): what the
+ * host-side population compiler (csrc/pmx_compile.cpp) produces in place of the
+ * reference's per-(subject, theta) Occasion::process_events + Analytical::solve
+ * splitting.  Lets the CPU test-suite check that logic without a GPU. */
+enum { PMX_OP_RESET = 0, PMX_OP_BOLUS = 1, PMX_OP_OBS = 2, PMX_OP_PROP = 3 };
+typedef struct pmx_op_stream_view {
+  int64_t n_subjects, n_ops;
+  int32_t n_cov, n_rate;
+  int32_t max_input_used, max_outeq;
+  const int64_t* subj_op_off; /* [n_subjects+1] */
+  const uint32_t* op_meta;    /* kind | io<<8 */
+  const double* op_a;         /* BOLUS amount | OBS time | PROP dt */
+  const double* op_b;         /* PROP rateiv[0] (analytical) / RK4 h (ODE) */
+  const int32_t* op_n;        /* ODE: RK4 steps per PROP (NULL for analytical) */
+  const double* op_rate;      /* ODE: [n_ops*n_rate] (NULL for analytical) */
+  const double* op_cov;       /* [n_ops*n_cov] (NULL if n_cov == 0) */
+  const int32_t* subj_order;  /* [n_subjects] lane order of the PAIR kernels */
+  void* owner;                /* library-owned storage; release with pmx_debug_free */
+} pmx_op_stream_view;
+int32_t pmx_debug_compile(const pmx_population_desc* pop, const pmx_model_desc* model, pmx_op_stream_view* out);
+void pmx_debug_free(pmx_op_stream_view* view);
 
 #ifdef __cplusplus
 }

@@ -190,6 +190,26 @@ class pmx_model_desc(C.Structure):
     ]
 
 
+class pmx_op_stream_view(C.Structure):
+    _fields_ = [
+        ("n_subjects", C.c_int64), ("n_ops", C.c_int64),
+        ("n_cov", C.c_int32), ("n_rate", C.c_int32),
+        ("max_input_used", C.c_int32), ("max_outeq", C.c_int32),
+        ("subj_op_off", C.POINTER(C.c_int64)),
+        ("op_meta", C.POINTER(C.c_uint32)),
+        ("op_a", C.POINTER(C.c_double)),
+        ("op_b", C.POINTER(C.c_double)),
+        ("op_n", C.POINTER(C.c_int32)),
+        ("op_rate", C.POINTER(C.c_double)),
+        ("op_cov", C.POINTER(C.c_double)),
+        ("subj_order", C.POINTER(C.c_int32)),
+        ("owner", C.c_void_p),
+    ]
+
+
+PMX_OP_RESET, PMX_OP_BOLUS, PMX_OP_OBS, PMX_OP_PROP = 0, 1, 2, 3
+
+
 class PmxError(RuntimeError):
     """A failed C-ABI call (the Python face of ``PharmsolError``, src/error/mod.rs:13-49)."""
 

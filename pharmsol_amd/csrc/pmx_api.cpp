@@ -1,0 +1,488 @@
+// pmx_api.cpp — the extern "C" boundary of libpmx_hip.so (include/pmx.h).
+//
+// No CPU compute path exists in this library: if there is no HIP device the
+// entry points fail with PMX_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/pmx.h"
+#include "pmx_compile.hpp"
+#include "pmx_kernels.hpp"
+#include "pmx_structures.hpp"  // kernel_nparams()
+
+namespace {
+
+thread_local std::string g_err;
+thread_local const char* g_kernel_name = "";
+
+int32_t fail(int32_t code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define PMX_HIP(call)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (call);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return fail(e_ == hipErrorOutOfMemory ? PMX_ERR_OUT_OF_MEMORY : PMX_ERR_HIP,                 \
+                  std::string(#call) + ": " + hipGetErrorString(e_));                              \
+  } while (0)
+
+// Restores the caller's current device on scope exit.
+struct DeviceGuard {
+  int prev = -1;
+  bool active = false;
+  hipError_t enter(int dev) {
+    hipError_t e = hipGetDevice(&prev);
+    if (e != hipSuccess) return e;
+    if (prev != dev) {
+      e = hipSetDevice(dev);
+      active = (e == hipSuccess);
+    }
+    return e;
+  }
+  ~DeviceGuard() {
+    if (active) (void)hipSetDevice(prev);
+  }
+};
+
+struct DeviceStream {
+  pmx::CompileKey key;
+  pmx::DevOps dev{};
+  std::vector<void*> allocs;
+  int32_t max_input_used = -1;
+  int64_t n_ops = 0, n_prop = 0;
+  ~DeviceStream() {
+    for (void* p : allocs) (void)hipFree(p);
+  }
+};
+
+template <class T>
+int32_t upload(const std::vector<T>& v, const T** out, std::vector<void*>* allocs) {
+  *out = nullptr;
+  if (v.empty()) return PMX_OK;
+  void* p = nullptr;
+  PMX_HIP(hipMalloc(&p, v.size() * sizeof(T)));
+  allocs->push_back(p);
+  PMX_HIP(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  *out = static_cast<const T*>(p);
+  return PMX_OK;
+}
+
+int ode_nstates(int model) {
+  static const int n[PMX_ODE_MODEL_COUNT] = {1, 2, 2, 3, 3, 4, 1};
+  return (model >= 0 && model < PMX_ODE_MODEL_COUNT) ? n[model] : -1;
+}
+int ode_nparams(int model) {
+  static const int n[PMX_ODE_MODEL_COUNT] = {1, 2, 3, 4, 5, 6, 3};
+  return (model >= 0 && model < PMX_ODE_MODEL_COUNT) ? n[model] : -1;
+}
+
+}  // namespace
+
+struct pmx_population {
+  int device = 0;
+  pmx::HostPopulation hp;
+  std::mutex mu;
+  std::vector<std::unique_ptr<DeviceStream>> streams;  // one per model flavour, built lazily
+};
+
+struct pmx_model {
+  pmx_model_desc d;
+  bool dyn = false;  // kernel parameters depend on covariates
+  bool has_init = false;
+};
+
+extern "C" {
+
+int32_t pmx_abi_version(void) { return PMX_ABI_VERSION; }
+int64_t pmx_sizeof_model_desc(void) { return static_cast<int64_t>(sizeof(pmx_model_desc)); }
+int64_t pmx_sizeof_population_desc(void) { return static_cast<int64_t>(sizeof(pmx_population_desc)); }
+
+int32_t pmx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* pmx_last_error(void) { return g_err.c_str(); }
+const char* pmx_last_kernel_name(void) { return g_kernel_name; }
+
+int32_t pmx_population_create(const pmx_population_desc* desc, int32_t device, pmx_population** out) {
+  g_err.clear();
+  if (!out) return fail(PMX_ERR_INVALID_ARGUMENT, "out is null");
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return fail(PMX_ERR_NO_DEVICE, "no HIP device visible (libpmx_hip has no CPU path)");
+  if (device < 0 || device >= n) return fail(PMX_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+  auto pop = std::make_unique<pmx_population>();
+  pop->device = device;
+  std::string err;
+  int32_t rc = pmx::build_host_population(desc, &pop->hp, &err);
+  if (rc != PMX_OK) return fail(rc, err);
+  *out = pop.release();
+  return PMX_OK;
+}
+
+void pmx_population_destroy(pmx_population* pop) {
+  if (!pop) return;
+  {
+    DeviceGuard g;
+    (void)g.enter(pop->device);
+    pop->streams.clear();
+  }
+  delete pop;
+}
+
+int64_t pmx_population_n_subjects(const pmx_population* pop) { return pop ? pop->hp.n_subjects : -1; }
+int64_t pmx_population_n_observations(const pmx_population* pop) { return pop ? pop->hp.n_obs : -1; }
+int64_t pmx_population_n_events(const pmx_population* pop) { return pop ? pop->hp.n_events : -1; }
+
+int32_t pmx_population_observation_offsets(const pmx_population* pop, int64_t* obs_off) {
+  if (!pop || !obs_off) return fail(PMX_ERR_INVALID_ARGUMENT, "null argument");
+  std::memcpy(obs_off, pop->hp.subj_obs_off.data(), sizeof(int64_t) * pop->hp.subj_obs_off.size());
+  return PMX_OK;
+}
+
+int32_t pmx_population_observation_info(const pmx_population* pop, double* time, int32_t* outeq, int64_t* subject) {
+  if (!pop) return fail(PMX_ERR_INVALID_ARGUMENT, "null population");
+  const auto& hp = pop->hp;
+  if (time) std::memcpy(time, hp.obs_time.data(), sizeof(double) * hp.obs_time.size());
+  if (outeq) std::memcpy(outeq, hp.obs_outeq.data(), sizeof(int32_t) * hp.obs_outeq.size());
+  if (subject) std::memcpy(subject, hp.obs_subject.data(), sizeof(int64_t) * hp.obs_subject.size());
+  return PMX_OK;
+}
+
+int32_t pmx_model_create(const pmx_model_desc* d, pmx_model** out) {
+  g_err.clear();
+  if (!d || !out) return fail(PMX_ERR_INVALID_ARGUMENT, "null argument");
+  *out = nullptr;
+  if (d->nstates < 1 || d->nstates > PMX_MAX_STATES) return fail(PMX_ERR_INVALID_ARGUMENT, "nstates out of range");
+  if (d->ndrugs < 0 || d->ndrugs > PMX_MAX_INPUTS) return fail(PMX_ERR_INVALID_ARGUMENT, "ndrugs out of range");
+  if (d->nout < 1 || d->nout > PMX_MAX_OUT) return fail(PMX_ERR_INVALID_ARGUMENT, "nout out of range");
+  if (d->nparams < 0 || d->nparams > PMX_MAX_PARAMS) return fail(PMX_ERR_INVALID_ARGUMENT, "nparams out of range");
+  if (d->n_covariates < 0 || d->n_covariates > PMX_MAX_COVARIATES)
+    return fail(PMX_ERR_INVALID_ARGUMENT, "n_covariates out of range");
+  if (d->n_derived < 0 || d->n_derived > PMX_MAX_DERIVED) return fail(PMX_ERR_INVALID_ARGUMENT, "n_derived out of range");
+  for (int i = 0; i < d->n_derived; ++i) {
+    const pmx_derived& dd = d->derived[i];
+    if (dd.src_param < 0 || dd.src_param >= d->nparams) return fail(PMX_ERR_INVALID_ARGUMENT, "derived.src_param out of range");
+    if (dd.n_factors < 0 || dd.n_factors > PMX_MAX_FACTORS) return fail(PMX_ERR_INVALID_ARGUMENT, "derived.n_factors out of range");
+    for (int k = 0; k < dd.n_factors; ++k)
+      if (dd.f[k].op != PMX_F_NONE && (dd.f[k].cov < 0 || dd.f[k].cov >= d->n_covariates))
+        return fail(PMX_ERR_INVALID_ARGUMENT, "derived factor covariate out of range");
+  }
+  auto m = std::make_unique<pmx_model>();
+  m->d = *d;
+  const int pm = d->pmetrics_indexing ? 1 : 0;
+  if (d->eq_kind == PMX_EQ_ANALYTICAL) {
+    if (d->kernel < 0 || d->kernel >= PMX_K_ANALYTICAL_COUNT) return fail(PMX_ERR_INVALID_ARGUMENT, "unknown analytical kernel");
+    static const int kNS[12] = {1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4};  // AnalyticalKernel::state_count analysis.rs:259-270
+    if (d->nstates < kNS[d->kernel] + pm) return fail(PMX_ERR_INVALID_ARGUMENT, "model has fewer states than its structure");
+    const int np = pmx::kernel_nparams(d->kernel);
+    if (d->n_bind == 0 && d->nparams < np) return fail(PMX_ERR_INVALID_ARGUMENT, "too few parameters for the structure");
+    if (d->n_bind != 0 && d->n_bind != np) return fail(PMX_ERR_INVALID_ARGUMENT, "n_bind must equal the structure's parameter count");
+    for (int j = 0; j < d->n_bind; ++j) {
+      const pmx_bind& b = d->bind[j];
+      if (b.src == PMX_SRC_PRIMARY) {
+        if (b.index < 0 || b.index >= d->nparams) return fail(PMX_ERR_INVALID_ARGUMENT, "bind index out of range");
+      } else if (b.src == PMX_SRC_DERIVED) {
+        if (b.index < 0 || b.index >= d->n_derived) return fail(PMX_ERR_INVALID_ARGUMENT, "bind derived index out of range");
+        if (d->derived[b.index].n_factors > 0) m->dyn = true;
+      } else
+        return fail(PMX_ERR_INVALID_ARGUMENT, "bind.src must be PRIMARY or DERIVED");
+    }
+    for (int i = 0; i < PMX_MAX_INPUTS; ++i)
+      if (d->lag_param[i] >= 0 || d->fa_param[i] >= 0)
+        return fail(PMX_ERR_UNSUPPORTED,
+                    "lag / bioavailability (theta-dependent event rewrite, structs.rs:611-666) is not on the device path yet");
+  } else if (d->eq_kind == PMX_EQ_ODE) {
+    if (ode_nstates(d->kernel) < 0) return fail(PMX_ERR_INVALID_ARGUMENT, "unknown ODE model");
+    if (d->nstates < ode_nstates(d->kernel)) return fail(PMX_ERR_INVALID_ARGUMENT, "model has fewer states than its diffeq");
+    if (d->nparams < ode_nparams(d->kernel)) return fail(PMX_ERR_INVALID_ARGUMENT, "too few parameters for the diffeq");
+    if (!(d->rk4_h_max > 0.0)) return fail(PMX_ERR_INVALID_ARGUMENT, "rk4_h_max must be > 0");
+    if (d->n_derived > 0 || d->n_bind > 0 || pm)
+      return fail(PMX_ERR_UNSUPPORTED, "derived parameters / pm indexing are not supported for ODE models yet");
+    for (int i = 0; i < PMX_MAX_INPUTS; ++i) {
+      if (d->lag_param[i] >= 0 || d->fa_param[i] >= 0) return fail(PMX_ERR_UNSUPPORTED, "lag / bioavailability not on the device path yet");
+      if (d->bolus_dest[i] >= d->nstates || d->infusion_dest[i] >= d->nstates)
+        return fail(PMX_ERR_INVALID_ARGUMENT, "route destination out of range");
+    }
+  } else
+    return fail(PMX_ERR_INVALID_ARGUMENT, "unknown eq_kind");
+  for (int o = 0; o < d->nout; ++o) {
+    const pmx_out& oo = d->out[o];
+    if (oo.state < 0 || oo.state >= d->nstates) return fail(PMX_ERR_INVALID_ARGUMENT, "out.state out of range");
+    if (oo.vol_src == PMX_SRC_PRIMARY && (oo.vol_index < 0 || oo.vol_index >= d->nparams))
+      return fail(PMX_ERR_INVALID_ARGUMENT, "out.vol_index out of range");
+    if (oo.vol_src == PMX_SRC_DERIVED && (oo.vol_index < 0 || oo.vol_index >= d->n_derived))
+      return fail(PMX_ERR_INVALID_ARGUMENT, "out.vol_index (derived) out of range");
+  }
+  for (int i = 0; i < PMX_MAX_STATES; ++i) {
+    if (d->init_param[i] >= d->nparams) return fail(PMX_ERR_INVALID_ARGUMENT, "init_param out of range");
+    if (d->init_param[i] >= 0 && i < d->nstates) m->has_init = true;
+  }
+  *out = m.release();
+  return PMX_OK;
+}
+
+void pmx_model_destroy(pmx_model* m) { delete m; }
+
+}  // extern "C"
+
+namespace {
+
+pmx::CompileKey key_for(const pmx_model* m) {
+  pmx::CompileKey k;
+  k.eq_kind = m->d.eq_kind;
+  if (m->d.eq_kind == PMX_EQ_ANALYTICAL) {
+    k.cov_time_mode = m->d.cov_time_mode;
+    k.rk4_h_max = 0.0;
+    k.n_rate = 1;
+    k.rate_input = m->d.pmetrics_indexing ? 1 : 0;
+  } else {
+    k.cov_time_mode = PMX_COV_TIME_SEGMENT_END_ABS;
+    k.rk4_h_max = m->d.rk4_h_max;
+    k.n_rate = m->d.ndrugs > 0 ? m->d.ndrugs : 1;
+    k.rate_input = 0;
+  }
+  return k;
+}
+
+// Find or build (compile + upload) the device op stream for this model flavour.
+int32_t get_stream(pmx_population* pop, const pmx::CompileKey& key, DeviceStream** out) {
+  std::lock_guard<std::mutex> lock(pop->mu);
+  for (auto& s : pop->streams)
+    if (s->key == key) {
+      *out = s.get();
+      return PMX_OK;
+    }
+  pmx::OpStream os;
+  std::string err;
+  int32_t rc = pmx::compile_ops(pop->hp, key, &os, &err);
+  if (rc != PMX_OK) return fail(rc, err);
+  auto ds = std::make_unique<DeviceStream>();
+  ds->key = key;
+  ds->max_input_used = os.max_input_used;
+  ds->n_ops = os.n_ops;
+  ds->n_prop = os.n_prop;
+  if ((rc = upload(os.subj_op_off, &ds->dev.subj_op_off, &ds->allocs)) != PMX_OK) return rc;
+  if ((rc = upload(pop->hp.subj_obs_off, &ds->dev.subj_obs_off, &ds->allocs)) != PMX_OK) return rc;
+  if ((rc = upload(os.subj_order, &ds->dev.subj_order, &ds->allocs)) != PMX_OK) return rc;
+  if ((rc = upload(os.op_meta, &ds->dev.op_meta, &ds->allocs)) != PMX_OK) return rc;
+  if ((rc = upload(os.op_a, &ds->dev.op_a, &ds->allocs)) != PMX_OK) return rc;
+  if ((rc = upload(os.op_b, &ds->dev.op_b, &ds->allocs)) != PMX_OK) return rc;
+  if ((rc = upload(os.op_n, &ds->dev.op_n, &ds->allocs)) != PMX_OK) return rc;
+  if ((rc = upload(os.op_rate, &ds->dev.op_rate, &ds->allocs)) != PMX_OK) return rc;
+  if ((rc = upload(os.op_cov, &ds->dev.op_cov, &ds->allocs)) != PMX_OK) return rc;
+  ds->dev.n_rate = key.n_rate;
+  *out = ds.get();
+  pop->streams.push_back(std::move(ds));
+  return PMX_OK;
+}
+
+int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_theta, int64_t P, int batch,
+                double* d_pred, int64_t ld, uint8_t* d_status, void* stream) {
+  const pmx_model_desc& d = model->d;
+  if (d.n_covariates != pop->hp.n_cov)
+    return fail(PMX_ERR_INVALID_ARGUMENT, "model declares " + std::to_string(d.n_covariates) +
+                                              " covariates, population carries " + std::to_string(pop->hp.n_cov));
+  DeviceStream* ds = nullptr;
+  int32_t rc = get_stream(pop, key_for(model), &ds);
+  if (rc != PMX_OK) return rc;
+  // range checks the reference performs inside the event loop
+  if (ds->max_input_used >= d.ndrugs)
+    return fail(PMX_ERR_INPUT_OUT_OF_RANGE, "input " + std::to_string(ds->max_input_used) + " >= ndrugs " +
+                                                std::to_string(d.ndrugs));  // equation/mod.rs:322-327
+  if (pop->hp.max_outeq >= d.nout)
+    return fail(PMX_ERR_OUTEQ_OUT_OF_RANGE,
+                "outeq " + std::to_string(pop->hp.max_outeq) + " >= nout " + std::to_string(d.nout));
+  if (pop->hp.n_subjects == 0 || (pop->hp.n_obs == 0 && d_status == nullptr)) return PMX_OK;
+
+  pmx::LaunchArgs a{};
+  a.m.eq_kind = d.eq_kind;
+  a.m.kernel = d.kernel;
+  a.m.nparams = d.nparams;
+  a.m.n_cov = d.n_covariates;
+  a.m.n_derived = d.n_derived;
+  a.m.n_bind = d.n_bind;
+  a.m.nout = d.nout;
+  a.m.pm = d.pmetrics_indexing ? 1 : 0;
+  a.m.has_init = model->has_init ? 1 : 0;
+  std::memcpy(a.m.derived, d.derived, sizeof(d.derived));
+  std::memcpy(a.m.bind, d.bind, sizeof(d.bind));
+  std::memcpy(a.m.out, d.out, sizeof(d.out));
+  std::memcpy(a.m.init_param, d.init_param, sizeof(d.init_param));
+  std::memcpy(a.m.bolus_dest, d.bolus_dest, sizeof(d.bolus_dest));
+  std::memcpy(a.m.infusion_dest, d.infusion_dest, sizeof(d.infusion_dest));
+  a.ops = ds->dev;
+  a.theta = d_theta;
+  a.P = batch ? 1 : P;
+  a.S = pop->hp.n_subjects;
+  a.pred = d_pred;
+  a.ld = batch ? 1 : ld;
+  a.status = d_status;
+  a.batch = batch;
+  a.dyn = model->dyn ? 1 : 0;
+  a.stream = stream;
+  if (!batch && P >= 32) {
+    a.mode = pmx::MODE_GRID;
+    a.n_ptiles = static_cast<int32_t>((P + 255) / 256);
+    // enough blocks to fill 256 CUs several times over, few enough that the per-block
+    // rate-constant setup stays amortised
+    int64_t chunk = (a.S * a.n_ptiles) / 8192;
+    if (chunk < 1) chunk = 1;
+    if (chunk > 64) chunk = 64;
+    a.s_chunk = static_cast<int32_t>(chunk);
+  } else {
+    a.mode = pmx::MODE_PAIR;
+    a.n_ptiles = 1;
+    a.s_chunk = 1;
+  }
+  const int64_t blocks = a.mode == pmx::MODE_GRID ? ((a.S + a.s_chunk - 1) / a.s_chunk) * a.n_ptiles
+                                                  : ((batch ? a.S : a.S * a.P) + 255) / 256;
+  if (blocks > 0x7fffffffLL) return fail(PMX_ERR_INVALID_ARGUMENT, "grid too large for one launch");
+  const char* name = "";
+  hipError_t e = pmx::launch_predict(a, &name);
+  g_kernel_name = name;
+  if (e != hipSuccess) return fail(PMX_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+  return PMX_OK;
+}
+
+int32_t predict_host(const pmx_model* model, const pmx_population* cpop, const double* theta, int64_t P, int batch,
+                     double* pred, int64_t ld, uint8_t* status) {
+  g_err.clear();
+  if (!model || !cpop || !theta || !pred) return fail(PMX_ERR_INVALID_ARGUMENT, "null argument");
+  pmx_population* pop = const_cast<pmx_population*>(cpop);
+  const int64_t S = pop->hp.n_subjects, NO = pop->hp.n_obs;
+  if (!batch && (P <= 0 || ld < P)) return fail(PMX_ERR_INVALID_ARGUMENT, "n_support must be > 0 and ld_pred >= n_support");
+  DeviceGuard g;
+  PMX_HIP(g.enter(pop->device));
+  const int64_t rows_theta = batch ? S : P;
+  const int64_t ldp = batch ? 1 : ld;
+  const int64_t n_status = batch ? S : S * P;
+  double *d_theta = nullptr, *d_pred = nullptr;
+  uint8_t* d_status = nullptr;
+  struct Free {
+    void** p;
+    ~Free() {
+      if (*p) (void)hipFree(*p);
+    }
+  };
+  Free f1{reinterpret_cast<void**>(&d_theta)}, f2{reinterpret_cast<void**>(&d_pred)},
+      f3{reinterpret_cast<void**>(&d_status)};
+  const size_t theta_bytes = static_cast<size_t>(rows_theta) * model->d.nparams * sizeof(double);
+  const size_t pred_bytes = static_cast<size_t>(NO) * ldp * sizeof(double);
+  PMX_HIP(hipMalloc(reinterpret_cast<void**>(&d_theta), theta_bytes > 0 ? theta_bytes : 8));
+  PMX_HIP(hipMalloc(reinterpret_cast<void**>(&d_pred), pred_bytes > 0 ? pred_bytes : 8));
+  PMX_HIP(hipMalloc(reinterpret_cast<void**>(&d_status), n_status > 0 ? n_status : 8));
+  PMX_HIP(hipMemcpy(d_theta, theta, theta_bytes, hipMemcpyHostToDevice));
+  if (ldp != P && !batch) PMX_HIP(hipMemcpy(d_pred, pred, pred_bytes, hipMemcpyHostToDevice));  // keep the caller's padding
+  PMX_HIP(hipMemset(d_status, 0, n_status > 0 ? n_status : 1));
+  int32_t rc = enqueue(model, pop, d_theta, P, batch, d_pred, ldp, d_status, nullptr);
+  if (rc != PMX_OK) return rc;
+  PMX_HIP(hipDeviceSynchronize());
+  PMX_HIP(hipMemcpy(pred, d_pred, pred_bytes, hipMemcpyDeviceToHost));
+  std::vector<uint8_t> hst(static_cast<size_t>(n_status));
+  PMX_HIP(hipMemcpy(hst.data(), d_status, static_cast<size_t>(n_status), hipMemcpyDeviceToHost));
+  if (status) std::memcpy(status, hst.data(), hst.size());
+  for (uint8_t s : hst)
+    if (s != PMX_PAIR_OK)
+      return fail(PMX_ERR_PAIR_FAILED, "at least one (subject, support point) pair failed; see the status array");
+  return PMX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t pmx_predict(const pmx_model* model, const pmx_population* pop, const double* theta, int64_t n_support,
+                    double* pred, int64_t ld_pred, uint8_t* status) {
+  return predict_host(model, pop, theta, n_support, 0, pred, ld_pred, status);
+}
+
+int32_t pmx_predict_batch(const pmx_model* model, const pmx_population* pop, const double* theta, double* pred,
+                          uint8_t* status) {
+  return predict_host(model, pop, theta, 1, 1, pred, 1, status);
+}
+
+int32_t pmx_predict_device(const pmx_model* model, const pmx_population* cpop, const double* d_theta,
+                           int64_t n_support, double* d_pred, int64_t ld_pred, uint8_t* d_status, void* stream) {
+  g_err.clear();
+  if (!model || !cpop || !d_theta || !d_pred) return fail(PMX_ERR_INVALID_ARGUMENT, "null argument");
+  if (n_support <= 0 || ld_pred < n_support) return fail(PMX_ERR_INVALID_ARGUMENT, "n_support must be > 0 and ld_pred >= n_support");
+  pmx_population* pop = const_cast<pmx_population*>(cpop);
+  DeviceGuard g;
+  PMX_HIP(g.enter(pop->device));
+  return enqueue(model, pop, d_theta, n_support, 0, d_pred, ld_pred, d_status, stream);
+}
+
+int32_t pmx_predict_batch_device(const pmx_model* model, const pmx_population* cpop, const double* d_theta,
+                                 double* d_pred, uint8_t* d_status, void* stream) {
+  g_err.clear();
+  if (!model || !cpop || !d_theta || !d_pred) return fail(PMX_ERR_INVALID_ARGUMENT, "null argument");
+  pmx_population* pop = const_cast<pmx_population*>(cpop);
+  DeviceGuard g;
+  PMX_HIP(g.enter(pop->device));
+  return enqueue(model, pop, d_theta, 1, 1, d_pred, 1, d_status, stream);
+}
+
+}  // extern "C"
+
+// ---- host-side introspection ---------------------------------------------------
+namespace {
+struct DebugOwner {
+  pmx::HostPopulation hp;
+  pmx::OpStream os;
+};
+}  // namespace
+
+extern "C" {
+
+int32_t pmx_debug_compile(const pmx_population_desc* pop, const pmx_model_desc* model, pmx_op_stream_view* out) {
+  g_err.clear();
+  if (!pop || !model || !out) return fail(PMX_ERR_INVALID_ARGUMENT, "null argument");
+  std::memset(out, 0, sizeof(*out));
+  pmx_model* m = nullptr;
+  int32_t rc = pmx_model_create(model, &m);
+  if (rc != PMX_OK) return rc;
+  std::unique_ptr<pmx_model> mg(m);
+  auto own = std::make_unique<DebugOwner>();
+  std::string err;
+  rc = pmx::build_host_population(pop, &own->hp, &err);
+  if (rc != PMX_OK) return fail(rc, err);
+  rc = pmx::compile_ops(own->hp, key_for(m), &own->os, &err);
+  if (rc != PMX_OK) return fail(rc, err);
+  const pmx::OpStream& os = own->os;
+  out->n_subjects = own->hp.n_subjects;
+  out->n_ops = os.n_ops;
+  out->n_cov = own->hp.n_cov;
+  out->n_rate = os.key.n_rate;
+  out->max_input_used = os.max_input_used;
+  out->max_outeq = own->hp.max_outeq;
+  out->subj_op_off = os.subj_op_off.data();
+  out->op_meta = os.op_meta.data();
+  out->op_a = os.op_a.data();
+  out->op_b = os.op_b.data();
+  out->op_n = os.op_n.empty() ? nullptr : os.op_n.data();
+  out->op_rate = os.op_rate.empty() ? nullptr : os.op_rate.data();
+  out->op_cov = os.op_cov.empty() ? nullptr : os.op_cov.data();
+  out->subj_order = os.subj_order.data();
+  out->owner = own.release();
+  return PMX_OK;
+}
+
+void pmx_debug_free(pmx_op_stream_view* view) {
+  if (!view || !view->owner) return;
+  delete static_cast<DebugOwner*>(view->owner);
+  std::memset(view, 0, sizeof(*view));
+}
+
+}  // extern "C"

@@ -1,0 +1,351 @@
+// pmx_compile.cpp — see pmx_compile.hpp.  Host C++ only (no HIP).
+#include "pmx_compile.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <numeric>
+
+namespace pmx {
+
+namespace {
+
+// f64::total_cmp as an integer key (event.rs:301, covariate.rs:191).
+inline int64_t total_key(double v) {
+  int64_t b;
+  std::memcpy(&b, &v, 8);
+  b ^= static_cast<int64_t>(static_cast<uint64_t>(b >> 63) >> 1);
+  return b;
+}
+
+struct ActiveInfusion {
+  double time, amount, duration;
+  int32_t input;
+};
+
+}  // namespace
+
+bool HostPopulation::interpolate(int64_t occ, int32_t cov, double t, double* out) const {
+  const int64_t idx = occ * n_cov + cov;
+  const int64_t s0 = cov_seg_off[idx], s1 = cov_seg_off[idx + 1];
+  if (s0 == s1) return false;
+  // linear scan: first segment with from <= t < to (covariate.rs:221-227, :60-64)
+  for (int64_t s = s0; s < s1; ++s) {
+    if (seg_from[s] <= t && t < seg_to[s]) {
+      *out = std::isnan(seg_slope[s]) ? seg_icpt[s] : (seg_slope[s] * t + seg_icpt[s]);
+      return true;
+    }
+  }
+  if (t < cov_first_t[idx]) {
+    *out = cov_first_v[idx];
+    return true;
+  }
+  if (t >= cov_last_t[idx]) {
+    *out = cov_last_v[idx];
+    return true;
+  }
+  return false;
+}
+
+int32_t build_host_population(const pmx_population_desc* d, HostPopulation* hp, std::string* err) {
+  auto fail = [&](int32_t code, const std::string& m) {
+    *err = m;
+    return code;
+  };
+  if (!d) return fail(PMX_ERR_INVALID_ARGUMENT, "null population descriptor");
+  if (d->n_subjects < 0 || d->n_occasions < 0 || d->n_events < 0)
+    return fail(PMX_ERR_INVALID_ARGUMENT, "negative sizes");
+  if (!d->subj_occ_off || !d->occ_ev_off) return fail(PMX_ERR_INVALID_ARGUMENT, "null offset arrays");
+  if (d->n_events > 0 && (!d->ev_time || !d->ev_value || !d->ev_duration || !d->ev_kind || !d->ev_io))
+    return fail(PMX_ERR_INVALID_ARGUMENT, "null event arrays");
+  if (d->n_covariates < 0 || d->n_covariates > PMX_MAX_COVARIATES)
+    return fail(PMX_ERR_INVALID_ARGUMENT, "n_covariates out of range");
+  const int64_t S = d->n_subjects, NO = d->n_occasions, NE = d->n_events;
+  if (d->subj_occ_off[0] != 0 || d->subj_occ_off[S] != NO)
+    return fail(PMX_ERR_INVALID_ARGUMENT, "subj_occ_off must span [0, n_occasions]");
+  if (d->occ_ev_off[0] != 0 || d->occ_ev_off[NO] != NE)
+    return fail(PMX_ERR_INVALID_ARGUMENT, "occ_ev_off must span [0, n_events]");
+  for (int64_t s = 0; s < S; ++s)
+    if (d->subj_occ_off[s + 1] < d->subj_occ_off[s]) return fail(PMX_ERR_INVALID_ARGUMENT, "subj_occ_off not monotone");
+  for (int64_t o = 0; o < NO; ++o)
+    if (d->occ_ev_off[o + 1] < d->occ_ev_off[o]) return fail(PMX_ERR_INVALID_ARGUMENT, "occ_ev_off not monotone");
+
+  hp->n_subjects = S;
+  hp->n_occasions = NO;
+  hp->n_events = NE;
+  hp->n_cov = d->n_covariates;
+  hp->subj_occ_off.assign(d->subj_occ_off, d->subj_occ_off + S + 1);
+  hp->occ_ev_off.assign(d->occ_ev_off, d->occ_ev_off + NO + 1);
+  hp->occ_index.resize(NO);
+  for (int64_t s = 0; s < S; ++s)
+    for (int64_t o = hp->subj_occ_off[s]; o < hp->subj_occ_off[s + 1]; ++o)
+      hp->occ_index[o] = d->occ_index ? d->occ_index[o] : static_cast<int32_t>(o - hp->subj_occ_off[s]);
+
+  hp->ev_time.resize(NE);
+  hp->ev_value.resize(NE);
+  hp->ev_dur.resize(NE);
+  hp->ev_kind.resize(NE);
+  hp->ev_io.resize(NE);
+  std::vector<int64_t> order;
+  for (int64_t o = 0; o < NO; ++o) {
+    const int64_t e0 = hp->occ_ev_off[o], e1 = hp->occ_ev_off[o + 1];
+    order.resize(e1 - e0);
+    std::iota(order.begin(), order.end(), e0);
+    if (!d->presorted) {
+      // Occasion::sort: stable, time.total_cmp then Observation < Bolus < Infusion (event.rs:292-304)
+      std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
+        const int64_t ka = total_key(d->ev_time[a]), kb = total_key(d->ev_time[b]);
+        if (ka != kb) return ka < kb;
+        return d->ev_kind[a] < d->ev_kind[b];
+      });
+    }
+    for (int64_t i = 0; i < e1 - e0; ++i) {
+      const int64_t src = order[i], dst = e0 + i;
+      const uint8_t k = d->ev_kind[src];
+      if (k > PMX_EV_INFUSION) return fail(PMX_ERR_INVALID_ARGUMENT, "unknown event kind");
+      hp->ev_time[dst] = d->ev_time[src];
+      hp->ev_value[dst] = d->ev_value[src];
+      hp->ev_dur[dst] = d->ev_duration[src];
+      hp->ev_kind[dst] = k;
+      hp->ev_io[dst] = d->ev_io[src];
+      if (k == PMX_EV_OBSERVATION)
+        hp->max_outeq = std::max<int32_t>(hp->max_outeq, d->ev_io[src]);
+    }
+  }
+  // prediction rows (event order == flat_predictions order, subject.rs:145-148)
+  hp->subj_obs_off.assign(S + 1, 0);
+  for (int64_t s = 0; s < S; ++s) {
+    const int64_t e0 = hp->occ_ev_off[hp->subj_occ_off[s]], e1 = hp->occ_ev_off[hp->subj_occ_off[s + 1]];
+    for (int64_t e = e0; e < e1; ++e)
+      if (hp->ev_kind[e] == PMX_EV_OBSERVATION) {
+        hp->obs_time.push_back(hp->ev_time[e]);
+        hp->obs_outeq.push_back(hp->ev_io[e]);
+        hp->obs_subject.push_back(s);
+      }
+    hp->subj_obs_off[s + 1] = static_cast<int64_t>(hp->obs_time.size());
+  }
+  hp->n_obs = static_cast<int64_t>(hp->obs_time.size());
+
+  // covariate segments (Covariate::build_segments, covariate.rs:189-214)
+  const int32_t nc = hp->n_cov;
+  if (nc > 0) {
+    if (!d->cov_knot_off || !d->cov_knot_time || !d->cov_knot_value)
+      return fail(PMX_ERR_INVALID_ARGUMENT, "covariate arrays missing");
+    const int64_t ncell = NO * nc;
+    hp->cov_seg_off.assign(ncell + 1, 0);
+    hp->cov_first_t.resize(ncell);
+    hp->cov_first_v.resize(ncell);
+    hp->cov_last_t.resize(ncell);
+    hp->cov_last_v.resize(ncell);
+    std::vector<std::pair<double, double>> obs;
+    for (int64_t c = 0; c < ncell; ++c) {
+      const int64_t k0 = d->cov_knot_off[c], k1 = d->cov_knot_off[c + 1];
+      if (k1 <= k0) return fail(PMX_ERR_INVALID_ARGUMENT, "a covariate has no observations in some occasion");
+      obs.clear();
+      for (int64_t k = k0; k < k1; ++k) obs.emplace_back(d->cov_knot_time[k], d->cov_knot_value[k]);
+      std::stable_sort(obs.begin(), obs.end(),
+                       [](const auto& a, const auto& b) { return total_key(a.first) < total_key(b.first); });
+      const bool fixed = d->cov_fixed && d->cov_fixed[c];
+      const size_t n = obs.size();
+      for (size_t i = 0; i < n; ++i) {
+        const bool has_next = i + 1 < n;
+        hp->seg_from.push_back(obs[i].first);
+        hp->seg_to.push_back(has_next ? obs[i + 1].first : std::numeric_limits<double>::infinity());
+        if (fixed || !has_next) {
+          hp->seg_slope.push_back(std::numeric_limits<double>::quiet_NaN());  // CarryForward
+          hp->seg_icpt.push_back(obs[i].second);
+        } else {
+          const double slope = (obs[i + 1].second - obs[i].second) / (obs[i + 1].first - obs[i].first);
+          hp->seg_slope.push_back(slope);
+          hp->seg_icpt.push_back(obs[i].second - slope * obs[i].first);
+        }
+      }
+      hp->cov_seg_off[c + 1] = static_cast<int64_t>(hp->seg_from.size());
+      hp->cov_first_t[c] = obs.front().first;
+      hp->cov_first_v[c] = obs.front().second;
+      hp->cov_last_t[c] = obs.back().first;
+      hp->cov_last_v[c] = obs.back().second;
+    }
+  }
+  return PMX_OK;
+}
+
+int32_t compile_ops(const HostPopulation& hp, const CompileKey& key, OpStream* os, std::string* err) {
+  const int32_t nc = hp.n_cov;
+  const bool ode = key.eq_kind == PMX_EQ_ODE;
+  const int32_t n_rate = key.n_rate;
+  os->key = key;
+  os->subj_op_off.assign(hp.n_subjects + 1, 0);
+  os->op_meta.clear();
+  os->op_a.clear();
+  os->op_b.clear();
+  os->op_n.clear();
+  os->op_rate.clear();
+  os->op_cov.clear();
+  os->n_prop = 0;
+
+  std::vector<double> covv(nc > 0 ? nc : 1, 0.0);
+  std::vector<double> rate(n_rate > 0 ? n_rate : 1, 0.0);
+  bool cov_missing = false;
+
+  auto push = [&](uint32_t kind, uint32_t io, double a, double b, int32_t n, const double* rates, int64_t occ,
+                  double t_cov, bool want_cov) {
+    os->op_meta.push_back(make_meta(kind, io));
+    os->op_a.push_back(a);
+    os->op_b.push_back(b);
+    if (ode) {
+      os->op_n.push_back(n);
+      for (int32_t r = 0; r < n_rate; ++r) os->op_rate.push_back(rates ? rates[r] : 0.0);
+    }
+    if (nc > 0) {
+      for (int32_t c = 0; c < nc; ++c) {
+        double v = 0.0;
+        if (want_cov && !hp.interpolate(occ, c, t_cov, &v)) cov_missing = true;
+        os->op_cov.push_back(v);
+      }
+    }
+  };
+
+  std::vector<ActiveInfusion> inf;
+  std::vector<double> ts, bounds;
+  int32_t max_input_used = -1;
+
+  for (int64_t s = 0; s < hp.n_subjects; ++s) {
+    for (int64_t oc = hp.subj_occ_off[s]; oc < hp.subj_occ_off[s + 1]; ++oc) {
+      const int64_t e0 = hp.occ_ev_off[oc], e1 = hp.occ_ev_off[oc + 1];
+      // initial_state: zeros, init only for occasion index 0 (analytical/mod.rs:409-426)
+      push(OP_RESET, hp.occ_index[oc] == 0 ? 1u : 0u, 0.0, 0.0, 0, nullptr, oc, 0.0, false);
+      inf.clear();
+      if (!ode) {
+        for (int64_t e = e0; e < e1; ++e) {  // simulate_event, equation/mod.rs:300-358
+          const uint8_t k = hp.ev_kind[e];
+          if (k == PMX_EV_BOLUS) {
+            max_input_used = std::max<int32_t>(max_input_used, hp.ev_io[e]);
+            push(OP_BOLUS, hp.ev_io[e], hp.ev_value[e], 0.0, 0, nullptr, oc, 0.0, false);
+          } else if (k == PMX_EV_INFUSION) {
+            inf.push_back({hp.ev_time[e], hp.ev_value[e], hp.ev_dur[e], static_cast<int32_t>(hp.ev_io[e])});
+          } else {
+            push(OP_OBS, hp.ev_io[e], hp.ev_time[e], 0.0, 0, nullptr, oc, hp.ev_time[e], true);
+          }
+          if (e + 1 < e1) {  // Analytical::solve, analytical/mod.rs:299-370
+            const double ti = hp.ev_time[e], tf = hp.ev_time[e + 1];
+            if (ti == tf) continue;  // :308-310
+            ts.clear();
+            ts.push_back(ti);
+            ts.push_back(tf);
+            for (const auto& f : inf) {  // :316-325 strictly-inside breakpoints
+              const double t0 = f.time, t1 = t0 + f.duration;
+              if (t0 > ti && t0 < tf) ts.push_back(t0);
+              if (t1 > ti && t1 < tf) ts.push_back(t1);
+            }
+            std::sort(ts.begin(), ts.end());  // :326
+            {                                 // dedup_by |a-b| < 1e-12 against the last retained, :327
+              size_t w = 1;
+              for (size_t r = 1; r < ts.size(); ++r)
+                if (!(std::fabs(ts[r] - ts[w - 1]) < 1e-12)) ts[w++] = ts[r];
+              ts.resize(w);
+            }
+            double cur = ts[0];
+            for (size_t i = 1; i < ts.size(); ++i) {  // :334-367
+              const double nxt = ts[i];
+              double r0 = 0.0;  // rateiv[0]: the only slot the closed forms read
+              for (const auto& f : inf) {
+                const double st = f.time, en = st + f.duration;
+                if (cur >= st && nxt <= en) {
+                  max_input_used = std::max(max_input_used, f.input);
+                  if (f.input == key.rate_input) r0 += f.amount / f.duration;  // :355
+                }
+              }
+              const double dt = nxt - cur;
+              const double t_cov = key.cov_time_mode == PMX_COV_TIME_SEGMENT_END_ABS ? nxt : dt;
+              push(OP_PROP, 0, dt, r0, 0, nullptr, oc, t_cov, true);
+              os->n_prop++;
+              cur = nxt;
+            }
+          }
+        }
+      } else {
+        // ODE::run_events (ode/mod.rs:609-823) with InfusionSchedule over ALL infusions
+        // of the occasion (closure.rs:109-180).
+        bounds.clear();
+        for (int64_t e = e0; e < e1; ++e) {
+          if (hp.ev_kind[e] != PMX_EV_INFUSION) continue;
+          if (hp.ev_dur[e] <= 0.0) continue;  // closure.rs:127-129
+          max_input_used = std::max<int32_t>(max_input_used, hp.ev_io[e]);
+          inf.push_back({hp.ev_time[e], hp.ev_value[e], hp.ev_dur[e], static_cast<int32_t>(hp.ev_io[e])});
+          bounds.push_back(hp.ev_time[e]);
+          bounds.push_back(hp.ev_time[e] + hp.ev_dur[e]);
+        }
+        std::sort(bounds.begin(), bounds.end());
+        bounds.erase(std::unique(bounds.begin(), bounds.end()), bounds.end());  // exact dedup, closure.rs:143-148
+        double t = 0.0;  // Occasion::initial_time, structs.rs:782-793
+        if (e1 > e0) {
+          t = hp.ev_time[e0];
+          for (int64_t e = e0 + 1; e < e1; ++e) t = std::min(t, hp.ev_time[e]);
+        }
+        size_t bcur = 0;
+        for (int64_t e = e0; e < e1; ++e) {
+          const uint8_t k = hp.ev_kind[e];
+          if (k == PMX_EV_BOLUS) {
+            max_input_used = std::max<int32_t>(max_input_used, hp.ev_io[e]);
+            push(OP_BOLUS, hp.ev_io[e], hp.ev_value[e], 0.0, 0, nullptr, oc, 0.0, false);
+          } else if (k == PMX_EV_OBSERVATION) {
+            push(OP_OBS, hp.ev_io[e], hp.ev_time[e], 0.0, 0, nullptr, oc, hp.ev_time[e], true);
+          }
+          if (e + 1 < e1) {
+            const double next_t = hp.ev_time[e + 1];
+            while (next_t > t) {  // ode/mod.rs:721-739
+              while (bcur < bounds.size() && bounds[bcur] <= t) ++bcur;
+              double stop = next_t;
+              if (bcur < bounds.size() && bounds[bcur] <= next_t) stop = bounds[bcur++];
+              std::fill(rate.begin(), rate.end(), 0.0);
+              for (const auto& f : inf) {  // right-continuous rate at t (closure.rs:80-99)
+                const double st = f.time, en = st + f.duration;
+                if (st <= t && t < en && f.input < n_rate) rate[f.input] += f.amount / f.duration;
+              }
+              const double dt = stop - t;
+              if (dt > 0.0) {
+                double nf = std::ceil(dt / key.rk4_h_max);
+                if (nf < 1.0) nf = 1.0;
+                if (nf > 2.0e9) {
+                  *err = "RK4 step count overflow (dt / rk4_h_max too large)";
+                  return PMX_ERR_INVALID_ARGUMENT;
+                }
+                const int32_t n = static_cast<int32_t>(nf);
+                push(OP_PROP, 0, dt, dt / static_cast<double>(n), n, rate.data(), oc, t, true);
+                os->n_prop++;
+              }
+              t = stop;
+            }
+          }
+        }
+      }
+    }
+    os->subj_op_off[s + 1] = static_cast<int64_t>(os->op_meta.size());
+  }
+  if (cov_missing) {
+    *err = "covariate interpolation failed (MissingSegments)";
+    return PMX_ERR_INVALID_ARGUMENT;
+  }
+  os->n_ops = static_cast<int64_t>(os->op_meta.size());
+  // lane-per-pair kernels: neighbours in a wavefront should have similar op counts
+  os->subj_order.resize(hp.n_subjects);
+  std::iota(os->subj_order.begin(), os->subj_order.end(), 0);
+  auto work = [&](int32_t s) -> int64_t {
+    if (!ode) return os->subj_op_off[s + 1] - os->subj_op_off[s];
+    int64_t w = 0;
+    for (int64_t o = os->subj_op_off[s]; o < os->subj_op_off[s + 1]; ++o) w += 1 + os->op_n[o];
+    return w;
+  };
+  std::vector<int64_t> wk(hp.n_subjects);
+  for (int64_t s = 0; s < hp.n_subjects; ++s) wk[s] = work(static_cast<int32_t>(s));
+  std::stable_sort(os->subj_order.begin(), os->subj_order.end(), [&](int32_t a, int32_t b) { return wk[a] > wk[b]; });
+  int64_t mx = 0;
+  for (int64_t s = 0; s < hp.n_subjects; ++s) mx = std::max(mx, os->subj_op_off[s + 1] - os->subj_op_off[s]);
+  os->max_ops_per_subject = static_cast<int32_t>(mx);
+  os->max_input_used = max_input_used;
+  return PMX_OK;
+}
+
+}  // namespace pmx

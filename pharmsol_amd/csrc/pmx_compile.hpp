@@ -1,0 +1,96 @@
+// pmx_compile.hpp — host-side "population compiler".
+//
+// The reference re-derives, for EVERY (subject, support point), the processed
+// event list (clone + label parse + sort: equation/mod.rs:247-273, structs.rs:669-690)
+// and, inside every `solve`, the infusion sub-segments (analytical/mod.rs:313-357).
+// None of that depends on the support point unless the model has lag/fa, so here
+// it is done once per subject on the host and flattened into a linear OP STREAM
+// that the device walks:
+//
+//   RESET  start of an occasion: x = 0 (+ init for occasion index 0)   analytical/mod.rs:409-426
+//   BOLUS  x[input] += amount                                          equation/mod.rs:313-329
+//   OBS    pred[row] = out(x, theta, t_obs)                            analytical/mod.rs:373-407
+//   PROP   x = eq(x, theta, dt, rateiv)   one constant-rate sub-segment analytical/mod.rs:334-367
+//
+// Infusion events need no op of their own: their effect is the rate carried by
+// the PROP ops they cover.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/pmx.h"
+
+namespace pmx {
+
+enum OpKind : uint32_t { OP_RESET = 0, OP_BOLUS = 1, OP_OBS = 2, OP_PROP = 3 };
+
+// op_meta layout: bits 0..7 kind, 8..23 io (input / outeq / reset: 1 = run init), 24..31 unused
+inline uint32_t make_meta(uint32_t kind, uint32_t io) { return kind | (io << 8); }
+
+// Sorted, validated copy of the caller's events (model independent).
+struct HostPopulation {
+  int64_t n_subjects = 0, n_occasions = 0, n_events = 0, n_obs = 0;
+  int32_t n_cov = 0;
+  std::vector<int64_t> subj_occ_off, occ_ev_off;
+  std::vector<int32_t> occ_index;
+  std::vector<double> ev_time, ev_value, ev_dur;
+  std::vector<uint8_t> ev_kind;
+  std::vector<uint16_t> ev_io;
+  std::vector<int64_t> subj_obs_off;  // [S+1]
+  // observation bookkeeping in prediction order
+  std::vector<double> obs_time;
+  std::vector<int32_t> obs_outeq;
+  std::vector<int64_t> obs_subject;
+  int32_t max_outeq = -1;  // over all observations (range check vs model.nout)
+  // covariates: per (occasion, covariate) segments as covariate.rs stores them
+  std::vector<int64_t> cov_seg_off;  // [n_occ*n_cov+1]
+  std::vector<double> seg_from, seg_to /* +inf = open */, seg_slope, seg_icpt /* slope==NaN => carry value in icpt */;
+  std::vector<double> cov_first_t, cov_first_v, cov_last_t, cov_last_v;  // [n_occ*n_cov]
+
+  // Covariate::interpolate (covariate.rs:216-241); returns false on MissingSegments.
+  bool interpolate(int64_t occ, int32_t cov, double t, double* out) const;
+};
+
+// What the model contributes to the op stream.
+struct CompileKey {
+  int32_t eq_kind = PMX_EQ_ANALYTICAL;
+  int32_t cov_time_mode = PMX_COV_TIME_SEGMENT_DT;
+  double rk4_h_max = 0.0;  // ODE only
+  int32_t n_rate = 1;      // rate columns carried per PROP op (1 for analytical: closed forms read rateiv[0])
+  int32_t rate_input = 0;  // analytical: the input whose rate the closed form reads (1 under pm_* indexing,
+                           // where rateiv slot 0 is a dead pad: analytical/mod.rs:86-88)
+  bool operator==(const CompileKey& o) const {
+    return eq_kind == o.eq_kind && cov_time_mode == o.cov_time_mode && rk4_h_max == o.rk4_h_max &&
+           n_rate == o.n_rate && rate_input == o.rate_input;
+  }
+};
+
+struct OpStream {
+  CompileKey key;
+  int64_t n_ops = 0;
+  std::vector<int64_t> subj_op_off;  // [S+1]
+  std::vector<uint32_t> op_meta;     // kind | io<<8
+  std::vector<double> op_a;          // BOLUS amount | OBS t_obs | PROP dt
+  std::vector<double> op_b;          // PROP: rateiv[0] (analytical) / h (ODE)
+  std::vector<int32_t> op_n;         // ODE PROP: RK4 step count (empty for analytical)
+  std::vector<double> op_rate;       // ODE: [n_ops * n_rate] rateiv per PROP (empty for analytical)
+  std::vector<double> op_cov;        // [n_ops * n_cov] covariates seen by the op (empty if n_cov == 0)
+  std::vector<int32_t> subj_order;   // subjects sorted by op count (desc), for the lane-per-pair kernels
+  int32_t max_ops_per_subject = 0;
+  int64_t n_prop = 0;
+  // Largest dose input that reaches the state: every bolus, and every infusion that is active in
+  // some PROP — what the reference range-checks against ndrugs (equation/mod.rs:322-327,
+  // analytical/mod.rs:349-354, closure.rs:131-134).
+  int32_t max_input_used = -1;
+};
+
+// Validate + copy + sort (Occasion::sort, structs.rs:669-671) + build covariate segments.
+// Returns PMX_OK or an error with `err` filled.
+int32_t build_host_population(const pmx_population_desc* d, HostPopulation* out, std::string* err);
+
+// Flatten into an op stream for one model flavour.
+int32_t compile_ops(const HostPopulation& hp, const CompileKey& key, OpStream* out, std::string* err);
+
+}  // namespace pmx

@@ -1,0 +1,643 @@
+// pmx_kernels.hip — hand-written gfx950 kernels for the (subject x support point) prediction grid.
+//
+// One wavefront lane per (subject, support point) pair, two lane mappings:
+//
+//  GRID  lane = support point (fastest index), a block walks a chunk of subjects.
+//        The op stream of a subject is WAVE-UNIFORM: every lane of every wave in the
+//        block executes the same BOLUS/OBS/PROP sequence, so op fetches are scalar
+//        (s_load through the scalar cache), branches are scalar, and there is no
+//        divergence at all.  Stores are pred[row][p0..p0+63]: 512 contiguous bytes per
+//        wave-instruction.  Used when n_support >= 32 (NPAG-style grids, C3/C5).
+//
+//  PAIR  lane = one (subject, support point) pair with its own op cursor; lanes of a
+//        wave run different schedules (divergent timelines), the wave loops until every
+//        lane's cursor reaches its end (exec-masked loop == ballot of "any lane active").
+//        Subjects are pre-sorted by work so neighbouring lanes finish together.
+//        Used for n_support < 32 (C2) and for the batch shape (C4: one theta per subject).
+//
+// States live in registers (1-4 doubles; LDS staging would only add latency), the
+// rate-constant-only part of every closed form is hoisted out of the event loop
+// (pmx_structures.hpp).  No MFMA: 2-6-state systems have no dense contraction.
+//
+// Reference contracts: equation/mod.rs:300-358,480-516 (event loop), analytical/mod.rs:299-426,
+// ode/mod.rs:609-823 (ODE event loop; diffsol replaced by fixed-step RK4).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+
+#include "pmx_kernels.hpp"
+#include "pmx_structures.hpp"
+
+namespace pmx {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ int64_t uniform64(int64_t v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
+  const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(static_cast<uint64_t>(v) >> 32));
+  return static_cast<int64_t>((static_cast<uint64_t>(hi) << 32) | lo);
+}
+__device__ __forceinline__ uint32_t uniform32(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double uniformf64(double v) {
+  return __longlong_as_double(uniform64(__double_as_longlong(v)));
+}
+
+// derive: derived[d] = ((theta[src] * f0) * f1), covariates as seen by the op
+// (expand/analytical.rs:254,286; bindings.rs:98-117).  `base` = theta[src_param].
+__device__ __forceinline__ double apply_factors(const pmx_derived& dd, double base, const double* cov) {
+  double v = base;
+#pragma unroll
+  for (int k = 0; k < PMX_MAX_FACTORS; ++k) {
+    if (k < dd.n_factors) {
+      const pmx_factor& f = dd.f[k];
+      const double cv = cov[f.cov];
+      const double fac = (f.op == PMX_F_POW) ? pow(cv / f.ref, f.coef) : (1.0 + f.coef * (cv - f.ref));
+      v = v * fac;
+    }
+  }
+  return v;
+}
+
+template <int N>
+__device__ __forceinline__ double select_state(const double (&x)[N], int idx) {
+  double v = x[0];
+#pragma unroll
+  for (int i = 1; i < N; ++i) v = (idx == i) ? x[i] : v;
+  return v;
+}
+
+// Everything a lane needs besides its state; filled once per lane.
+template <int KID>
+struct LaneModel {
+  static constexpr int ST = kernel_structure(KID);
+  using S = Structure<ST>;
+  static constexpr int NS = S::NS;
+  static constexpr int NKP = kernel_nparams(KID);
+  typename S::Coef coef;
+  double kp_base[NKP];         // theta[...] for each kernel-order parameter (base value when derived)
+  double vol_base[PMX_MAX_OUT];  // theta[...] behind each output's volume (1.0 when none)
+  double inv_vol[PMX_MAX_OUT];
+  double xinit[NS];
+  bool ok;
+};
+
+template <int KID, bool DYN>
+__device__ __forceinline__ void lane_setup(const DevModel& m, const double* __restrict__ th, LaneModel<KID>& L) {
+  using LM = LaneModel<KID>;
+#pragma unroll
+  for (int j = 0; j < LM::NKP; ++j) {
+    int idx = j;
+    if (m.n_bind > 0) idx = (m.bind[j].src == PMX_SRC_DERIVED) ? m.derived[m.bind[j].index].src_param : m.bind[j].index;
+    L.kp_base[j] = th[idx];
+  }
+#pragma unroll
+  for (int o = 0; o < PMX_MAX_OUT; ++o) {
+    double v = 1.0;
+    if (o < m.nout) {
+      if (m.out[o].vol_src == PMX_SRC_PRIMARY) v = th[m.out[o].vol_index];
+      if (m.out[o].vol_src == PMX_SRC_DERIVED) v = th[m.derived[m.out[o].vol_index].src_param];
+    }
+    L.vol_base[o] = v;
+    L.inv_vol[o] = 1.0 / v;
+  }
+#pragma unroll
+  for (int i = 0; i < LM::NS; ++i) {
+    const int st = i + m.pm;  // model state index of kernel state i
+    L.xinit[i] = (m.has_init && m.init_param[st] >= 0) ? th[m.init_param[st]] : 0.0;
+  }
+  L.ok = true;
+  if constexpr (!DYN) {
+    double q[LM::NKP];
+    to_native_params<KID>(L.kp_base, q);
+    L.ok = LM::S::prepare(q, L.coef);
+  }
+}
+
+// PROP with covariate-derived kernel parameters: rebuild the coefficients for this op.
+template <int KID>
+__device__ __forceinline__ bool lane_prepare_dyn(const DevModel& m, LaneModel<KID>& L, const double* cov) {
+  using LM = LaneModel<KID>;
+  double kp[LM::NKP], q[LM::NKP];
+#pragma unroll
+  for (int j = 0; j < LM::NKP; ++j) {
+    double v = L.kp_base[j];
+    if (m.bind[j].src == PMX_SRC_DERIVED) v = apply_factors(m.derived[m.bind[j].index], v, cov);
+    kp[j] = v;
+  }
+  to_native_params<KID>(kp, q);
+  return LM::S::prepare(q, L.coef);
+}
+
+template <int KID>
+__device__ __forceinline__ double lane_out(const DevModel& m, const LaneModel<KID>& L,
+                                           const double (&x)[LaneModel<KID>::NS], double xpad, int outeq,
+                                           const double* cov) {
+  using LM = LaneModel<KID>;
+  // y[o] = x[state] / vol  (e.g. examples/analytical_vs_ode.rs:82-84)
+  int state = 0, vsrc = PMX_SRC_NONE, vidx = 0;
+  double inv = 1.0, vbase = 1.0;
+#pragma unroll
+  for (int o = 0; o < PMX_MAX_OUT; ++o) {
+    if (o == outeq) {
+      state = m.out[o].state;
+      vsrc = m.out[o].vol_src;
+      vidx = m.out[o].vol_index;
+      inv = L.inv_vol[o];
+      vbase = L.vol_base[o];
+    }
+  }
+  double xs = select_state<LM::NS>(x, state - m.pm);
+  if (m.pm && state == 0) xs = xpad;
+  if (vsrc == PMX_SRC_DERIVED) return xs / apply_factors(m.derived[vidx], vbase, cov);
+  return xs * inv;
+}
+
+// ------------------------------------------------------------------------------------
+// GRID kernel (analytical)
+// ------------------------------------------------------------------------------------
+template <int KID, bool DYN>
+__global__ __launch_bounds__(kBlock) void pmx_analytical_grid(DevModel m, DevOps ops, const double* __restrict__ theta,
+                                                              int64_t P, int64_t S, int32_t s_chunk, int32_t n_ptiles,
+                                                              double* __restrict__ pred, int64_t ld,
+                                                              uint8_t* __restrict__ status) {
+  using LM = LaneModel<KID>;
+  constexpr int NS = LM::NS;
+  const int64_t b = blockIdx.x;
+  const int32_t ptile = static_cast<int32_t>(b % n_ptiles);
+  const int64_t chunk = b / n_ptiles;
+  const int64_t p = static_cast<int64_t>(ptile) * kBlock + threadIdx.x;
+  const bool lane_ok = p < P;
+  const int64_t pc = lane_ok ? p : (P - 1);  // idle lanes shadow the last support point; their stores are masked
+  const double* __restrict__ th = theta + pc * m.nparams;
+
+  LM L;
+  lane_setup<KID, DYN>(m, th, L);
+  const uint8_t st_lane = L.ok ? PMX_PAIR_OK : PMX_PAIR_COMPLEX_ROOTS;
+  const double nanv = __longlong_as_double(0x7ff8000000000000LL);
+
+  const int64_t s_begin = chunk * s_chunk;
+  const int64_t s_end = (s_begin + s_chunk < S) ? (s_begin + s_chunk) : S;
+  for (int64_t s = s_begin; s < s_end; ++s) {
+    const int64_t o0 = uniform64(ops.subj_op_off[s]);
+    const int64_t o1 = uniform64(ops.subj_op_off[s + 1]);
+    int64_t row = uniform64(ops.subj_obs_off[s]);
+    double x[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) x[i] = 0.0;
+    double xpad = 0.0;
+    uint8_t st = st_lane;
+    for (int64_t o = o0; o < o1; ++o) {
+      const uint32_t meta = uniform32(ops.op_meta[o]);
+      const uint32_t kind = meta & 0xffu;
+      const int io = static_cast<int>((meta >> 8) & 0xffffu);
+      const double a = uniformf64(ops.op_a[o]);
+      const double* cov = ops.op_cov + o * m.n_cov;
+      if (kind == OP_PROP) {
+        const double r = uniformf64(ops.op_b[o]);
+        if constexpr (DYN) {
+          if (!lane_prepare_dyn<KID>(m, L, cov)) st = PMX_PAIR_COMPLEX_ROOTS;
+        }
+        LM::S::advance(L.coef, x, a, r);
+        xpad = 0.0;  // pm_* wrappers re-pad slot 0 with 0 after every kernel call (analytical/mod.rs:70-75)
+      } else if (kind == OP_OBS) {
+        double y = lane_out<KID>(m, L, x, xpad, io, cov);
+        if (st == PMX_PAIR_COMPLEX_ROOTS) y = nanv;
+        if (st == PMX_PAIR_OK && !isfinite(y)) st = PMX_PAIR_NONFINITE;
+        if (lane_ok) pred[row * ld + p] = y;
+        ++row;
+      } else if (kind == OP_BOLUS) {
+        const int k = io - m.pm;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) x[i] += (i == k) ? a : 0.0;
+        if (m.pm && io == 0) xpad += a;
+      } else {  // OP_RESET
+#pragma unroll
+        for (int i = 0; i < NS; ++i) x[i] = io ? L.xinit[i] : 0.0;
+        xpad = 0.0;
+        if constexpr (DYN) st = st_lane;  // a new occasion re-derives its coefficients
+      }
+    }
+    if (status != nullptr && lane_ok) status[s * P + p] = st;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// PAIR kernel (analytical): lane = (subject, support point), divergent schedules
+// ------------------------------------------------------------------------------------
+template <int KID, bool DYN>
+__global__ __launch_bounds__(kBlock) void pmx_analytical_pair(DevModel m, DevOps ops, const double* __restrict__ theta,
+                                                              int64_t P, int64_t S, int32_t batch,
+                                                              double* __restrict__ pred, int64_t ld,
+                                                              uint8_t* __restrict__ status) {
+  using LM = LaneModel<KID>;
+  constexpr int NS = LM::NS;
+  const int64_t n_pairs = batch ? S : S * P;
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const bool lane_ok = i < n_pairs;
+  const int64_t ic = lane_ok ? i : (n_pairs - 1);
+  const int64_t s = ops.subj_order[batch ? ic : (ic / P)];
+  const int64_t p = batch ? 0 : (ic % P);
+  const double* __restrict__ th = theta + (batch ? s : p) * m.nparams;
+
+  LM L;
+  lane_setup<KID, DYN>(m, th, L);
+  const uint8_t st_lane = L.ok ? PMX_PAIR_OK : PMX_PAIR_COMPLEX_ROOTS;
+  const double nanv = __longlong_as_double(0x7ff8000000000000LL);
+
+  int64_t o = ops.subj_op_off[s];
+  const int64_t o1 = lane_ok ? ops.subj_op_off[s + 1] : o;  // idle lanes have an empty stream
+  int64_t row = ops.subj_obs_off[s];
+  double x[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) x[k] = 0.0;
+  double xpad = 0.0;
+  uint8_t st = st_lane;
+  // exec-masked loop: runs while ANY lane of the wave still has ops (each lane exits at its own o1)
+  for (; o < o1; ++o) {
+    const uint32_t meta = ops.op_meta[o];
+    const uint32_t kind = meta & 0xffu;
+    const int io = static_cast<int>((meta >> 8) & 0xffffu);
+    const double a = ops.op_a[o];
+    const double* cov = ops.op_cov + o * m.n_cov;
+    if (kind == OP_PROP) {
+      const double r = ops.op_b[o];
+      if constexpr (DYN) {
+        if (!lane_prepare_dyn<KID>(m, L, cov)) st = PMX_PAIR_COMPLEX_ROOTS;
+      }
+      LM::S::advance(L.coef, x, a, r);
+      xpad = 0.0;
+    } else if (kind == OP_OBS) {
+      double y = lane_out<KID>(m, L, x, xpad, io, cov);
+      if (st == PMX_PAIR_COMPLEX_ROOTS) y = nanv;
+      if (st == PMX_PAIR_OK && !isfinite(y)) st = PMX_PAIR_NONFINITE;
+      pred[row * ld + p] = y;
+      ++row;
+    } else if (kind == OP_BOLUS) {
+      const int k = io - m.pm;
+#pragma unroll
+      for (int j = 0; j < NS; ++j) x[j] += (j == k) ? a : 0.0;
+      if (m.pm && io == 0) xpad += a;
+    } else {
+#pragma unroll
+      for (int j = 0; j < NS; ++j) x[j] = io ? L.xinit[j] : 0.0;
+      xpad = 0.0;
+      if constexpr (DYN) st = st_lane;
+    }
+  }
+  if (status != nullptr && lane_ok) status[batch ? s : (s * P + p)] = st;
+}
+
+// ------------------------------------------------------------------------------------
+// ODE: built-in diffeq bodies + classic RK4 (fixed step per constant-rate piece)
+// ------------------------------------------------------------------------------------
+template <int MODEL>
+struct OdeModel;
+
+template <>
+struct OdeModel<PMX_ODE_ONE_CMT_IV> {  // examples/ode_readme.rs:17-19
+  static constexpr int NS = 1, NP = 1, CENTRAL = 0;
+  __device__ __forceinline__ static void rhs(const double* p, const double (&x)[NS], double (&dx)[NS]) {
+    dx[0] = -p[0] * x[0];
+  }
+};
+template <>
+struct OdeModel<PMX_ODE_ONE_CMT_ORAL> {
+  static constexpr int NS = 2, NP = 2, CENTRAL = 1;
+  __device__ __forceinline__ static void rhs(const double* p, const double (&x)[NS], double (&dx)[NS]) {
+    dx[0] = -p[0] * x[0];
+    dx[1] = p[0] * x[0] - p[1] * x[1];
+  }
+};
+template <>
+struct OdeModel<PMX_ODE_TWO_CMT_IV> {  // two_compartment_models.rs:131-136
+  static constexpr int NS = 2, NP = 3, CENTRAL = 0;
+  __device__ __forceinline__ static void rhs(const double* p, const double (&x)[NS], double (&dx)[NS]) {
+    dx[0] = -p[0] * x[0] - p[1] * x[0] + p[2] * x[1];
+    dx[1] = p[1] * x[0] - p[2] * x[1];
+  }
+};
+template <>
+struct OdeModel<PMX_ODE_TWO_CMT_ORAL> {  // two_compartment_models.rs:188-194, p=[ke,ka,kcp,kpc]
+  static constexpr int NS = 3, NP = 4, CENTRAL = 1;
+  __device__ __forceinline__ static void rhs(const double* p, const double (&x)[NS], double (&dx)[NS]) {
+    dx[0] = -p[1] * x[0];
+    dx[1] = -p[0] * x[1] + p[1] * x[0] - p[2] * x[1] + p[3] * x[2];
+    dx[2] = p[2] * x[1] - p[3] * x[2];
+  }
+};
+template <>
+struct OdeModel<PMX_ODE_THREE_CMT_IV> {
+  static constexpr int NS = 3, NP = 5, CENTRAL = 0;
+  __device__ __forceinline__ static void rhs(const double* p, const double (&x)[NS], double (&dx)[NS]) {
+    dx[0] = -(p[0] + p[1] + p[2]) * x[0] + p[3] * x[1] + p[4] * x[2];
+    dx[1] = p[1] * x[0] - p[3] * x[1];
+    dx[2] = p[2] * x[0] - p[4] * x[2];
+  }
+};
+template <>
+struct OdeModel<PMX_ODE_THREE_CMT_ORAL> {
+  static constexpr int NS = 4, NP = 6, CENTRAL = 1;
+  __device__ __forceinline__ static void rhs(const double* p, const double (&x)[NS], double (&dx)[NS]) {
+    dx[0] = -p[0] * x[0];
+    dx[1] = p[0] * x[0] - (p[1] + p[2] + p[3]) * x[1] + p[4] * x[2] + p[5] * x[3];
+    dx[2] = p[2] * x[1] - p[4] * x[2];
+    dx[3] = p[3] * x[1] - p[5] * x[3];
+  }
+};
+template <>
+struct OdeModel<PMX_ODE_ONE_CMT_MM> {  // p=[vmax,km,v]
+  static constexpr int NS = 1, NP = 3, CENTRAL = 0;
+  __device__ __forceinline__ static void rhs(const double* p, const double (&x)[NS], double (&dx)[NS]) {
+    const double cc = x[0] / p[2];
+    dx[0] = -p[0] * cc / (p[1] + cc);
+  }
+};
+
+// one classic RK4 step of dx = rhs(x) + rs   (rs = per-state infusion rates, constant over the piece)
+template <int MODEL>
+__device__ __forceinline__ void rk4_step(const double* kp, double (&x)[OdeModel<MODEL>::NS],
+                                         const double (&rs)[OdeModel<MODEL>::NS], double h) {
+  using M = OdeModel<MODEL>;
+  constexpr int NS = M::NS;
+  double k1[NS], k2[NS], k3[NS], k4[NS], xt[NS];
+  M::rhs(kp, x, k1);
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    k1[i] += rs[i];
+    xt[i] = x[i] + (0.5 * h) * k1[i];
+  }
+  M::rhs(kp, xt, k2);
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    k2[i] += rs[i];
+    xt[i] = x[i] + (0.5 * h) * k2[i];
+  }
+  M::rhs(kp, xt, k3);
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    k3[i] += rs[i];
+    xt[i] = x[i] + h * k3[i];
+  }
+  M::rhs(kp, xt, k4);
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    k4[i] += rs[i];
+    x[i] = x[i] + (h / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+  }
+}
+
+template <int MODEL>
+struct OdeLane {
+  using M = OdeModel<MODEL>;
+  double kp[M::NP];
+  double inv_vol[PMX_MAX_OUT];
+  double xinit[M::NS];
+};
+
+template <int MODEL>
+__device__ __forceinline__ void ode_lane_setup(const DevModel& m, const double* __restrict__ th, OdeLane<MODEL>& L) {
+  using M = OdeModel<MODEL>;
+#pragma unroll
+  for (int j = 0; j < M::NP; ++j) L.kp[j] = th[j];
+#pragma unroll
+  for (int o = 0; o < PMX_MAX_OUT; ++o) {
+    double v = 1.0;
+    if (o < m.nout && m.out[o].vol_src == PMX_SRC_PRIMARY) v = th[m.out[o].vol_index];
+    L.inv_vol[o] = 1.0 / v;
+  }
+#pragma unroll
+  for (int i = 0; i < M::NS; ++i) L.xinit[i] = (m.has_init && m.init_param[i] >= 0) ? th[m.init_param[i]] : 0.0;
+}
+
+template <int MODEL>
+__device__ __forceinline__ double ode_out(const DevModel& m, const OdeLane<MODEL>& L,
+                                          const double (&x)[OdeModel<MODEL>::NS], int outeq) {
+  int state = 0;
+  double inv = 1.0;
+#pragma unroll
+  for (int o = 0; o < PMX_MAX_OUT; ++o) {
+    if (o == outeq) {
+      state = m.out[o].state;
+      inv = L.inv_vol[o];
+    }
+  }
+  return select_state<OdeModel<MODEL>::NS>(x, state) * inv;
+}
+
+// per-state rate vector of a PROP op: dx[dest(input)] += rateiv[input]  (expand/ode.rs:380-406)
+template <int MODEL>
+__device__ __forceinline__ void ode_rates(const DevModel& m, const double* __restrict__ op_rate, int64_t o, int n_rate,
+                                          double (&rs)[OdeModel<MODEL>::NS]) {
+  using M = OdeModel<MODEL>;
+#pragma unroll
+  for (int i = 0; i < M::NS; ++i) rs[i] = 0.0;
+  for (int k = 0; k < n_rate; ++k) {
+    const double r = op_rate[o * n_rate + k];
+    const int dest = (m.infusion_dest[k] >= 0) ? m.infusion_dest[k] : M::CENTRAL;
+#pragma unroll
+    for (int i = 0; i < M::NS; ++i) rs[i] += (i == dest) ? r : 0.0;
+  }
+}
+
+template <int MODEL>
+__global__ __launch_bounds__(kBlock) void pmx_ode_rk4_grid(DevModel m, DevOps ops, const double* __restrict__ theta,
+                                                           int64_t P, int64_t S, int32_t s_chunk, int32_t n_ptiles,
+                                                           double* __restrict__ pred, int64_t ld,
+                                                           uint8_t* __restrict__ status) {
+  using M = OdeModel<MODEL>;
+  constexpr int NS = M::NS;
+  const int64_t b = blockIdx.x;
+  const int32_t ptile = static_cast<int32_t>(b % n_ptiles);
+  const int64_t chunk = b / n_ptiles;
+  const int64_t p = static_cast<int64_t>(ptile) * kBlock + threadIdx.x;
+  const bool lane_ok = p < P;
+  const int64_t pc = lane_ok ? p : (P - 1);
+  OdeLane<MODEL> L;
+  ode_lane_setup<MODEL>(m, theta + pc * m.nparams, L);
+  const int64_t s_begin = chunk * s_chunk;
+  const int64_t s_end = (s_begin + s_chunk < S) ? (s_begin + s_chunk) : S;
+  for (int64_t s = s_begin; s < s_end; ++s) {
+    const int64_t o0 = uniform64(ops.subj_op_off[s]);
+    const int64_t o1 = uniform64(ops.subj_op_off[s + 1]);
+    int64_t row = uniform64(ops.subj_obs_off[s]);
+    double x[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) x[i] = 0.0;
+    uint8_t st = PMX_PAIR_OK;
+    for (int64_t o = o0; o < o1; ++o) {
+      const uint32_t meta = uniform32(ops.op_meta[o]);
+      const uint32_t kind = meta & 0xffu;
+      const int io = static_cast<int>((meta >> 8) & 0xffffu);
+      const double a = uniformf64(ops.op_a[o]);
+      if (kind == OP_PROP) {
+        const double h = uniformf64(ops.op_b[o]);
+        const int32_t n = static_cast<int32_t>(uniform32(static_cast<uint32_t>(ops.op_n[o])));
+        double rs[NS];
+        ode_rates<MODEL>(m, ops.op_rate, o, ops.n_rate, rs);
+        for (int32_t k = 0; k < n; ++k) rk4_step<MODEL>(L.kp, x, rs, h);
+      } else if (kind == OP_OBS) {
+        const double y = ode_out<MODEL>(m, L, x, io);
+        if (st == PMX_PAIR_OK && !isfinite(y)) st = PMX_PAIR_NONFINITE;
+        if (lane_ok) pred[row * ld + p] = y;
+        ++row;
+      } else if (kind == OP_BOLUS) {
+        const int dest = (m.bolus_dest[io] >= 0) ? m.bolus_dest[io] : io;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) x[i] += (i == dest) ? a : 0.0;
+      } else {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) x[i] = io ? L.xinit[i] : 0.0;
+      }
+    }
+    if (status != nullptr && lane_ok) status[s * P + p] = st;
+  }
+}
+
+// PAIR: each lane is a small state machine {cursor o, remaining RK4 steps}; one trip of the
+// wave loop performs either one RK4 step or one op per lane, so lanes in different segments
+// of different subjects still step in lock-step (divergent timelines, C4).
+template <int MODEL>
+__global__ __launch_bounds__(kBlock) void pmx_ode_rk4_pair(DevModel m, DevOps ops, const double* __restrict__ theta,
+                                                           int64_t P, int64_t S, int32_t batch,
+                                                           double* __restrict__ pred, int64_t ld,
+                                                           uint8_t* __restrict__ status) {
+  using M = OdeModel<MODEL>;
+  constexpr int NS = M::NS;
+  const int64_t n_pairs = batch ? S : S * P;
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const bool lane_ok = i < n_pairs;
+  const int64_t ic = lane_ok ? i : (n_pairs - 1);
+  const int64_t s = ops.subj_order[batch ? ic : (ic / P)];
+  const int64_t p = batch ? 0 : (ic % P);
+  OdeLane<MODEL> L;
+  ode_lane_setup<MODEL>(m, theta + (batch ? s : p) * m.nparams, L);
+
+  int64_t o = ops.subj_op_off[s];
+  const int64_t o1 = lane_ok ? ops.subj_op_off[s + 1] : o;
+  int64_t row = ops.subj_obs_off[s];
+  double x[NS], rs[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    x[k] = 0.0;
+    rs[k] = 0.0;
+  }
+  int32_t rem = 0;
+  double h = 0.0;
+  uint8_t st = PMX_PAIR_OK;
+  while (rem > 0 || o < o1) {
+    if (rem > 0) {
+      rk4_step<MODEL>(L.kp, x, rs, h);
+      --rem;
+    } else {
+      const uint32_t meta = ops.op_meta[o];
+      const uint32_t kind = meta & 0xffu;
+      const int io = static_cast<int>((meta >> 8) & 0xffffu);
+      const double a = ops.op_a[o];
+      if (kind == OP_PROP) {
+        h = ops.op_b[o];
+        rem = ops.op_n[o];
+        ode_rates<MODEL>(m, ops.op_rate, o, ops.n_rate, rs);
+      } else if (kind == OP_OBS) {
+        const double y = ode_out<MODEL>(m, L, x, io);
+        if (st == PMX_PAIR_OK && !isfinite(y)) st = PMX_PAIR_NONFINITE;
+        pred[row * ld + p] = y;
+        ++row;
+      } else if (kind == OP_BOLUS) {
+        const int dest = (m.bolus_dest[io] >= 0) ? m.bolus_dest[io] : io;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) x[j] += (j == dest) ? a : 0.0;
+      } else {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) x[j] = io ? L.xinit[j] : 0.0;
+      }
+      ++o;
+    }
+  }
+  if (status != nullptr && lane_ok) status[batch ? s : (s * P + p)] = st;
+}
+
+// ------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------
+template <int KID, bool DYN>
+hipError_t launch_analytical(const LaunchArgs& a, const char** name) {
+  static const char* const kNameGrid = DYN ? "pmx_analytical_grid<dyn>" : "pmx_analytical_grid";
+  static const char* const kNamePair = DYN ? "pmx_analytical_pair<dyn>" : "pmx_analytical_pair";
+  hipStream_t st = static_cast<hipStream_t>(a.stream);
+  if (a.mode == MODE_GRID) {
+    *name = kNameGrid;
+    const int64_t n_chunks = (a.S + a.s_chunk - 1) / a.s_chunk;
+    const int64_t blocks = n_chunks * a.n_ptiles;
+    hipLaunchKernelGGL((pmx_analytical_grid<KID, DYN>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlock), 0, st, a.m,
+                       a.ops, a.theta, a.P, a.S, a.s_chunk, a.n_ptiles, a.pred, a.ld, a.status);
+  } else {
+    *name = kNamePair;
+    const int64_t n_pairs = a.batch ? a.S : a.S * a.P;
+    const int64_t blocks = (n_pairs + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL((pmx_analytical_pair<KID, DYN>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlock), 0, st, a.m,
+                       a.ops, a.theta, a.P, a.S, a.batch, a.pred, a.ld, a.status);
+  }
+  return hipGetLastError();
+}
+
+template <int MODEL>
+hipError_t launch_ode(const LaunchArgs& a, const char** name) {
+  hipStream_t st = static_cast<hipStream_t>(a.stream);
+  if (a.mode == MODE_GRID) {
+    *name = "pmx_ode_rk4_grid";
+    const int64_t n_chunks = (a.S + a.s_chunk - 1) / a.s_chunk;
+    const int64_t blocks = n_chunks * a.n_ptiles;
+    hipLaunchKernelGGL((pmx_ode_rk4_grid<MODEL>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlock), 0, st, a.m, a.ops,
+                       a.theta, a.P, a.S, a.s_chunk, a.n_ptiles, a.pred, a.ld, a.status);
+  } else {
+    *name = "pmx_ode_rk4_pair";
+    const int64_t n_pairs = a.batch ? a.S : a.S * a.P;
+    const int64_t blocks = (n_pairs + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL((pmx_ode_rk4_pair<MODEL>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlock), 0, st, a.m, a.ops,
+                       a.theta, a.P, a.S, a.batch, a.pred, a.ld, a.status);
+  }
+  return hipGetLastError();
+}
+
+template <int KID>
+hipError_t launch_analytical_k(const LaunchArgs& a, const char** name) {
+  return a.dyn ? launch_analytical<KID, true>(a, name) : launch_analytical<KID, false>(a, name);
+}
+
+}  // namespace
+
+hipError_t launch_predict(const LaunchArgs& a, const char** name) {
+  if (a.S <= 0 || (a.P <= 0 && !a.batch)) return hipSuccess;
+  if (a.m.eq_kind == PMX_EQ_ANALYTICAL) {
+    switch (a.m.kernel) {
+      case 0: return launch_analytical_k<0>(a, name);
+      case 1: return launch_analytical_k<1>(a, name);
+      case 2: return launch_analytical_k<2>(a, name);
+      case 3: return launch_analytical_k<3>(a, name);
+      case 4: return launch_analytical_k<4>(a, name);
+      case 5: return launch_analytical_k<5>(a, name);
+      case 6: return launch_analytical_k<6>(a, name);
+      case 7: return launch_analytical_k<7>(a, name);
+      case 8: return launch_analytical_k<8>(a, name);
+      case 9: return launch_analytical_k<9>(a, name);
+      case 10: return launch_analytical_k<10>(a, name);
+      case 11: return launch_analytical_k<11>(a, name);
+      default: return hipErrorInvalidValue;
+    }
+  }
+  switch (a.m.kernel) {
+    case PMX_ODE_ONE_CMT_IV: return launch_ode<PMX_ODE_ONE_CMT_IV>(a, name);
+    case PMX_ODE_ONE_CMT_ORAL: return launch_ode<PMX_ODE_ONE_CMT_ORAL>(a, name);
+    case PMX_ODE_TWO_CMT_IV: return launch_ode<PMX_ODE_TWO_CMT_IV>(a, name);
+    case PMX_ODE_TWO_CMT_ORAL: return launch_ode<PMX_ODE_TWO_CMT_ORAL>(a, name);
+    case PMX_ODE_THREE_CMT_IV: return launch_ode<PMX_ODE_THREE_CMT_IV>(a, name);
+    case PMX_ODE_THREE_CMT_ORAL: return launch_ode<PMX_ODE_THREE_CMT_ORAL>(a, name);
+    case PMX_ODE_ONE_CMT_MM: return launch_ode<PMX_ODE_ONE_CMT_MM>(a, name);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace pmx

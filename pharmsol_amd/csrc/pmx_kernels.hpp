@@ -1,0 +1,63 @@
+// pmx_kernels.hpp — host <-> device launch contract (internal to libpmx_hip.so).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/pmx.h"
+#include "pmx_compile.hpp"
+
+namespace pmx {
+
+// Model description as the kernels see it (passed by value in the kernarg segment).
+struct DevModel {
+  int32_t eq_kind, kernel;
+  int32_t nparams, n_cov, n_derived, n_bind, nout, pm;
+  int32_t has_init;
+  int32_t pad_;
+  pmx_derived derived[PMX_MAX_DERIVED];
+  pmx_bind bind[PMX_MAX_KPARAMS];
+  pmx_out out[PMX_MAX_OUT];
+  int32_t init_param[PMX_MAX_STATES];
+  int32_t bolus_dest[PMX_MAX_INPUTS];
+  int32_t infusion_dest[PMX_MAX_INPUTS];
+};
+
+// Device mirror of an OpStream (all pointers are device pointers).
+struct DevOps {
+  const int64_t* subj_op_off;   // [S+1]
+  const int64_t* subj_obs_off;  // [S+1]
+  const int32_t* subj_order;    // [S]
+  const uint32_t* op_meta;      // [n_ops]
+  const double* op_a;           // [n_ops]
+  const double* op_b;           // [n_ops]
+  const int32_t* op_n;          // [n_ops] (ODE)
+  const double* op_rate;        // [n_ops*n_rate] (ODE)
+  const double* op_cov;         // [n_ops*n_cov]
+  int32_t n_rate;
+  int32_t pad_;
+};
+
+enum LaneMode : int32_t { MODE_GRID = 0, MODE_PAIR = 1 };
+
+struct LaunchArgs {
+  DevModel m;
+  DevOps ops;
+  const double* theta;
+  int64_t P, S;
+  double* pred;
+  int64_t ld;
+  uint8_t* status;
+  int32_t mode;      // LaneMode
+  int32_t batch;     // PAIR only: subject s uses theta row s
+  int32_t s_chunk;   // GRID: subjects walked by one block
+  int32_t n_ptiles;  // GRID: ceil(P / 256)
+  int32_t dyn;       // analytical: kernel parameters depend on covariates (re-prepare per PROP)
+  void* stream;
+};
+
+// Enqueue the prediction kernel; *name receives a static string naming the kernel family.
+hipError_t launch_predict(const LaunchArgs& a, const char** name);
+
+}  // namespace pmx

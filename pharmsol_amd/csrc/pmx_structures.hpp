@@ -1,0 +1,357 @@
+// pmx_structures.hpp — closed-form compartment propagators as device functors.
+//
+// Arithmetic contracts (f64 throughout, src/simulator/mod.rs:14):
+//   one_compartment                      one_compartment_models.rs:12-19
+//   one_compartment_with_absorption      one_compartment_models.rs:32-44
+//   two_compartments                     two_compartment_models.rs:14-48
+//   two_compartments_with_absorption     two_compartment_models.rs:61-112
+//   three_compartments                   three_compartment_models.rs:17-109
+//   three_compartments_with_absorption   three_compartment_models.rs:126-240
+//   CL re-parameterisations              {one,two,three}_compartment_cl_models.rs
+//
+// The reference recomputes eigenvalues and all coefficient quotients on EVERY
+// sub-segment.  Here each structure is split into
+//   prepare(kp)  -> Coef : everything that depends on the rate constants only
+//                          (eigenvalues, coefficient quotients as reciprocals)
+//   advance(Coef, x, dt, r)  : the exp() calls and the state update
+// so that a lane whose rate constants are fixed (no covariate-derived parameter)
+// prepares once and only pays exp + a handful of FMAs per sub-segment.
+// Divisions by (l1-l2), l_i, (ka-l_i) become multiplications by reciprocals
+// computed in prepare(): results differ from the reference by a few ulp
+// (parity budget 1e-6 relative, tests/test_gpu_parity.py).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace pmx {
+
+enum StructId : int { S_ONE = 0, S_ONE_ABS = 1, S_TWO = 2, S_TWO_ABS = 3, S_THREE = 4, S_THREE_ABS = 5 };
+
+// kernel id (include/pmx.h PMX_K_*) -> structure / CL flag, usable on host and device
+__host__ __device__ constexpr int kernel_structure(int k) {
+  return (k == 0 || k == 1) ? S_ONE
+         : (k == 2 || k == 3) ? S_ONE_ABS
+         : (k == 4 || k == 5) ? S_TWO
+         : (k == 6 || k == 7) ? S_TWO_ABS
+         : (k == 8 || k == 9) ? S_THREE
+                              : S_THREE_ABS;
+}
+__host__ __device__ constexpr bool kernel_is_cl(int k) { return k == 1 || k == 2 || k == 5 || k == 6 || k == 9 || k == 10; }
+__host__ __device__ constexpr int kernel_nparams(int k) {
+  return k == 0 ? 1 : k == 1 ? 2 : k == 2 ? 3 : k == 3 ? 2 : k == 4 ? 3 : k == 5 ? 4 : k == 6 ? 5 : k == 7 ? 4
+         : k == 8 ? 5 : k == 9 ? 6 : k == 10 ? 7 : 6;
+}
+
+// CL -> micro-constant conversion, in the structure's native parameter order.
+template <int KID>
+__device__ __forceinline__ void to_native_params(const double* p, double* q) {
+  if constexpr (KID == 1) {  // one_compartment_cl_models.rs:16-22
+    q[0] = p[0] / p[1];
+  } else if constexpr (KID == 2) {  // :38-45  [ka, ke]
+    q[0] = p[0];
+    q[1] = p[1] / p[2];
+  } else if constexpr (KID == 5) {  // two_compartment_cl_models.rs:16-26  [ke,kcp,kpc]
+    q[0] = p[0] / p[2];
+    q[1] = p[1] / p[2];
+    q[2] = p[1] / p[3];
+  } else if constexpr (KID == 6) {  // :41-53  [ke,ka,kcp,kpc]
+    q[0] = p[1] / p[3];
+    q[1] = p[0];
+    q[2] = p[2] / p[3];
+    q[3] = p[2] / p[4];
+  } else if constexpr (KID == 9) {  // three_compartment_cl_models.rs:16-31  [k10,k12,k13,k21,k31]
+    q[0] = p[0] / p[3];
+    q[1] = p[1] / p[3];
+    q[2] = p[2] / p[3];
+    q[3] = p[1] / p[4];
+    q[4] = p[2] / p[5];
+  } else if constexpr (KID == 10) {  // :46-67  [ka,k10,k12,k13,k21,k31]
+    q[0] = p[0];
+    q[1] = p[1] / p[4];
+    q[2] = p[2] / p[4];
+    q[3] = p[3] / p[4];
+    q[4] = p[2] / p[5];
+    q[5] = p[3] / p[6];
+  } else {
+    constexpr int n = kernel_nparams(KID);
+#pragma unroll
+    for (int i = 0; i < n; ++i) q[i] = p[i];
+  }
+}
+
+template <int ST>
+struct Structure;
+
+// ---------------------------------------------------------------- one compartment
+template <>
+struct Structure<S_ONE> {
+  static constexpr int NS = 1;
+  struct Coef {
+    double ke, inv_ke;
+  };
+  __device__ __forceinline__ static bool prepare(const double* kp, Coef& c) {
+    c.ke = kp[0];
+    c.inv_ke = 1.0 / kp[0];
+    return true;
+  }
+  __device__ __forceinline__ static void advance(const Coef& c, double (&x)[NS], double dt, double r) {
+    const double e = exp(-c.ke * dt);
+    x[0] = x[0] * e + (r * c.inv_ke) * (1.0 - e);
+  }
+};
+
+template <>
+struct Structure<S_ONE_ABS> {
+  static constexpr int NS = 2;
+  struct Coef {
+    double ka, ke, inv_ke, ka_over;  // ka_over = ka / (ka - ke)
+  };
+  __device__ __forceinline__ static bool prepare(const double* kp, Coef& c) {
+    c.ka = kp[0];
+    c.ke = kp[1];
+    c.inv_ke = 1.0 / kp[1];
+    c.ka_over = kp[0] / (kp[0] - kp[1]);
+    return true;
+  }
+  __device__ __forceinline__ static void advance(const Coef& c, double (&x)[NS], double dt, double r) {
+    const double ea = exp(-c.ka * dt);
+    const double ee = exp(-c.ke * dt);
+    const double g = x[0];
+    x[0] = g * ea;
+    x[1] = x[1] * ee + (r * c.inv_ke) * (1.0 - ee) + (c.ka_over * g) * (ee - ea);
+  }
+};
+
+// ---------------------------------------------------------------- two compartments
+struct TwoCore {
+  double l1, l2, inv_d;       // inv_d = 1/(l1-l2)
+  double a11, b11, kpc, kcp;  // M11 = a11 E1 + b11 E2 ; M12 = kpc (E2-E1) ; M21 = kcp (E2-E1)
+  double a22, b22;            // M22 = a22 E1 + b22 E2
+  double i0a, i0b, i1a, i1b;  // infusion vector: I0 = i0a(1-E1)+i0b(1-E2), I1 = i1a(1-E1)+i1b(1-E2)
+  __device__ __forceinline__ bool prepare(double ke, double kcp_, double kpc_) {
+    const double s = ke + kcp_ + kpc_;
+    double disc = s * s - 4.0 * ke * kpc_;
+    const bool ok = !(disc < 0.0);  // reference panics on disc < 0 (two_compartment_models.rs:20-22)
+    disc = sqrt(disc);
+    l1 = (s + disc) / 2.0;
+    l2 = (s - disc) / 2.0;
+    inv_d = 1.0 / (l1 - l2);
+    a11 = l1 - kpc_;
+    b11 = kpc_ - l2;
+    kpc = kpc_;
+    kcp = kcp_;
+    a22 = l1 - ke - kcp_;
+    b22 = ke + kcp_ - l2;
+    i0a = a11 / l1;
+    i0b = b11 / l2;
+    i1a = -kcp_ / l1;
+    i1b = kcp_ / l2;
+    return ok;
+  }
+};
+
+template <>
+struct Structure<S_TWO> {
+  static constexpr int NS = 2;
+  struct Coef {
+    TwoCore t;
+  };
+  __device__ __forceinline__ static bool prepare(const double* kp, Coef& c) { return c.t.prepare(kp[0], kp[1], kp[2]); }
+  __device__ __forceinline__ static void advance(const Coef& c, double (&x)[NS], double dt, double r) {
+    const TwoCore& t = c.t;
+    const double e1 = exp(-t.l1 * dt);
+    const double e2 = exp(-t.l2 * dt);
+    const double de = e2 - e1;
+    const double m11 = t.a11 * e1 + t.b11 * e2;
+    const double m12 = t.kpc * de;
+    const double m21 = t.kcp * de;
+    const double m22 = t.a22 * e1 + t.b22 * e2;
+    double n0 = (m11 * x[0] + m12 * x[1]) * t.inv_d;
+    double n1 = (m21 * x[0] + m22 * x[1]) * t.inv_d;
+    if (r != 0.0) {
+      const double f = r * t.inv_d;
+      const double o1 = 1.0 - e1, o2 = 1.0 - e2;
+      n0 += (t.i0a * o1 + t.i0b * o2) * f;
+      n1 += (t.i1a * o1 + t.i1b * o2) * f;
+    }
+    x[0] = n0;
+    x[1] = n1;
+  }
+};
+
+template <>
+struct Structure<S_TWO_ABS> {
+  static constexpr int NS = 3;
+  struct Coef {
+    TwoCore t;
+    double ka, a0a, a0b, a1a, a1b;  // absorption vector quotients: (l1-kpc)/(ka-l1) ...
+  };
+  __device__ __forceinline__ static bool prepare(const double* kp, Coef& c) {
+    // native order [ke, ka, kcp, kpc] (two_compartment_models.rs:62-65)
+    const bool ok = c.t.prepare(kp[0], kp[2], kp[3]);
+    c.ka = kp[1];
+    const double r1 = 1.0 / (c.ka - c.t.l1), r2 = 1.0 / (c.ka - c.t.l2);
+    c.a0a = c.t.a11 * r1;
+    c.a0b = c.t.b11 * r2;
+    c.a1a = -c.t.kcp * r1;
+    c.a1b = c.t.kcp * r2;
+    return ok;
+  }
+  __device__ __forceinline__ static void advance(const Coef& c, double (&x)[NS], double dt, double r) {
+    const TwoCore& t = c.t;
+    const double e1 = exp(-t.l1 * dt);
+    const double e2 = exp(-t.l2 * dt);
+    const double ea = exp(-c.ka * dt);
+    const double de = e2 - e1;
+    const double m11 = t.a11 * e1 + t.b11 * e2;
+    const double m12 = t.kpc * de;
+    const double m21 = t.kcp * de;
+    const double m22 = t.a22 * e1 + t.b22 * e2;
+    const double g = x[0];
+    double n0 = (m11 * x[1] + m12 * x[2]) * t.inv_d;
+    double n1 = (m21 * x[1] + m22 * x[2]) * t.inv_d;
+    if (r != 0.0) {
+      const double f = r * t.inv_d;
+      const double o1 = 1.0 - e1, o2 = 1.0 - e2;
+      n0 += (t.i0a * o1 + t.i0b * o2) * f;
+      n1 += (t.i1a * o1 + t.i1b * o2) * f;
+    }
+    const double h = c.ka * g * t.inv_d;  // :103
+    const double d1 = e1 - ea, d2 = e2 - ea;
+    n0 += (c.a0a * d1 + c.a0b * d2) * h;
+    n1 += (c.a1a * d1 + c.a1b * d2) * h;
+    x[0] = g * ea;
+    x[1] = n0;
+    x[2] = n1;
+  }
+};
+
+// ---------------------------------------------------------------- three compartments
+struct ThreeCore {
+  double l[3];
+  double c[27];  // c[3*j + i]: row-major matrix entry j (0..8), eigenvalue i  == reference c_{3j+i+1}
+  double d[9];   // d[3*row + i] = C_{row,1}^{(i)} / l_i        (infusion vector quotients)
+  // eigen-solve + coefficients: three_compartment_models.rs:24-77
+  __device__ __forceinline__ bool prepare(double k10, double k12, double k13, double k21, double k31) {
+    const double a = k10 + k12 + k13 + k21 + k31;
+    const double b = k10 * k21 + k13 * k21 + k10 * k31 + k12 * k31 + k21 * k31;
+    const double cc = k10 * k21 * k31;
+    const double m = (3.0 * b - a * a) / 3.0;
+    const double n = (2.0 * (a * a * a) - 9.0 * a * b + 27.0 * cc) / 27.0;
+    const double q = (n * n) / 4.0 + (m * m * m) / 27.0;
+    const bool ok = !(q > 0.0);  // reference panics on q > 0 (:32-34)
+    const double alpha = sqrt(-q);
+    const double beta = -n / 2.0;
+    const double gamma = sqrt(beta * beta + alpha * alpha);
+    const double theta = atan2(alpha, beta);
+    const double cr = cbrt(gamma);  // reference: gamma.powf(1.0/3.0)
+    double sn, cs;
+    sincos(theta / 3.0, &sn, &cs);
+    const double rt3 = 1.7320508075688772;
+    l[0] = a / 3.0 + cr * (cs + rt3 * sn);
+    l[1] = a / 3.0 + cr * (cs - rt3 * sn);
+    l[2] = a / 3.0 - (2.0 * cr * cs);
+    const double K = k10 + k12 + k13;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const double li = l[i];
+      const double lo1 = l[(i + 1) % 3], lo2 = l[(i + 2) % 3];
+      const double inv = 1.0 / ((lo1 - li) * (lo2 - li));  // d_i
+      const double u = k21 - li, v = k31 - li, w = K - li;
+      c[0 * 3 + i] = u * v * inv;                    // c1..3
+      c[1 * 3 + i] = k21 * v * inv;                  // c4..6
+      c[2 * 3 + i] = k31 * u * inv;                  // c7..9
+      c[3 * 3 + i] = k12 * v * inv;                  // c10..12
+      c[4 * 3 + i] = (w * v - k13 * k31) * inv;      // c13..15
+      c[5 * 3 + i] = k12 * k31 * inv;                // c16..18
+      c[6 * 3 + i] = k13 * u * inv;                  // c19..21
+      c[7 * 3 + i] = k21 * k13 * inv;                // c22..24
+      c[8 * 3 + i] = (w * u - k12 * k21) * inv;      // c25..27
+      const double il = 1.0 / li;
+      d[0 * 3 + i] = c[0 * 3 + i] * il;
+      d[1 * 3 + i] = c[3 * 3 + i] * il;
+      d[2 * 3 + i] = c[6 * 3 + i] * il;
+    }
+    return ok;
+  }
+  __device__ __forceinline__ void apply(const double (&e)[3], double x0, double x1, double x2, double r, double& y0,
+                                        double& y1, double& y2) const {
+    double mm[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) mm[j] = c[3 * j] * e[0] + c[3 * j + 1] * e[1] + c[3 * j + 2] * e[2];
+    y0 = mm[0] * x0 + mm[1] * x1 + mm[2] * x2;
+    y1 = mm[3] * x0 + mm[4] * x1 + mm[5] * x2;
+    y2 = mm[6] * x0 + mm[7] * x1 + mm[8] * x2;
+    if (r != 0.0) {
+      const double o0 = 1.0 - e[0], o1 = 1.0 - e[1], o2 = 1.0 - e[2];
+      y0 += (o0 * d[0] + o1 * d[1] + o2 * d[2]) * r;
+      y1 += (o0 * d[3] + o1 * d[4] + o2 * d[5]) * r;
+      y2 += (o0 * d[6] + o1 * d[7] + o2 * d[8]) * r;
+    }
+  }
+};
+
+template <>
+struct Structure<S_THREE> {
+  static constexpr int NS = 3;
+  struct Coef {
+    ThreeCore t;
+  };
+  __device__ __forceinline__ static bool prepare(const double* kp, Coef& c) {
+    return c.t.prepare(kp[0], kp[1], kp[2], kp[3], kp[4]);
+  }
+  __device__ __forceinline__ static void advance(const Coef& c, double (&x)[NS], double dt, double r) {
+    double e[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) e[i] = exp(-(c.t.l[i] * dt));
+    double y0, y1, y2;
+    c.t.apply(e, x[0], x[1], x[2], r, y0, y1, y2);
+    x[0] = y0;
+    x[1] = y1;
+    x[2] = y2;
+  }
+};
+
+template <>
+struct Structure<S_THREE_ABS> {
+  static constexpr int NS = 4;
+  struct Coef {
+    ThreeCore t;
+    double ka;
+    double f[9];  // f[3*row + i] = C_{row,1}^{(i)} / (ka - l_i)   (:218-228)
+  };
+  __device__ __forceinline__ static bool prepare(const double* kp, Coef& c) {
+    const bool ok = c.t.prepare(kp[1], kp[2], kp[3], kp[4], kp[5]);
+    c.ka = kp[0];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const double inv = 1.0 / (c.ka - c.t.l[i]);
+      c.f[0 * 3 + i] = c.t.c[0 * 3 + i] * inv;
+      c.f[1 * 3 + i] = c.t.c[3 * 3 + i] * inv;
+      c.f[2 * 3 + i] = c.t.c[6 * 3 + i] * inv;
+    }
+    return ok;
+  }
+  __device__ __forceinline__ static void advance(const Coef& c, double (&x)[NS], double dt, double r) {
+    double e[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) e[i] = exp(-(c.t.l[i] * dt));
+    const double ea = exp(-c.ka * dt);
+    const double g = x[0];
+    double y0, y1, y2;
+    c.t.apply(e, x[1], x[2], x[3], r, y0, y1, y2);
+    const double h = c.ka * g;  // absorption_vector * ka * x[0]  (:230)
+    const double d0 = e[0] - ea, d1 = e[1] - ea, d2 = e[2] - ea;
+    y0 += (d0 * c.f[0] + d1 * c.f[1] + d2 * c.f[2]) * h;
+    y1 += (d0 * c.f[3] + d1 * c.f[4] + d2 * c.f[5]) * h;
+    y2 += (d0 * c.f[6] + d1 * c.f[7] + d2 * c.f[8]) * h;
+    x[0] = g * ea;
+    x[1] = y0;
+    x[2] = y1;
+    x[3] = y2;
+  }
+};
+
+}  // namespace pmx

@@ -1,0 +1,171 @@
+"""Device-resident handles over the C ABI.
+
+``DevicePopulation`` = ``pmx_population*`` (flattened events uploaded once, like the
+reference's ``Data`` living across NPAG cycles); ``DeviceModel`` = ``pmx_model*``.
+``predict`` takes/returns torch tensors resident in HBM and enqueues on torch's
+current stream (PyTorch is plumbing here: device memory + streams).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _abi, _ffi
+from .flatten import FlatPopulation
+
+
+def device_count() -> int:
+    return int(_ffi.lib().pmx_device_count())
+
+
+class DeviceModel:
+    def __init__(self, model):
+        self.model = model
+        self.desc = model.desc() if not isinstance(model, _abi.pmx_model_desc) else model
+        h = C.c_void_p()
+        _ffi.check(_ffi.lib().pmx_model_create(C.byref(self.desc), C.byref(h)))
+        self.handle = h
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h and _ffi is not None and _ffi._lib is not None:  # (module globals vanish at interpreter exit)
+            _ffi._lib.pmx_model_destroy(h)
+            self.handle = None
+
+
+class DevicePopulation:
+    def __init__(self, flat: FlatPopulation, device: int = 0):
+        L = _ffi.lib()
+        self.flat = flat
+        self.device = int(device)
+        d = flat.desc()
+        h = C.c_void_p()
+        _ffi.check(L.pmx_population_create(C.byref(d), self.device, C.byref(h)))
+        self.handle = h
+        self.n_subjects = int(L.pmx_population_n_subjects(h))
+        self.n_observations = int(L.pmx_population_n_observations(h))
+        self.n_events = int(L.pmx_population_n_events(h))
+
+    def observation_offsets(self) -> np.ndarray:
+        off = np.zeros(self.n_subjects + 1, dtype=np.int64)
+        _ffi.check(_ffi.lib().pmx_population_observation_offsets(self.handle, off.ctypes.data))
+        return off
+
+    def observation_info(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        t = np.zeros(self.n_observations, dtype=np.float64)
+        o = np.zeros(self.n_observations, dtype=np.int32)
+        s = np.zeros(self.n_observations, dtype=np.int64)
+        _ffi.check(_ffi.lib().pmx_population_observation_info(self.handle, t.ctypes.data, o.ctypes.data, s.ctypes.data))
+        return t, o, s
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h and _ffi is not None and _ffi._lib is not None:
+            _ffi._lib.pmx_population_destroy(h)
+            self.handle = None
+
+
+def _as_model(model) -> DeviceModel:
+    if isinstance(model, DeviceModel):
+        return model
+    dm = getattr(model, "_handle", None)
+    if dm is None:
+        dm = DeviceModel(model)
+        model._handle = dm
+    return dm
+
+
+def predict_host(model, flat: FlatPopulation, theta: np.ndarray, device: int = 0, batch: bool = False,
+                 raise_on_pair_failure: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+    """Host-pointer ABI form (``pmx_predict`` / ``pmx_predict_batch``): numpy in, numpy out."""
+    L = _ffi.lib()
+    dm = _as_model(model)
+    pop = DevicePopulation(flat, device)
+    theta = np.ascontiguousarray(theta, dtype=np.float64)
+    if theta.ndim == 1:
+        theta = theta.reshape(1, -1)
+    if theta.shape[1] != dm.desc.nparams:
+        raise ValueError(f"theta has {theta.shape[1]} columns, model declares {dm.desc.nparams} parameters")
+    if batch:
+        if theta.shape[0] != pop.n_subjects:
+            raise ValueError("batch form needs one theta row per subject")
+        pred = np.full((pop.n_observations,), np.nan)
+        status = np.zeros((pop.n_subjects,), dtype=np.uint8)
+        rc = L.pmx_predict_batch(dm.handle, pop.handle, theta.ctypes.data, pred.ctypes.data, status.ctypes.data)
+    else:
+        P = theta.shape[0]
+        pred = np.full((pop.n_observations, P), np.nan)
+        status = np.zeros((pop.n_subjects, P), dtype=np.uint8)
+        rc = L.pmx_predict(dm.handle, pop.handle, theta.ctypes.data, P, pred.ctypes.data, P, status.ctypes.data)
+    _ffi.check(rc, allow_pair_failures=not raise_on_pair_failure)
+    return pred, status
+
+
+def predict(model, pop: DevicePopulation, theta, pred=None, status=None, batch: bool = False, want_status: bool = True):
+    """Device-pointer ABI form (``pmx_predict_device``): torch CUDA tensors, enqueued on torch's
+    current stream, not synchronised.  Returns ``(pred, status)`` tensors."""
+    import torch
+
+    L = _ffi.lib()
+    dm = _as_model(model)
+    dev = torch.device("cuda", pop.device)
+    if not (isinstance(theta, torch.Tensor) and theta.is_cuda):
+        theta = torch.as_tensor(np.ascontiguousarray(theta, dtype=np.float64), device=dev)
+    theta = theta.contiguous()
+    assert theta.dtype == torch.float64 and theta.dim() == 2 and theta.shape[1] == dm.desc.nparams
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    if batch:
+        assert theta.shape[0] == pop.n_subjects
+        if pred is None:
+            pred = torch.empty((pop.n_observations,), dtype=torch.float64, device=dev)
+        if status is None and want_status:
+            status = torch.zeros((pop.n_subjects,), dtype=torch.uint8, device=dev)
+        rc = L.pmx_predict_batch_device(dm.handle, pop.handle, theta.data_ptr(), pred.data_ptr(),
+                                        status.data_ptr() if status is not None else None, stream)
+    else:
+        P = int(theta.shape[0])
+        if pred is None:
+            pred = torch.empty((pop.n_observations, P), dtype=torch.float64, device=dev)
+        assert pred.is_contiguous() or pred.stride(1) == 1
+        ld = int(pred.stride(0)) if pred.dim() == 2 and pred.shape[0] > 1 else P
+        if status is None and want_status:
+            status = torch.zeros((pop.n_subjects, P), dtype=torch.uint8, device=dev)
+        rc = L.pmx_predict_device(dm.handle, pop.handle, theta.data_ptr(), P, pred.data_ptr(), ld,
+                                  status.data_ptr() if status is not None else None, stream)
+    _ffi.check(rc)
+    return pred, status
+
+
+def last_kernel_name() -> str:
+    return _ffi.lib().pmx_last_kernel_name().decode()
+
+
+def compile_ops(model, flat: FlatPopulation) -> dict:
+    """Host-side introspection (``pmx_debug_compile``): the op stream the device would walk, as numpy
+    arrays.  Needs no GPU."""
+    L = _ffi.lib()
+    md = model.desc() if not isinstance(model, _abi.pmx_model_desc) else model
+    pd = flat.desc()
+    v = _abi.pmx_op_stream_view()
+    _ffi.check(L.pmx_debug_compile(C.byref(pd), C.byref(md), C.byref(v)))
+    try:
+        n, S = int(v.n_ops), int(v.n_subjects)
+
+        def arr(ptr, count, dtype):
+            if not ptr or count == 0:
+                return np.zeros((0,), dtype=dtype)
+            return np.ctypeslib.as_array(ptr, shape=(count,)).astype(dtype, copy=True)
+
+        meta = arr(v.op_meta, n, np.uint32)
+        out = dict(
+            n_ops=n, n_subjects=S, n_cov=int(v.n_cov), n_rate=int(v.n_rate), max_input_used=int(v.max_input_used),
+            max_outeq=int(v.max_outeq), subj_op_off=arr(v.subj_op_off, S + 1, np.int64), kind=(meta & 0xFF).astype(np.int32),
+            io=((meta >> 8) & 0xFFFF).astype(np.int32), a=arr(v.op_a, n, np.float64), b=arr(v.op_b, n, np.float64),
+            n=arr(v.op_n, n, np.int32), rate=arr(v.op_rate, n * int(v.n_rate), np.float64).reshape(-1, max(int(v.n_rate), 1)),
+            cov=arr(v.op_cov, n * int(v.n_cov), np.float64).reshape(-1, max(int(v.n_cov), 1)),
+            subj_order=arr(v.subj_order, S, np.int32))
+    finally:
+        L.pmx_debug_free(C.byref(v))
+    return out
