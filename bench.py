@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""bench.py — subject-event-steps/s of the HIP prediction path on BASELINE.json's headline workload.
+
+A "step" of this benchmark = one pass of the hot path (every subject x every support point, one
+kernel launch) over one resident batch of synthetic input.  Workload at N=1 = C3, the configuration
+the north-star target is quoted on: two-compartment IV analytical, 100k subjects x 1000 support
+points, 8 events per subject (8e8 subject-event-steps per pass).  For N>1 (weak scaling) every rank
+holds its own 100k-subject shard of an N x 100k population and the full theta grid; there is no
+data-path collective (the reference's loop nest, likelihood/matrix.rs:79-98, has no exchange step).
+
+Contract: W untimed warm-up passes, then exactly K timed passes bracketed by barrier +
+torch.cuda.synchronize() on both sides; MAX over ranks; rank 0 prints ONE JSON line.
+Inputs (population, theta) are resident in HBM before the timed region starts.
+
+Extra objects on the line:
+  roofline      dominant kernel vs the HBM roofline: achieved = algorithmic bytes per launch
+                (8*S*O*P + 8*P*k + 26*S*E) / mean launch duration measured with HIP
+                events on the launch stream inside the timed region; peak = 8 TB/s (MI355X HBM3E).
+  cpu_baseline  the CPU oracle (a port of the reference algorithm, OpenMP over subjects like the
+                reference's rayon loop) on a bounded sample of the same workload, rank 0 at N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(S, O, P, k, E, cov_segments=0):
+    """each array touched once."""
+    return 8 * S * O * P + 8 * P * k + 26 * S * E + 24 * cov_segments
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--subjects", type=int, default=100_000, help="subjects per GPU (C3: 100000)")
+    ap.add_argument("--support", type=int, default=1000, help="support points (C3: 1000)")
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c4", "c5"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
+    ap.add_argument("--gather", action="store_true", help="N>1: also time the optional RCCL all-gather")
+    ap.add_argument("--no-status", action="store_true", help="do not write the per-pair status bytes")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from pharmsol_amd import runtime, synth
+    from pharmsol_amd.distributed import ShardedPopulation, all_gather_predictions
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: launch with torch.distributed.run "
+                  f"--nproc-per-node {args.gpus}", file=sys.stderr)
+        sys.exit(2)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+    backend = os.environ.get("PMX_BENCH_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    device_index = local_rank % n_dev  # (rehearsal on a 1-GPU box maps every rank to cuda:0)
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    red_dev = dev if (world > 1 and backend == "nccl") else torch.device("cpu")
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[device_index]) if backend == "nccl" else dist.barrier()
+
+    # ---------------------------------------------------------------- workload (synthetic, seeded)
+    S_local, P = args.subjects, args.support
+    batch = False
+    if args.workload in ("c3", "c2"):
+        if args.workload == "c2":
+            S_local, P = 10_000, 1
+        model = synth.model_two_cpt_iv()
+        theta = synth.theta_c3(P) if args.workload == "c3" else synth.theta_c2()
+        flat_global = synth.population_c23(S_local * world)
+        label = f"C{'3' if args.workload == 'c3' else '2'}: two_compartments analytical, {S_local} subjects/GPU x {P} support points, 8 events/subject"
+        dtype_tol = 1e-6
+    elif args.workload == "c4":
+        S_local = 50_000 if args.subjects == 100_000 else args.subjects
+        model, flat_global, theta_all = synth.config_c4(S_local * world)
+        batch, P = True, 1
+        label = f"C4: ode one_cmt_iv RK4 h<=0.02, {S_local} subjects/GPU, irregular schedules, one theta per subject"
+        dtype_tol = 1e-4
+    else:
+        S_local = 200_000 if args.subjects == 100_000 else args.subjects
+        P = 512 if args.support == 1000 else args.support
+        model = synth.model_three_cpt_abs_wt()
+        theta = synth.theta_c5(P)
+        flat_global = synth.population_c5(S_local * world)
+        label = f"C5: three_compartments_with_absorption + wt covariate, {S_local} subjects/GPU x {P} support points"
+        dtype_tol = 1e-6
+    sh = ShardedPopulation(flat_global, rank, world)
+    flat = sh.local
+    if batch:
+        s0, s1 = sh.bounds[rank]
+        theta = theta_all[s0:s1]
+    k = theta.shape[1]
+
+    pop = runtime.DevicePopulation(flat, device_index)
+    d_theta = torch.as_tensor(np.ascontiguousarray(theta), device=dev)
+    n_obs = pop.n_observations
+    pred = torch.empty((n_obs,) if batch else (n_obs, P), dtype=torch.float64, device=dev)
+    status = None if args.no_status else torch.zeros((pop.n_subjects,) if batch else (pop.n_subjects, P),
+                                                     dtype=torch.uint8, device=dev)
+    steps_per_pass_local = pop.n_events * (1 if batch else P)
+
+    def one_pass():
+        runtime.predict(model, pop, d_theta, pred=pred, status=status, batch=batch, want_status=not args.no_status)
+
+    for _ in range(args.warmup):
+        one_pass()
+    torch.cuda.synchronize()
+
+    # ---------------------------------------------------------------- timed region
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev0[i].record()  # torch's current stream == the stream the kernel is enqueued on
+        one_pass()
+        ev1[i].record()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = [a.elapsed_time(b) for a, b in zip(ev0, ev1)]
+    kernel_name = runtime.last_kernel_name()
+
+    t_el = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    t_steps = torch.tensor([steps_per_pass_local], dtype=torch.int64, device=red_dev)
+    t_kms = torch.tensor([float(np.mean(kernel_ms))], dtype=torch.float64, device=red_dev)
+    if world > 1:
+        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t_steps, op=dist.ReduceOp.SUM)
+        dist.all_reduce(t_kms, op=dist.ReduceOp.MAX)
+    elapsed_max = float(t_el.item())
+    steps_per_pass = int(t_steps.item())
+    kernel_ms_mean = float(t_kms.item())
+
+    # ---------------------------------------------------------------- optional all-gather (outside `value`)
+    gather = None
+    if world > 1 and args.gather and not batch:
+        try:
+            torch.cuda.synchronize()
+            barrier()
+            g0 = time.perf_counter()
+            full = all_gather_predictions(pred, sh)
+            torch.cuda.synchronize()
+            barrier()
+            gms = (time.perf_counter() - g0) * 1e3
+            gather = {"ms": gms, "GB_per_rank_out": full.numel() * 8 / 1e9, "backend": backend}
+            del full
+        except Exception as e:  # never let the optional leg kill the measured line
+            gather = {"error": repr(e)[:200]}
+
+    # ---------------------------------------------------------------- parity sample + CPU baseline (rank 0)
+    cpu_baseline = None
+    max_rel_err = None
+    if rank == 0:
+        import oracle  # test infrastructure: the checker / the timed CPU baseline, never the product path
+
+        cores = oracle.max_threads()
+        run = (lambda f, th: oracle.predict_batch(model, f, th)) if batch else (lambda f, th: oracle.predict(model, f, th))
+        per_subject = max(flat.n_events / max(flat.n_subjects, 1) * (1 if batch else P), 1.0)
+
+        def timed(n):
+            f = flat.subject_slice(0, n)
+            th = theta[:n] if batch else theta
+            c0 = time.perf_counter()
+            w, _ = run(f, th)
+            return w, time.perf_counter() - c0, f.n_events * (1 if batch else P)
+
+        # parity sample: the first subjects of this rank's shard, GPU vs oracle
+        n_probe = min(flat.n_subjects, max(64, 4 * cores))
+        want, probe_s, probe_steps = timed(n_probe)
+        got = pred[: want.shape[0]].cpu().numpy()
+        scale = max(float(np.nanmax(np.abs(want))), 1e-300)
+        max_rel_err = float(np.max(np.abs(got - want) / np.maximum(np.abs(want), 1e-12 * scale)))
+        if world == 1 and not args.no_cpu_baseline:
+            # grow the sample until one run takes >= 1 s, then size the timed run for ~cpu_seconds of wall time
+            n, secs, steps = n_probe, probe_s, probe_steps
+            while secs < 1.0 and n < flat.n_subjects:
+                n = min(flat.n_subjects, n * 4)
+                _, secs, steps = timed(n)
+            rate = steps / secs
+            n_sample = int(min(flat.n_subjects, max(n, args.cpu_seconds * rate / per_subject)))
+            if n_sample > n:
+                _, secs, steps = timed(n_sample)
+            else:
+                n_sample = n
+            cpu_baseline = {
+                "value": steps / secs, "unit": "subject-event-steps/s", "cores": cores, "kind": "port",
+                "sample": f"first {n_sample} subjects of the same population x {'own theta' if batch else str(P) + ' support points'} "
+                          f"({steps} steps, {secs:.1f} s wall on {cores} threads); oracle/pmx_oracle.c, OpenMP over subjects "
+                          f"(rayon-shaped loop nest of likelihood/matrix.rs:79-98), f64",
+            }
+
+    if rank == 0:
+        E_tot = flat.n_events
+        O_tot = n_obs
+        # per-launch algorithmic bytes of THIS rank's kernel (S*O = n_obs rows, S*E = n_events)
+        b_alg = 8 * O_tot * (1 if batch else P) + 8 * theta.shape[0] * k + 26 * E_tot
+        achieved = b_alg / (kernel_ms_mean * 1e-3) / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tp) and args.workload == "c3" and S_local == 100_000 and P == 1000:
+            try:
+                traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        value = steps_per_pass * args.steps / elapsed_max
+        line = {
+            "metric": "subject_event_steps_per_sec", "value": value, "unit": "subject-event-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": label, "subjects_per_gpu": S_local, "support_points": P,
+                       "steps_per_pass": steps_per_pass, "kernel": kernel_name,
+                       "status_bytes_written": not args.no_status, "sharding": f"subjects x{world}, no collective"},
+            "max_rel_err_vs_cpu_ref": max_rel_err, "rel_err_tolerance": dtype_tol,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": kernel_name, "kernel_ms": kernel_ms_mean, "algorithmic_bytes": b_alg},
+            "cpu_baseline": cpu_baseline,
+        }
+        if gather is not None:
+            line["gather"] = gather
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,312 @@
+"""GPU parity tests (run with `-m gpu` on the MI355X box): the HIP path, called through the C ABI,
+against the CPU oracle on the same seeded inputs, against the committed golden fixtures, and — at
+BASELINE.json's full sizes — through size-independent properties.
+
+Tolerances (BASELINE.json north_star): 1e-6 relative for the analytical back-end, 1e-4 for the ODE
+back-end.  Relative error is |gpu - cpu| / max(|cpu|, floor) with floor = 1e-12 x the column scale,
+so pre-dose zeros compare absolutely (SURVEY.md §8d "Error metric").
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from pharmsol_amd import (Analytical, Data, Parameters, Pow, Ratio, Scaled, Subject, _abi, analytical, bolus,
+                          infusion, runtime, synth)
+from tests import models
+from tests.test_oracle_independent_math import CENTRAL, GOLD, build_subject
+
+pytestmark = pytest.mark.gpu
+
+TOL_ANALYTICAL = 1e-6
+TOL_ODE = 1e-4
+
+
+def rel_err(got, want):
+    scale = max(float(np.nanmax(np.abs(want))) if want.size else 0.0, 1e-300)
+    return np.abs(got - want) / np.maximum(np.abs(want), 1e-12 * scale)
+
+
+def gpu_predict(model, flat, theta, batch=False):
+    """Through the device-pointer C ABI (pmx_predict_device / pmx_predict_batch_device)."""
+    import torch
+
+    pop = runtime.DevicePopulation(flat, 0)
+    pred, status = runtime.predict(model, pop, np.ascontiguousarray(theta, dtype=np.float64), batch=batch)
+    torch.cuda.synchronize()
+    return pred.cpu().numpy(), status.cpu().numpy()
+
+
+def assert_parity(model, flat, theta, tol, batch=False, expect_kernel=None):
+    got, st = gpu_predict(model, flat, theta, batch=batch)
+    if expect_kernel:
+        assert runtime.last_kernel_name().startswith(expect_kernel), runtime.last_kernel_name()
+    want, wst = (oracle.predict_batch if batch else oracle.predict)(model, flat, theta)
+    assert got.shape == want.shape
+    np.testing.assert_array_equal(st, wst)
+    ok = np.isfinite(want)
+    np.testing.assert_array_equal(np.isfinite(got), ok)
+    if ok.any():
+        err = rel_err(got[ok], want[ok]).max()
+        assert err <= tol, f"max rel err {err:.3e} > {tol:g}"
+    return got, want
+
+
+# --------------------------------------------------------------------------- C1..C5 (reduced sizes vs oracle)
+def test_c1_analytical_readme_through_the_equation_api():
+    # examples/analytical_readme.rs, read like the reference example
+    m = models.readme_analytical()
+    params = Parameters.with_model(m, [("ka", 1.2), ("ke0", 0.08), ("v", 194.0)])
+    predictions = m.estimate_predictions(models.readme_subject(), params)
+    assert predictions.flat_times() == [0.5, 1.0, 2.0, 4.0]
+    want = [1.1363216631314599, 1.7130756583758835, 2.0906323551896495, 1.956103669112038]
+    np.testing.assert_allclose(predictions.flat_predictions(), want, rtol=TOL_ANALYTICAL)
+
+
+def test_c2_two_compartment_10k_subjects_one_support_point():
+    m, flat, theta = synth.config_c2(10_000)
+    assert_parity(m, flat, theta, TOL_ANALYTICAL, expect_kernel="pmx_analytical_pair")
+
+
+def test_c3_grid_slice():
+    m, flat, theta = synth.config_c3(500, 1000)
+    assert_parity(m, flat, theta, TOL_ANALYTICAL, expect_kernel="pmx_analytical_grid")
+
+
+def test_c4_ode_rk4_divergent_schedules_batch():
+    m, flat, theta = synth.config_c4(5_000)
+    got, want = assert_parity(m, flat, theta, TOL_ODE, batch=True, expect_kernel="pmx_ode_rk4_pair")
+    # and against the EXACT solution (closed form one_compartment) at the ODE tolerance
+    ma = Analytical.new("one_compartment", {0: Ratio(0, 1)}, nparams=2).with_nstates(1).with_ndrugs(1).with_nout(1)
+    exact, _ = oracle.predict_batch(ma, flat, theta)
+    assert rel_err(got, exact).max() <= TOL_ODE
+
+
+@pytest.mark.parametrize("cov_time", ["segment_dt", "segment_end_abs"])
+def test_c5_three_compartment_absorption_time_varying_wt(cov_time):
+    m, flat, theta = synth.config_c5(300, 512, cov_time)
+    assert_parity(m, flat, theta, TOL_ANALYTICAL, expect_kernel="pmx_analytical_grid<dyn>")
+
+
+# --------------------------------------------------------------------------- every kernel, both lane mappings
+@pytest.mark.parametrize("structure,central,theta,subject_fn,diffeq", models.KERNEL_CASES)
+@pytest.mark.parametrize("n_support", [1, 70])
+def test_every_analytical_kernel_on_reference_fixtures(structure, central, theta, subject_fn, diffeq, n_support):
+    m = models.handwritten_analytical(structure, central, len(theta))
+    rng = np.random.default_rng(11)
+    th = np.array(theta)[None, :] * np.exp(rng.uniform(-0.3, 0.3, size=(n_support, len(theta))))
+    if "absorption" in structure:  # keep ka away from the elimination eigenvalues (singular closed form)
+        th[:, 1 if structure.startswith("two_compartments_with") else 0] = rng.uniform(9.0, 15.0, size=n_support)
+    th[0] = theta
+    assert_parity(m, m.flatten(subject_fn()), th, TOL_ANALYTICAL)
+
+
+@pytest.mark.parametrize("structure,central,theta,subject_fn,diffeq", [c for c in models.KERNEL_CASES if c[4]])
+@pytest.mark.parametrize("n_support", [1, 70])
+def test_every_ode_model_matches_rk4_oracle_and_closed_form(structure, central, theta, subject_fn, diffeq, n_support):
+    mo = models.handwritten_ode(diffeq, central, len(theta), h_max=0.01)
+    ma = models.handwritten_analytical(structure, central, len(theta))
+    rng = np.random.default_rng(12)
+    th = np.array(theta)[None, :] * np.exp(rng.uniform(-0.2, 0.2, size=(n_support, len(theta))))
+    if "absorption" in structure:
+        th[:, 1 if structure.startswith("two_compartments_with") else 0] *= 2.5
+    subj = subject_fn()
+    got, _ = assert_parity(mo, mo.flatten(subj), th, TOL_ODE)
+    exact, _ = oracle.predict(ma, ma.flatten(subj), th)
+    scale = np.abs(exact).max()
+    assert np.abs(got - exact).max() / scale <= TOL_ODE
+
+
+def test_nonlinear_ode_michaelis_menten():
+    from pharmsol_amd import ODE
+
+    m = ODE.new("one_cmt_mm", {0: Ratio(0, 2)}, nparams=3, h_max=0.01).with_nstates(1).with_ndrugs(1).with_nout(1)
+    rng = np.random.default_rng(5)
+    subjects = [models.random_subject(rng) for _ in range(40)]
+    flat = m.flatten(Data(subjects))
+    th = np.stack([rng.uniform(5, 50, 33), rng.uniform(0.5, 5, 33), rng.uniform(5, 50, 33)], axis=1)
+    assert_parity(m, flat, th, TOL_ODE, expect_kernel="pmx_ode_rk4_grid")
+
+
+# --------------------------------------------------------------------------- golden fixtures
+@pytest.mark.parametrize("n_support", [1, 64])
+def test_golden_independent_math_fixtures(n_support):
+    """tests/golden/independent_math.json (mpmath, 40 digits) straight against the GPU."""
+    worst = 0.0
+    for case in GOLD:
+        st = case["structure"]
+        m = models.handwritten_analytical(st, CENTRAL[st], len(case["theta"]))
+        flat = m.flatten(build_subject(case["events"]))
+        th = np.tile(np.array(case["theta"]), (n_support, 1))
+        got, status = gpu_predict(m, flat, th)
+        want = np.array(case["expected"])
+        assert (status == 0).all()
+        scale = max(np.abs(want).max(), 1e-300)
+        worst = max(worst, np.abs(got - want[:, None]).max() / scale)
+    assert worst <= TOL_ANALYTICAL, worst
+
+
+# --------------------------------------------------------------------------- edge cases
+def test_ragged_population_with_empty_and_doseless_subjects():
+    rng = np.random.default_rng(3)
+    subjects = [models.random_subject(rng, n_bolus_inputs=2, multi_occasion=True) for _ in range(300)]
+    subjects.insert(17, Subject.builder("empty").build())
+    subjects.insert(40, Subject.builder("only_dose").bolus(1.0, 5.0, 0).build())
+    subjects.append(Subject.builder("only_obs").missing_observation(0.0, 0).missing_observation(3.0, 0).build())
+    subjects.append(Subject.builder("empty_last").build())
+    m = models.handwritten_analytical("two_compartments", 0, 4)
+    flat = m.flatten(Data(subjects))
+    th = synth.theta_c3(97)
+    assert_parity(m, flat, th, TOL_ANALYTICAL, expect_kernel="pmx_analytical_grid")
+    assert_parity(m, flat, th[:3], TOL_ANALYTICAL, expect_kernel="pmx_analytical_pair")
+    th_b = synth.theta_c3(len(subjects))
+    assert_parity(m, flat, th_b, TOL_ANALYTICAL, batch=True, expect_kernel="pmx_analytical_pair")
+
+
+def test_support_point_counts_around_the_tile_edges():
+    m, flat, _ = synth.config_c3(37, 8)
+    for P in (31, 32, 33, 255, 256, 257, 1000):
+        assert_parity(m, flat, synth.theta_c3(P), TOL_ANALYTICAL)
+
+
+def test_padded_leading_dimension_is_respected():
+    import torch
+
+    m, flat, theta = synth.config_c3(50, 100)
+    pop = runtime.DevicePopulation(flat, 0)
+    buf = torch.full((pop.n_observations, 128), -7.0, dtype=torch.float64, device="cuda")
+    pred, _ = runtime.predict(m, pop, theta, pred=buf[:, :100])
+    torch.cuda.synchronize()
+    want, _ = oracle.predict(m, flat, theta)
+    host = buf.cpu().numpy()
+    assert rel_err(host[:, :100], want).max() <= TOL_ANALYTICAL
+    assert (host[:, 100:] == -7.0).all()  # padding untouched
+
+
+def test_complex_roots_are_flagged_per_pair():
+    m = models.handwritten_analytical("two_compartments", 0, 4).with_ndrugs(1)
+    s = Subject.builder("cx").bolus(0.0, 10.0, 0).missing_observation(0.0, 0).missing_observation(1.0, 0).build()
+    th = np.tile(np.array([[0.1, 0.3, 0.2, 50.0]]), (64, 1))
+    th[5] = [1.0, -1.9, 1.0, 1.0]
+    got, st = gpu_predict(m, m.flatten(Data([s, s])), th)
+    want, wst = oracle.predict(m, m.flatten(Data([s, s])), th)
+    np.testing.assert_array_equal(st, wst)
+    assert st[0, 5] == _abi.PMX_PAIR_COMPLEX_ROOTS and st[:, :5].sum() == 0
+    assert np.isnan(got[1, 5]) and np.isfinite(np.delete(got, 5, axis=1)).all()
+    # host-pointer form reports the failed pair like log_likelihood_matrix aborting (matrix.rs:83,104)
+    with pytest.raises(_abi.PmxError) as e:
+        runtime.predict_host(m, m.flatten(s), th, raise_on_pair_failure=True)
+    assert e.value.status == _abi.PMX_ERR_PAIR_FAILED
+
+
+def test_input_and_outeq_out_of_range_errors():
+    m = models.handwritten_analytical("one_compartment", 0, 2).with_ndrugs(1)
+    s = Subject.builder("oor").bolus(0.0, 1.0, 1).missing_observation(1.0, 0).build()
+    with pytest.raises(_abi.PmxError) as e:
+        runtime.predict_host(m, m.flatten(s), np.array([[0.1, 1.0]]))
+    assert e.value.status == _abi.PMX_ERR_INPUT_OUT_OF_RANGE
+    s = Subject.builder("oor2").bolus(0.0, 1.0, 0).missing_observation(1.0, 3).build()
+    with pytest.raises(_abi.PmxError) as e:
+        runtime.predict_host(m, m.flatten(s), np.array([[0.1, 1.0]]))
+    assert e.value.status == _abi.PMX_ERR_OUTEQ_OUT_OF_RANGE
+
+
+def test_init_and_multiple_occasions():
+    m = Analytical.new("one_compartment", {0: Ratio(0, 1)}, nparams=3, init={0: 2}).with_nstates(1).with_ndrugs(
+        1).with_nout(1)
+    s = (Subject.builder("occ").missing_observation(0.0, 0).missing_observation(1.0, 0).reset()
+         .missing_observation(0.0, 0).bolus(0.0, 10.0, 0).missing_observation(1.0, 0).build())
+    th = np.array([[0.5, 2.0, 40.0]] * 40)
+    got, want = assert_parity(m, m.flatten(s), th, TOL_ANALYTICAL)
+    np.testing.assert_allclose(got[:, 0], [20.0, 40.0 * math.exp(-0.5) / 2.0, 0.0, 10.0 * math.exp(-0.5) / 2.0],
+                               rtol=1e-12)
+
+
+def test_pmetrics_one_based_wrappers():
+    # pm_* kernels: state/rateiv slot 0 is a dead pad (analytical/mod.rs:62-90)
+    m = Analytical.new("pm_two_compartments", {0: Ratio(1, 3)}, nparams=4).with_nstates(3).with_ndrugs(2).with_nout(1)
+    s = (Subject.builder("pm").bolus(0.0, 100.0, 1).infusion(2.0, 50.0, 1, 1.0).missing_observation(1.0, 0)
+         .missing_observation(2.5, 0).missing_observation(6.0, 0).build())
+    th = synth.theta_c3(40)
+    got, _ = assert_parity(m, m.flatten(s), th, TOL_ANALYTICAL)
+    m0 = Analytical.new("two_compartments", {0: Ratio(0, 3)}, nparams=4).with_nstates(2).with_ndrugs(1).with_nout(1)
+    s0 = (Subject.builder("native").bolus(0.0, 100.0, 0).infusion(2.0, 50.0, 0, 1.0).missing_observation(1.0, 0)
+          .missing_observation(2.5, 0).missing_observation(6.0, 0).build())
+    want, _ = oracle.predict(m0, m0.flatten(s0), th)
+    assert rel_err(got, want).max() <= TOL_ANALYTICAL
+
+
+def test_macro_projection_with_reordered_params():
+    # params declared in a different order than the structure needs -> projection (expand/analytical.rs:214-292)
+    m = analytical(name="reordered", params=["v", "kpc", "ke", "kcp"], structure="two_compartments",
+                   states=["central", "peripheral"], outputs=["cp"], routes=[infusion("iv", "central")],
+                   out={"cp": Ratio("central", "v")})
+    assert m.desc().n_bind == 3
+    _, flat, th = synth.config_c3(20, 50)
+    th2 = th[:, [3, 2, 0, 1]]
+    got, _ = assert_parity(m, flat, th2, TOL_ANALYTICAL)
+    want, _ = oracle.predict(synth.model_two_cpt_iv(), flat, th)
+    assert rel_err(got, want).max() <= TOL_ANALYTICAL
+
+
+def test_host_pointer_form_matches_device_pointer_form():
+    m, flat, theta = synth.config_c3(64, 40)
+    a, sa = runtime.predict_host(m, flat, theta)
+    b, sb = gpu_predict(m, flat, theta)
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(sa, sb)
+
+
+def test_results_are_deterministic_across_launches():
+    m, flat, theta = synth.config_c3(200, 300)
+    a, _ = gpu_predict(m, flat, theta)
+    b, _ = gpu_predict(m, flat, theta)
+    np.testing.assert_array_equal(a, b)
+
+
+# --------------------------------------------------------------------------- full BASELINE sizes: properties
+def test_c3_full_size_properties():
+    """100k subjects x 1000 support points (5.6 GB of predictions): too big for the oracle, so check
+    (1) a random sample of subjects against the oracle, (2) linearity in the dose (the system is linear:
+    pred(s) / amount(s) is the same for every subject with this shared schedule), (3) subjects with equal
+    (s mod 1000) have bit-identical rows."""
+    import torch
+
+    m, flat, theta = synth.config_c3(100_000, 1000)
+    pop = runtime.DevicePopulation(flat, 0)
+    pred, status = runtime.predict(m, pop, theta)
+    torch.cuda.synchronize()
+    assert int(status.max().item()) == 0
+    assert bool(torch.isfinite(pred).all().item())
+    P = 1000
+    pr = pred.view(100_000, 7, P)
+    # (3) identical dosing => identical predictions
+    assert torch.equal(pr[:1000], pr[1000:2000]) and torch.equal(pr[:1000], pr[99_000:100_000])
+    # (2) linearity: pred / amount constant over subjects
+    amt = torch.as_tensor(500.0 * (1.0 + 0.001 * (np.arange(100_000) % 1000)), device="cuda")
+    unit = pr / amt[:, None, None]
+    dev = (unit - unit[0:1]).abs().amax() / unit[0].abs().amax()
+    assert float(dev) < 1e-13
+    # (1) sample vs oracle
+    idx = np.sort(np.random.default_rng(0).choice(100_000, size=64, replace=False))
+    sub = np.concatenate([np.arange(s * 8, s * 8 + 8) for s in idx])
+    from pharmsol_amd.flatten import FlatPopulation
+
+    small = FlatPopulation(subj_occ_off=np.arange(65), occ_ev_off=np.arange(65) * 8, occ_index=np.zeros(64, np.int32),
+                           ev_time=flat.ev_time[sub], ev_value=flat.ev_value[sub], ev_duration=flat.ev_duration[sub],
+                           ev_kind=flat.ev_kind[sub], ev_io=flat.ev_io[sub])
+    want, _ = oracle.predict(m, small, theta)
+    got = pr[torch.as_tensor(idx, device="cuda")].reshape(64 * 7, P).cpu().numpy()
+    assert rel_err(got, want).max() <= TOL_ANALYTICAL
+
+
+def test_c4_full_size_against_closed_form():
+    m, flat, theta = synth.config_c4(50_000)
+    got, st = gpu_predict(m, flat, theta, batch=True)
+    assert (st == 0).all()
+    ma = Analytical.new("one_compartment", {0: Ratio(0, 1)}, nparams=2).with_nstates(1).with_ndrugs(1).with_nout(1)
+    exact, _ = oracle.predict_batch(ma, flat, theta)
+    assert rel_err(got, exact).max() <= TOL_ODE
