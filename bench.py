@@ -51,7 +51,11 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
     ap.add_argument("--gather", action="store_true", help="N>1: also time the optional RCCL all-gather")
     ap.add_argument("--no-status", action="store_true", help="do not write the per-pair status bytes")
+    ap.add_argument("--no-class", action="store_true",
+                    help="A/B: disable the classed kernel (shared-design propagator reuse); every subject walks the generic kernel")
     args = ap.parse_args()
+    if args.no_class:
+        os.environ["PMX_DISABLE_CLASSING"] = "1"
 
     import numpy as np
     import torch

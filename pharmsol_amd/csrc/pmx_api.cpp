@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -55,6 +56,8 @@ struct DeviceGuard {
 struct DeviceStream {
   pmx::CompileKey key;
   pmx::DevOps dev{};
+  pmx::DevClassPlan cls{};
+  int64_t n_classed_subjects = 0;
   std::vector<void*> allocs;
   int32_t max_input_used = -1;
   int64_t n_ops = 0, n_prop = 0;
@@ -247,6 +250,13 @@ pmx::CompileKey key_for(const pmx_model* m) {
     k.rk4_h_max = 0.0;
     k.n_rate = 1;
     k.rate_input = m->d.pmetrics_indexing ? 1 : 0;
+    // classed fast path: theta-only coefficients, no covariates, plain indexing
+    const char* off = std::getenv("PMX_DISABLE_CLASSING");
+    const bool disabled = off && off[0] && off[0] != '0';
+    if (!disabled && !m->dyn && !m->d.pmetrics_indexing && m->d.n_covariates == 0) {
+      const int st = pmx::kernel_structure(m->d.kernel);
+      k.class_g = (st == pmx::S_ONE || st == pmx::S_ONE_ABS || st == pmx::S_TWO) ? 8 : 4;  // == ClassBatch<KID>::G
+    }
   } else {
     k.cov_time_mode = PMX_COV_TIME_SEGMENT_END_ABS;
     k.rk4_h_max = m->d.rk4_h_max;
@@ -283,6 +293,26 @@ int32_t get_stream(pmx_population* pop, const pmx::CompileKey& key, DeviceStream
   if ((rc = upload(os.op_rate, &ds->dev.op_rate, &ds->allocs)) != PMX_OK) return rc;
   if ((rc = upload(os.op_cov, &ds->dev.op_cov, &ds->allocs)) != PMX_OK) return rc;
   ds->dev.n_rate = key.n_rate;
+  if (key.class_g > 0) {
+    pmx::ClassPlan cp;
+    pmx::build_class_plan(pop->hp, os, key.class_g, key.class_g / 2, &cp);
+    if (cp.n_chunks > 0) {
+      if ((rc = upload(cp.prog_meta, &ds->cls.prog_meta, &ds->allocs)) != PMX_OK) return rc;
+      if ((rc = upload(cp.prog_dt, &ds->cls.prog_dt, &ds->allocs)) != PMX_OK) return rc;
+      if ((rc = upload(cp.cls_prog_off, &ds->cls.cls_prog_off, &ds->allocs)) != PMX_OK) return rc;
+      if ((rc = upload(cp.chunk_cls, &ds->cls.chunk_cls, &ds->allocs)) != PMX_OK) return rc;
+      if ((rc = upload(cp.chunk_n, &ds->cls.chunk_n, &ds->allocs)) != PMX_OK) return rc;
+      if ((rc = upload(cp.chunk_val_off, &ds->cls.chunk_val_off, &ds->allocs)) != PMX_OK) return rc;
+      if ((rc = upload(cp.chunk_subj, &ds->cls.chunk_subj, &ds->allocs)) != PMX_OK) return rc;
+      if ((rc = upload(cp.chunk_row, &ds->cls.chunk_row, &ds->allocs)) != PMX_OK) return rc;
+      if ((rc = upload(cp.val, &ds->cls.val, &ds->allocs)) != PMX_OK) return rc;
+      if ((rc = upload(cp.generic_subjects, &ds->cls.generic_subjects, &ds->allocs)) != PMX_OK) return rc;
+      ds->cls.n_chunks = cp.n_chunks;
+      ds->cls.n_generic = static_cast<int64_t>(cp.generic_subjects.size());
+      ds->cls.G = cp.G;
+      ds->n_classed_subjects = cp.n_classed_subjects;
+    }
+  }
   *out = ds.get();
   pop->streams.push_back(std::move(ds));
   return PMX_OK;
@@ -332,6 +362,8 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
   a.batch = batch;
   a.dyn = model->dyn ? 1 : 0;
   a.stream = stream;
+  a.cls = ds->cls;
+  a.use_classes = ds->cls.n_chunks > 0 ? 1 : 0;
   if (!batch && P >= 32) {
     a.mode = pmx::MODE_GRID;
     a.n_ptiles = static_cast<int32_t>((P + 255) / 256);

@@ -349,3 +349,108 @@ int32_t compile_ops(const HostPopulation& hp, const CompileKey& key, OpStream* o
 }
 
 }  // namespace pmx
+
+// ------------------------------------------------------------------------------------
+// class plan
+// ------------------------------------------------------------------------------------
+#include <unordered_map>
+
+namespace pmx {
+
+namespace {
+inline uint64_t mix64(uint64_t h, uint64_t v) {
+  h ^= v + 0x9E3779B97F4A7C15ULL + (h << 6) + (h >> 2);
+  h *= 0xBF58476D1CE4E5B9ULL;
+  return h ^ (h >> 31);
+}
+}  // namespace
+
+void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, int32_t min_class_size, ClassPlan* cp) {
+  *cp = ClassPlan{};
+  cp->G = G;
+  const int64_t S = hp.n_subjects;
+  auto sig_key = [&](int64_t o) -> uint64_t {  // what must match between class members, per op
+    const uint32_t kind = os.op_meta[o] & 0xffu;
+    uint64_t bits = 0;
+    if (kind == OP_PROP) std::memcpy(&bits, &os.op_a[o], 8);  // dt; BOLUS amount / PROP rate / OBS time are free
+    return (static_cast<uint64_t>(os.op_meta[o]) << 1) ^ (bits * 0x9E3779B97F4A7C15ULL) ^ bits;
+  };
+  auto same_program = [&](int64_t a, int64_t b) {
+    const int64_t a0 = os.subj_op_off[a], a1 = os.subj_op_off[a + 1];
+    const int64_t b0 = os.subj_op_off[b], b1 = os.subj_op_off[b + 1];
+    if (a1 - a0 != b1 - b0) return false;
+    for (int64_t i = 0; i < a1 - a0; ++i) {
+      if (os.op_meta[a0 + i] != os.op_meta[b0 + i]) return false;
+      if ((os.op_meta[a0 + i] & 0xffu) == OP_PROP && std::memcmp(&os.op_a[a0 + i], &os.op_a[b0 + i], 8) != 0) return false;
+    }
+    return true;
+  };
+  // class id per subject (representative = first subject seen with that program)
+  std::unordered_map<uint64_t, std::vector<int32_t>> buckets;  // hash -> class ids
+  std::vector<int32_t> cls_rep;                                 // class -> representative subject
+  std::vector<std::vector<int32_t>> members;
+  for (int64_t s = 0; s < S; ++s) {
+    const int64_t o0 = os.subj_op_off[s], o1 = os.subj_op_off[s + 1];
+    if (o1 == o0) continue;  // nothing to do for an empty subject
+    uint64_t h = static_cast<uint64_t>(o1 - o0);
+    for (int64_t o = o0; o < o1; ++o) h = mix64(h, sig_key(o));
+    auto& ids = buckets[h];
+    int32_t cls = -1;
+    for (int32_t c : ids)
+      if (same_program(cls_rep[c], s)) {
+        cls = c;
+        break;
+      }
+    if (cls < 0) {
+      cls = static_cast<int32_t>(cls_rep.size());
+      cls_rep.push_back(static_cast<int32_t>(s));
+      members.emplace_back();
+      ids.push_back(cls);
+    }
+    members[cls].push_back(static_cast<int32_t>(s));
+  }
+  cp->cls_prog_off.push_back(0);
+  int32_t out_cls = 0;
+  for (size_t c = 0; c < members.size(); ++c) {
+    const auto& mem = members[c];
+    if (static_cast<int32_t>(mem.size()) < min_class_size) {
+      cp->generic_subjects.insert(cp->generic_subjects.end(), mem.begin(), mem.end());
+      continue;
+    }
+    const int64_t r0 = os.subj_op_off[cls_rep[c]], r1 = os.subj_op_off[cls_rep[c] + 1];
+    const int64_t L = r1 - r0;
+    for (int64_t o = r0; o < r1; ++o) {
+      cp->prog_meta.push_back(os.op_meta[o]);
+      cp->prog_dt.push_back((os.op_meta[o] & 0xffu) == OP_PROP ? os.op_a[o] : 0.0);
+    }
+    cp->cls_prog_off.push_back(static_cast<int64_t>(cp->prog_meta.size()));
+    for (size_t m0 = 0; m0 < mem.size(); m0 += G) {
+      const int32_t n = static_cast<int32_t>(std::min<size_t>(G, mem.size() - m0));
+      cp->chunk_cls.push_back(out_cls);
+      cp->chunk_n.push_back(n);
+      cp->chunk_val_off.push_back(static_cast<int64_t>(cp->val.size()));
+      for (int32_t j = 0; j < G; ++j) {
+        cp->chunk_subj.push_back(j < n ? mem[m0 + j] : -1);
+        cp->chunk_row.push_back(j < n ? hp.subj_obs_off[mem[m0 + j]] : 0);
+      }
+      const size_t base = cp->val.size();
+      cp->val.resize(base + static_cast<size_t>(L) * G, 0.0);
+      for (int32_t j = 0; j < n; ++j) {
+        const int64_t s0 = os.subj_op_off[mem[m0 + j]];
+        for (int64_t i = 0; i < L; ++i) {
+          const uint32_t kind = os.op_meta[s0 + i] & 0xffu;
+          double v = 0.0;
+          if (kind == OP_BOLUS) v = os.op_a[s0 + i];
+          if (kind == OP_PROP) v = os.op_b[s0 + i];
+          cp->val[base + static_cast<size_t>(i) * G + j] = v;
+        }
+      }
+      cp->n_classed_subjects += n;
+    }
+    ++out_cls;
+  }
+  cp->n_chunks = static_cast<int64_t>(cp->chunk_cls.size());
+  std::sort(cp->generic_subjects.begin(), cp->generic_subjects.end());
+}
+
+}  // namespace pmx

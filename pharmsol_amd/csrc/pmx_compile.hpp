@@ -61,9 +61,10 @@ struct CompileKey {
   int32_t n_rate = 1;      // rate columns carried per PROP op (1 for analytical: closed forms read rateiv[0])
   int32_t rate_input = 0;  // analytical: the input whose rate the closed form reads (1 under pm_* indexing,
                            // where rateiv slot 0 is a dead pad: analytical/mod.rs:86-88)
+  int32_t class_g = 0;     // analytical GRID: members per chunk of the classed kernel (0 = no class plan)
   bool operator==(const CompileKey& o) const {
     return eq_kind == o.eq_kind && cov_time_mode == o.cov_time_mode && rk4_h_max == o.rk4_h_max &&
-           n_rate == o.n_rate && rate_input == o.rate_input;
+           n_rate == o.n_rate && rate_input == o.rate_input && class_g == o.class_g;
   }
 };
 
@@ -85,6 +86,32 @@ struct OpStream {
   // analytical/mod.rs:349-354, closure.rs:131-134).
   int32_t max_input_used = -1;
 };
+
+// "Classes" = subjects whose op streams are identical except for dose amounts / infusion rates
+// (same op kinds, inputs, outeqs and the same PROP lengths dt): a shared dosing/sampling design,
+// the normal case for trial protocols and simulation studies (C2/C3).  For such subjects the
+// propagator exp(-lambda*dt) of a support point is the same value for every member, so the classed
+// kernel computes it once per (lane, program step) and applies it to a register-resident batch of
+// G members.  Identical arithmetic per (subject, support point); only the redundant exp() calls go.
+struct ClassPlan {
+  int32_t G = 0;                       // members per chunk (register batch of the classed kernel)
+  int64_t n_chunks = 0;
+  int64_t n_classed_subjects = 0;
+  std::vector<uint32_t> prog_meta;     // concatenated class programs: kind | io<<8
+  std::vector<double> prog_dt;         // PROP: dt
+  std::vector<int64_t> cls_prog_off;   // [n_classes+1]
+  std::vector<int32_t> chunk_cls;      // [n_chunks]
+  std::vector<int32_t> chunk_n;        // [n_chunks] live members (<= G)
+  std::vector<int64_t> chunk_val_off;  // [n_chunks] offset of the chunk's value block in `val`
+  std::vector<int32_t> chunk_subj;     // [n_chunks*G] subject ids, -1 = padding
+  std::vector<int64_t> chunk_row;      // [n_chunks*G] first prediction row of each member
+  std::vector<double> val;             // per chunk: [program length][G]  BOLUS amount / PROP rate
+  std::vector<int32_t> generic_subjects;  // subjects left to the generic kernel (ascending)
+};
+
+// Group the subjects of an analytical op stream into classes; classes with fewer than
+// `min_class_size` members stay generic.
+void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, int32_t min_class_size, ClassPlan* out);
 
 // Validate + copy + sort (Occasion::sort, structs.rs:669-671) + build covariate segments.
 // Returns PMX_OK or an error with `err` filled.

@@ -41,6 +41,15 @@ __device__ __forceinline__ int64_t uniform64(int64_t v) {
   return static_cast<int64_t>((static_cast<uint64_t>(hi) << 32) | lo);
 }
 __device__ __forceinline__ uint32_t uniform32(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// Read-only-for-the-launch data addressed with wave-uniform indices: a constant-address-space
+// pointer lets the backend use the scalar unit (s_load_*) instead of 64 identical vector loads.
+template <class T>
+using cptr = const __attribute__((address_space(4))) T*;
+template <class T>
+__device__ __forceinline__ cptr<T> as_const(const T* p) {
+  return (cptr<T>)(p);
+}
 __device__ __forceinline__ double uniformf64(double v) {
   return __longlong_as_double(uniform64(__double_as_longlong(v)));
 }
@@ -63,9 +72,16 @@ __device__ __forceinline__ double apply_factors(const pmx_derived& dd, double ba
 
 template <int N>
 __device__ __forceinline__ double select_state(const double (&x)[N], int idx) {
+  // The empty asm pins each element in a VGPR pair: without it LLVM rewrites the select chain into
+  // ONE load from a selected address, which forces the whole state array out of registers (it was
+  // promoted to LDS/scratch for every 3- and 4-state structure).
   double v = x[0];
 #pragma unroll
-  for (int i = 1; i < N; ++i) v = (idx == i) ? x[i] : v;
+  for (int i = 1; i < N; ++i) {
+    double xi = x[i];
+    asm volatile("" : "+v"(xi));
+    v = (idx == i) ? xi : v;
+  }
   return v;
 }
 
@@ -162,7 +178,8 @@ template <int KID, bool DYN>
 __global__ __launch_bounds__(kBlock) void pmx_analytical_grid(DevModel m, DevOps ops, const double* __restrict__ theta,
                                                               int64_t P, int64_t S, int32_t s_chunk, int32_t n_ptiles,
                                                               double* __restrict__ pred, int64_t ld,
-                                                              uint8_t* __restrict__ status) {
+                                                              uint8_t* __restrict__ status,
+                                                              const int32_t* __restrict__ subj_list) {
   using LM = LaneModel<KID>;
   constexpr int NS = LM::NS;
   const int64_t b = blockIdx.x;
@@ -180,7 +197,8 @@ __global__ __launch_bounds__(kBlock) void pmx_analytical_grid(DevModel m, DevOps
 
   const int64_t s_begin = chunk * s_chunk;
   const int64_t s_end = (s_begin + s_chunk < S) ? (s_begin + s_chunk) : S;
-  for (int64_t s = s_begin; s < s_end; ++s) {
+  for (int64_t si = s_begin; si < s_end; ++si) {
+    const int64_t s = subj_list ? static_cast<int64_t>(uniform32(static_cast<uint32_t>(subj_list[si]))) : si;
     const int64_t o0 = uniform64(ops.subj_op_off[s]);
     const int64_t o1 = uniform64(ops.subj_op_off[s + 1]);
     int64_t row = uniform64(ops.subj_obs_off[s]);
@@ -200,7 +218,7 @@ __global__ __launch_bounds__(kBlock) void pmx_analytical_grid(DevModel m, DevOps
         if constexpr (DYN) {
           if (!lane_prepare_dyn<KID>(m, L, cov)) st = PMX_PAIR_COMPLEX_ROOTS;
         }
-        LM::S::advance(L.coef, x, a, r);
+        advance<LM::ST>(L.coef, x, a, r);
         xpad = 0.0;  // pm_* wrappers re-pad slot 0 with 0 after every kernel call (analytical/mod.rs:70-75)
       } else if (kind == OP_OBS) {
         double y = lane_out<KID>(m, L, x, xpad, io, cov);
@@ -221,6 +239,153 @@ __global__ __launch_bounds__(kBlock) void pmx_analytical_grid(DevModel m, DevOps
       }
     }
     if (status != nullptr && lane_ok) status[s * P + p] = st;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// CLASSED GRID kernel (analytical): one propagator per (lane, program step), applied to a
+// register-resident batch of G subjects that share a dosing/sampling design (pmx_compile.hpp
+// ClassPlan).  Per (subject, support point) the arithmetic is the generic kernel's; what goes away
+// is recomputing exp(-lambda*dt) for every member, and fetching/decoding the op stream per subject.
+// ------------------------------------------------------------------------------------
+template <int KID>
+struct ClassBatch {
+  static constexpr int G = (LaneModel<KID>::NS <= 2) ? 8 : 4;
+};
+
+// __launch_bounds__ 2nd argument = waves per SIMD the register allocator must leave room for
+// (4 -> at most 128 VGPRs): the kernel is a latency/bandwidth mix and wants the occupancy.
+template <int KID>
+__global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx_analytical_classed(DevModel m, DevOps ops, DevClassPlan cp,
+                                                                 const double* __restrict__ theta, int64_t P,
+                                                                 int32_t chunks_per_block, int32_t n_ptiles,
+                                                                 double* __restrict__ pred, int64_t ld,
+                                                                 uint8_t* __restrict__ status) {
+  using LM = LaneModel<KID>;
+  constexpr int NS = LM::NS;
+  constexpr int G = ClassBatch<KID>::G;
+  const int64_t b = blockIdx.x;
+  const int32_t ptile = static_cast<int32_t>(b % n_ptiles);
+  const int64_t cblock = b / n_ptiles;
+  const int64_t p = static_cast<int64_t>(ptile) * kBlock + threadIdx.x;
+  const bool lane_ok = p < P;
+  const int64_t pc = lane_ok ? p : (P - 1);
+  const uint32_t p32 = static_cast<uint32_t>(pc);
+
+  LM L;
+  lane_setup<KID, false>(m, theta + pc * m.nparams, L);
+  if (!L.ok) {  // complex roots: every prediction of this lane is NaN (the reference panics)
+    const double nanv = __longlong_as_double(0x7ff8000000000000LL);
+#pragma unroll
+    for (int q = 0; q < PMX_MAX_OUT; ++q) L.inv_vol[q] = nanv;
+  }
+  // the plan arrays are read-only for the whole launch and every index below is wave-uniform:
+  // constant-address-space pointers make these scalar (s_load) fetches
+  const auto prog_meta = as_const(cp.prog_meta);
+  const auto prog_dt = as_const(cp.prog_dt);
+  const auto cls_prog_off = as_const(cp.cls_prog_off);
+  const auto chunk_cls = as_const(cp.chunk_cls);
+  const auto chunk_n = as_const(cp.chunk_n);
+  const auto chunk_val_off = as_const(cp.chunk_val_off);
+  const auto chunk_subj = as_const(cp.chunk_subj);
+  const auto chunk_row = as_const(cp.chunk_row);
+  const auto val = as_const(cp.val);
+
+  const int64_t c_begin = cblock * chunks_per_block;
+  const int64_t c_end = (c_begin + chunks_per_block < cp.n_chunks) ? (c_begin + chunks_per_block) : cp.n_chunks;
+  for (int64_t c = c_begin; c < c_end; ++c) {
+    const int32_t cls = chunk_cls[c];
+    const int32_t n_live = chunk_n[c];
+    int64_t voff = chunk_val_off[c];
+    const int64_t pb = cls_prog_off[cls];
+    const int64_t pe = cls_prog_off[cls + 1];
+    int64_t kld = 0;  // (observations emitted so far) * ld
+    int64_t rbase[G];  // element offset of each member's first prediction row (wave-uniform)
+    {
+      const auto rows = chunk_row + c * G;
+#pragma unroll
+      for (int j = 0; j < G; ++j) rbase[j] = rows[j] * ld;
+    }
+    double x[G][NS];
+    double acc[G];  // acc[j] turns NaN as soon as member j emits a non-finite prediction (0*y is NaN iff y is)
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      acc[j] = 0.0;
+#pragma unroll
+      for (int i = 0; i < NS; ++i) x[j][i] = 0.0;
+    }
+    for (int64_t o = pb; o < pe; ++o, voff += G) {
+      const uint32_t meta = prog_meta[o];
+      const uint32_t kind = meta & 0xffu;
+      const int io = static_cast<int>((meta >> 8) & 0xffffu);
+      if (kind == OP_PROP) {
+        const double dt = prog_dt[o];
+        typename LM::S::Prop pr;
+        LM::S::make_prop(L.coef, dt, pr);
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+          LM::S::apply(pr, x[j], val[voff + j]);
+          // keep the scheduler from interleaving all G updates (it would hold old and new state of
+          // every member at once: +2*NS*G registers, one wave per SIMD less)
+          if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+        }
+      } else if (kind == OP_OBS) {
+        int out_state = 0;
+        double inv_vol = 1.0;
+#pragma unroll
+        for (int q = 0; q < PMX_MAX_OUT; ++q) {
+          if (q == io) {
+            out_state = m.out[q].state;
+            inv_vol = L.inv_vol[q];
+          }
+        }
+        double y[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j) y[j] = 0.0;
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+          if (out_state == st) {  // wave-uniform: no per-lane selects
+#pragma unroll
+            for (int j = 0; j < G; ++j) y[j] = x[j][st] * inv_vol;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < G; ++j) acc[j] = fma(y[j], 0.0, acc[j]);
+        if (lane_ok) {
+          if (n_live == G) {
+#pragma unroll
+            for (int j = 0; j < G; ++j) (pred + (rbase[j] + kld))[p32] = y[j];  // wave-uniform row base + lane
+          } else {
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+              if (j < n_live) (pred + (rbase[j] + kld))[p32] = y[j];
+          }
+        }
+        kld += ld;
+      } else if (kind == OP_BOLUS) {
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+          const double a = val[voff + j];
+#pragma unroll
+          for (int i = 0; i < NS; ++i) x[j][i] += (i == io) ? a : 0.0;
+        }
+      } else {  // OP_RESET
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+#pragma unroll
+          for (int i = 0; i < NS; ++i) x[j][i] = io ? L.xinit[i] : 0.0;
+      }
+    }
+    if (status != nullptr && lane_ok) {
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        if (j < n_live) {
+          const int64_t sid = chunk_subj[c * G + j];
+          const uint8_t st = !L.ok ? PMX_PAIR_COMPLEX_ROOTS : ((acc[j] != acc[j]) ? PMX_PAIR_NONFINITE : PMX_PAIR_OK);
+          (status + sid * P)[p32] = st;
+        }
+      }
+    }
   }
 }
 
@@ -267,7 +432,7 @@ __global__ __launch_bounds__(kBlock) void pmx_analytical_pair(DevModel m, DevOps
       if constexpr (DYN) {
         if (!lane_prepare_dyn<KID>(m, L, cov)) st = PMX_PAIR_COMPLEX_ROOTS;
       }
-      LM::S::advance(L.coef, x, a, r);
+      advance<LM::ST>(L.coef, x, a, r);
       xpad = 0.0;
     } else if (kind == OP_OBS) {
       double y = lane_out<KID>(m, L, x, xpad, io, cov);
@@ -568,11 +733,36 @@ hipError_t launch_analytical(const LaunchArgs& a, const char** name) {
   static const char* const kNamePair = DYN ? "pmx_analytical_pair<dyn>" : "pmx_analytical_pair";
   hipStream_t st = static_cast<hipStream_t>(a.stream);
   if (a.mode == MODE_GRID) {
+    int64_t n_walk = a.S;
+    const int32_t* list = nullptr;
     *name = kNameGrid;
-    const int64_t n_chunks = (a.S + a.s_chunk - 1) / a.s_chunk;
+    if constexpr (!DYN) {
+      if (a.use_classes && a.cls.n_chunks > 0) {
+        *name = "pmx_analytical_classed";
+        // enough blocks to fill the chip several times over, few enough that lane_setup stays amortised
+        int64_t cpb = (a.cls.n_chunks * a.n_ptiles) / 8192;
+        if (cpb < 1) cpb = 1;
+        if (cpb > 8) cpb = 8;
+        const int64_t cblocks = (a.cls.n_chunks + cpb - 1) / cpb;
+        hipLaunchKernelGGL((pmx_analytical_classed<KID>), dim3(static_cast<uint32_t>(cblocks * a.n_ptiles)), dim3(kBlock),
+                           0, st, a.m, a.ops, a.cls, a.theta, a.P, static_cast<int32_t>(cpb), a.n_ptiles, a.pred, a.ld,
+                           a.status);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        n_walk = a.cls.n_generic;
+        list = a.cls.generic_subjects;
+        if (n_walk == 0) return hipSuccess;
+      }
+    }
+    int32_t s_chunk = a.s_chunk;
+    if (list != nullptr) {
+      int64_t ch = (n_walk * a.n_ptiles) / 8192;
+      s_chunk = static_cast<int32_t>(ch < 1 ? 1 : (ch > 64 ? 64 : ch));
+    }
+    const int64_t n_chunks = (n_walk + s_chunk - 1) / s_chunk;
     const int64_t blocks = n_chunks * a.n_ptiles;
     hipLaunchKernelGGL((pmx_analytical_grid<KID, DYN>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlock), 0, st, a.m,
-                       a.ops, a.theta, a.P, a.S, a.s_chunk, a.n_ptiles, a.pred, a.ld, a.status);
+                       a.ops, a.theta, a.P, n_walk, s_chunk, a.n_ptiles, a.pred, a.ld, a.status, list);
   } else {
     *name = kNamePair;
     const int64_t n_pairs = a.batch ? a.S : a.S * a.P;

@@ -39,6 +39,24 @@ struct DevOps {
   int32_t pad_;
 };
 
+// Device mirror of a ClassPlan (pmx_compile.hpp).
+struct DevClassPlan {
+  const uint32_t* prog_meta;
+  const double* prog_dt;
+  const int64_t* cls_prog_off;
+  const int32_t* chunk_cls;
+  const int32_t* chunk_n;
+  const int64_t* chunk_val_off;
+  const int32_t* chunk_subj;
+  const int64_t* chunk_row;  // [n_chunks*G] first prediction row of each member (0 for padding)
+  const double* val;
+  const int32_t* generic_subjects;  // subjects the generic GRID kernel still has to walk
+  int64_t n_chunks;
+  int64_t n_generic;
+  int32_t G;
+  int32_t pad_;
+};
+
 enum LaneMode : int32_t { MODE_GRID = 0, MODE_PAIR = 1 };
 
 struct LaunchArgs {
@@ -54,6 +72,10 @@ struct LaunchArgs {
   int32_t s_chunk;   // GRID: subjects walked by one block
   int32_t n_ptiles;  // GRID: ceil(P / 256)
   int32_t dyn;       // analytical: kernel parameters depend on covariates (re-prepare per PROP)
+  int32_t use_classes;  // GRID analytical: run the classed kernel on cls.n_chunks, the generic one on the rest
+  DevClassPlan cls;
+  const int32_t* subj_list;  // GRID: walk these subjects instead of 0..S-1 (nullptr = all)
+  int64_t n_list;
   void* stream;
 };
 

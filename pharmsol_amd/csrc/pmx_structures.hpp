@@ -11,11 +11,15 @@
 //
 // The reference recomputes eigenvalues and all coefficient quotients on EVERY
 // sub-segment.  Here each structure is split into
-//   prepare(kp)  -> Coef : everything that depends on the rate constants only
-//                          (eigenvalues, coefficient quotients as reciprocals)
-//   advance(Coef, x, dt, r)  : the exp() calls and the state update
-// so that a lane whose rate constants are fixed (no covariate-derived parameter)
-// prepares once and only pays exp + a handful of FMAs per sub-segment.
+//   prepare(kp)            -> Coef : everything that depends on the rate constants only
+//                                    (eigenvalues, coefficient quotients as reciprocals)
+//   make_prop(Coef, dt)    -> Prop : the exp() calls: the one-step propagator of the linear system,
+//                                    x' = F x + J r  (F = transition matrix over dt, J = response to a
+//                                    unit infusion rate)
+//   apply(Prop, x, r)              : the state update, a handful of FMAs
+// A lane whose rate constants are fixed (no covariate-derived parameter) prepares once; subjects that
+// share a segment length dt (shared dosing/sampling design) can also share the lane's Prop — the
+// "classed" kernel in pmx_kernels.hip applies one Prop to a register-resident batch of subjects.
 // Divisions by (l1-l2), l_i, (ka-l_i) become multiplications by reciprocals
 // computed in prepare(): results differ from the reference by a few ulp
 // (parity budget 1e-6 relative, tests/test_gpu_parity.py).
@@ -91,14 +95,20 @@ struct Structure<S_ONE> {
   struct Coef {
     double ke, inv_ke;
   };
+  struct Prop {
+    double e, j;
+  };
   __device__ __forceinline__ static bool prepare(const double* kp, Coef& c) {
     c.ke = kp[0];
     c.inv_ke = 1.0 / kp[0];
     return true;
   }
-  __device__ __forceinline__ static void advance(const Coef& c, double (&x)[NS], double dt, double r) {
-    const double e = exp(-c.ke * dt);
-    x[0] = x[0] * e + (r * c.inv_ke) * (1.0 - e);
+  __device__ __forceinline__ static void make_prop(const Coef& c, double dt, Prop& p) {
+    p.e = exp(-c.ke * dt);
+    p.j = c.inv_ke * (1.0 - p.e);
+  }
+  __device__ __forceinline__ static void apply(const Prop& p, double (&x)[NS], double r) {
+    x[0] = x[0] * p.e + p.j * r;
   }
 };
 
@@ -108,6 +118,9 @@ struct Structure<S_ONE_ABS> {
   struct Coef {
     double ka, ke, inv_ke, ka_over;  // ka_over = ka / (ka - ke)
   };
+  struct Prop {
+    double ea, ee, j, g;
+  };
   __device__ __forceinline__ static bool prepare(const double* kp, Coef& c) {
     c.ka = kp[0];
     c.ke = kp[1];
@@ -115,12 +128,16 @@ struct Structure<S_ONE_ABS> {
     c.ka_over = kp[0] / (kp[0] - kp[1]);
     return true;
   }
-  __device__ __forceinline__ static void advance(const Coef& c, double (&x)[NS], double dt, double r) {
-    const double ea = exp(-c.ka * dt);
-    const double ee = exp(-c.ke * dt);
+  __device__ __forceinline__ static void make_prop(const Coef& c, double dt, Prop& p) {
+    p.ea = exp(-c.ka * dt);
+    p.ee = exp(-c.ke * dt);
+    p.j = c.inv_ke * (1.0 - p.ee);
+    p.g = c.ka_over * (p.ee - p.ea);
+  }
+  __device__ __forceinline__ static void apply(const Prop& p, double (&x)[NS], double r) {
     const double g = x[0];
-    x[0] = g * ea;
-    x[1] = x[1] * ee + (r * c.inv_ke) * (1.0 - ee) + (c.ka_over * g) * (ee - ea);
+    x[0] = g * p.ea;
+    x[1] = x[1] * p.ee + p.j * r + p.g * g;
   }
 };
 
@@ -151,6 +168,19 @@ struct TwoCore {
     return ok;
   }
 };
+struct TwoProp {
+  double f00, f01, f10, f11, j0, j1;
+  __device__ __forceinline__ void make(const TwoCore& t, double e1, double e2) {
+    const double de = (e2 - e1) * t.inv_d;
+    f00 = (t.a11 * e1 + t.b11 * e2) * t.inv_d;
+    f01 = t.kpc * de;
+    f10 = t.kcp * de;
+    f11 = (t.a22 * e1 + t.b22 * e2) * t.inv_d;
+    const double o1 = 1.0 - e1, o2 = 1.0 - e2;
+    j0 = (t.i0a * o1 + t.i0b * o2) * t.inv_d;
+    j1 = (t.i1a * o1 + t.i1b * o2) * t.inv_d;
+  }
+};
 
 template <>
 struct Structure<S_TWO> {
@@ -158,24 +188,17 @@ struct Structure<S_TWO> {
   struct Coef {
     TwoCore t;
   };
+  struct Prop {
+    TwoProp p;
+  };
   __device__ __forceinline__ static bool prepare(const double* kp, Coef& c) { return c.t.prepare(kp[0], kp[1], kp[2]); }
-  __device__ __forceinline__ static void advance(const Coef& c, double (&x)[NS], double dt, double r) {
-    const TwoCore& t = c.t;
-    const double e1 = exp(-t.l1 * dt);
-    const double e2 = exp(-t.l2 * dt);
-    const double de = e2 - e1;
-    const double m11 = t.a11 * e1 + t.b11 * e2;
-    const double m12 = t.kpc * de;
-    const double m21 = t.kcp * de;
-    const double m22 = t.a22 * e1 + t.b22 * e2;
-    double n0 = (m11 * x[0] + m12 * x[1]) * t.inv_d;
-    double n1 = (m21 * x[0] + m22 * x[1]) * t.inv_d;
-    if (r != 0.0) {
-      const double f = r * t.inv_d;
-      const double o1 = 1.0 - e1, o2 = 1.0 - e2;
-      n0 += (t.i0a * o1 + t.i0b * o2) * f;
-      n1 += (t.i1a * o1 + t.i1b * o2) * f;
-    }
+  __device__ __forceinline__ static void make_prop(const Coef& c, double dt, Prop& p) {
+    p.p.make(c.t, exp(-c.t.l1 * dt), exp(-c.t.l2 * dt));
+  }
+  __device__ __forceinline__ static void apply(const Prop& q, double (&x)[NS], double r) {
+    const TwoProp& p = q.p;
+    const double n0 = p.f00 * x[0] + p.f01 * x[1] + p.j0 * r;
+    const double n1 = p.f10 * x[0] + p.f11 * x[1] + p.j1 * r;
     x[0] = n0;
     x[1] = n1;
   }
@@ -188,6 +211,10 @@ struct Structure<S_TWO_ABS> {
     TwoCore t;
     double ka, a0a, a0b, a1a, a1b;  // absorption vector quotients: (l1-kpc)/(ka-l1) ...
   };
+  struct Prop {
+    TwoProp p;
+    double ea, g0, g1;
+  };
   __device__ __forceinline__ static bool prepare(const double* kp, Coef& c) {
     // native order [ke, ka, kcp, kpc] (two_compartment_models.rs:62-65)
     const bool ok = c.t.prepare(kp[0], kp[2], kp[3]);
@@ -199,30 +226,22 @@ struct Structure<S_TWO_ABS> {
     c.a1b = c.t.kcp * r2;
     return ok;
   }
-  __device__ __forceinline__ static void advance(const Coef& c, double (&x)[NS], double dt, double r) {
-    const TwoCore& t = c.t;
-    const double e1 = exp(-t.l1 * dt);
-    const double e2 = exp(-t.l2 * dt);
-    const double ea = exp(-c.ka * dt);
-    const double de = e2 - e1;
-    const double m11 = t.a11 * e1 + t.b11 * e2;
-    const double m12 = t.kpc * de;
-    const double m21 = t.kcp * de;
-    const double m22 = t.a22 * e1 + t.b22 * e2;
+  __device__ __forceinline__ static void make_prop(const Coef& c, double dt, Prop& p) {
+    const double e1 = exp(-c.t.l1 * dt);
+    const double e2 = exp(-c.t.l2 * dt);
+    p.ea = exp(-c.ka * dt);
+    p.p.make(c.t, e1, e2);
+    const double h = c.ka * c.t.inv_d;  // ka * x[0] / (l1 - l2)  (:103)
+    const double d1 = e1 - p.ea, d2 = e2 - p.ea;
+    p.g0 = (c.a0a * d1 + c.a0b * d2) * h;
+    p.g1 = (c.a1a * d1 + c.a1b * d2) * h;
+  }
+  __device__ __forceinline__ static void apply(const Prop& q, double (&x)[NS], double r) {
+    const TwoProp& p = q.p;
     const double g = x[0];
-    double n0 = (m11 * x[1] + m12 * x[2]) * t.inv_d;
-    double n1 = (m21 * x[1] + m22 * x[2]) * t.inv_d;
-    if (r != 0.0) {
-      const double f = r * t.inv_d;
-      const double o1 = 1.0 - e1, o2 = 1.0 - e2;
-      n0 += (t.i0a * o1 + t.i0b * o2) * f;
-      n1 += (t.i1a * o1 + t.i1b * o2) * f;
-    }
-    const double h = c.ka * g * t.inv_d;  // :103
-    const double d1 = e1 - ea, d2 = e2 - ea;
-    n0 += (c.a0a * d1 + c.a0b * d2) * h;
-    n1 += (c.a1a * d1 + c.a1b * d2) * h;
-    x[0] = g * ea;
+    const double n0 = p.f00 * x[1] + p.f01 * x[2] + p.j0 * r + q.g0 * g;
+    const double n1 = p.f10 * x[1] + p.f11 * x[2] + p.j1 * r + q.g1 * g;
+    x[0] = g * q.ea;
     x[1] = n0;
     x[2] = n1;
   }
@@ -260,15 +279,15 @@ struct ThreeCore {
       const double lo1 = l[(i + 1) % 3], lo2 = l[(i + 2) % 3];
       const double inv = 1.0 / ((lo1 - li) * (lo2 - li));  // d_i
       const double u = k21 - li, v = k31 - li, w = K - li;
-      c[0 * 3 + i] = u * v * inv;                    // c1..3
-      c[1 * 3 + i] = k21 * v * inv;                  // c4..6
-      c[2 * 3 + i] = k31 * u * inv;                  // c7..9
-      c[3 * 3 + i] = k12 * v * inv;                  // c10..12
-      c[4 * 3 + i] = (w * v - k13 * k31) * inv;      // c13..15
-      c[5 * 3 + i] = k12 * k31 * inv;                // c16..18
-      c[6 * 3 + i] = k13 * u * inv;                  // c19..21
-      c[7 * 3 + i] = k21 * k13 * inv;                // c22..24
-      c[8 * 3 + i] = (w * u - k12 * k21) * inv;      // c25..27
+      c[0 * 3 + i] = u * v * inv;                // c1..3
+      c[1 * 3 + i] = k21 * v * inv;              // c4..6
+      c[2 * 3 + i] = k31 * u * inv;              // c7..9
+      c[3 * 3 + i] = k12 * v * inv;              // c10..12
+      c[4 * 3 + i] = (w * v - k13 * k31) * inv;  // c13..15
+      c[5 * 3 + i] = k12 * k31 * inv;            // c16..18
+      c[6 * 3 + i] = k13 * u * inv;              // c19..21
+      c[7 * 3 + i] = k21 * k13 * inv;            // c22..24
+      c[8 * 3 + i] = (w * u - k12 * k21) * inv;  // c25..27
       const double il = 1.0 / li;
       d[0 * 3 + i] = c[0 * 3 + i] * il;
       d[1 * 3 + i] = c[3 * 3 + i] * il;
@@ -276,20 +295,15 @@ struct ThreeCore {
     }
     return ok;
   }
-  __device__ __forceinline__ void apply(const double (&e)[3], double x0, double x1, double x2, double r, double& y0,
-                                        double& y1, double& y2) const {
-    double mm[9];
+};
+struct ThreeProp {
+  double m[9], j[3];
+  __device__ __forceinline__ void make(const ThreeCore& t, const double (&e)[3]) {
 #pragma unroll
-    for (int j = 0; j < 9; ++j) mm[j] = c[3 * j] * e[0] + c[3 * j + 1] * e[1] + c[3 * j + 2] * e[2];
-    y0 = mm[0] * x0 + mm[1] * x1 + mm[2] * x2;
-    y1 = mm[3] * x0 + mm[4] * x1 + mm[5] * x2;
-    y2 = mm[6] * x0 + mm[7] * x1 + mm[8] * x2;
-    if (r != 0.0) {
-      const double o0 = 1.0 - e[0], o1 = 1.0 - e[1], o2 = 1.0 - e[2];
-      y0 += (o0 * d[0] + o1 * d[1] + o2 * d[2]) * r;
-      y1 += (o0 * d[3] + o1 * d[4] + o2 * d[5]) * r;
-      y2 += (o0 * d[6] + o1 * d[7] + o2 * d[8]) * r;
-    }
+    for (int k = 0; k < 9; ++k) m[k] = t.c[3 * k] * e[0] + t.c[3 * k + 1] * e[1] + t.c[3 * k + 2] * e[2];
+    const double o0 = 1.0 - e[0], o1 = 1.0 - e[1], o2 = 1.0 - e[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) j[k] = o0 * t.d[3 * k] + o1 * t.d[3 * k + 1] + o2 * t.d[3 * k + 2];
   }
 };
 
@@ -299,15 +313,23 @@ struct Structure<S_THREE> {
   struct Coef {
     ThreeCore t;
   };
+  struct Prop {
+    ThreeProp p;
+  };
   __device__ __forceinline__ static bool prepare(const double* kp, Coef& c) {
     return c.t.prepare(kp[0], kp[1], kp[2], kp[3], kp[4]);
   }
-  __device__ __forceinline__ static void advance(const Coef& c, double (&x)[NS], double dt, double r) {
+  __device__ __forceinline__ static void make_prop(const Coef& c, double dt, Prop& p) {
     double e[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) e[i] = exp(-(c.t.l[i] * dt));
-    double y0, y1, y2;
-    c.t.apply(e, x[0], x[1], x[2], r, y0, y1, y2);
+    p.p.make(c.t, e);
+  }
+  __device__ __forceinline__ static void apply(const Prop& q, double (&x)[NS], double r) {
+    const ThreeProp& p = q.p;
+    const double y0 = p.m[0] * x[0] + p.m[1] * x[1] + p.m[2] * x[2] + p.j[0] * r;
+    const double y1 = p.m[3] * x[0] + p.m[4] * x[1] + p.m[5] * x[2] + p.j[1] * r;
+    const double y2 = p.m[6] * x[0] + p.m[7] * x[1] + p.m[8] * x[2] + p.j[2] * r;
     x[0] = y0;
     x[1] = y1;
     x[2] = y2;
@@ -322,6 +344,10 @@ struct Structure<S_THREE_ABS> {
     double ka;
     double f[9];  // f[3*row + i] = C_{row,1}^{(i)} / (ka - l_i)   (:218-228)
   };
+  struct Prop {
+    ThreeProp p;
+    double ea, g[3];
+  };
   __device__ __forceinline__ static bool prepare(const double* kp, Coef& c) {
     const bool ok = c.t.prepare(kp[1], kp[2], kp[3], kp[4], kp[5]);
     c.ka = kp[0];
@@ -334,24 +360,36 @@ struct Structure<S_THREE_ABS> {
     }
     return ok;
   }
-  __device__ __forceinline__ static void advance(const Coef& c, double (&x)[NS], double dt, double r) {
+  __device__ __forceinline__ static void make_prop(const Coef& c, double dt, Prop& p) {
     double e[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) e[i] = exp(-(c.t.l[i] * dt));
-    const double ea = exp(-c.ka * dt);
+    p.ea = exp(-c.ka * dt);
+    p.p.make(c.t, e);
+    const double d0 = e[0] - p.ea, d1 = e[1] - p.ea, d2 = e[2] - p.ea;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p.g[k] = (d0 * c.f[3 * k] + d1 * c.f[3 * k + 1] + d2 * c.f[3 * k + 2]) * c.ka;  // (:230)
+  }
+  __device__ __forceinline__ static void apply(const Prop& q, double (&x)[NS], double r) {
+    const ThreeProp& p = q.p;
     const double g = x[0];
-    double y0, y1, y2;
-    c.t.apply(e, x[1], x[2], x[3], r, y0, y1, y2);
-    const double h = c.ka * g;  // absorption_vector * ka * x[0]  (:230)
-    const double d0 = e[0] - ea, d1 = e[1] - ea, d2 = e[2] - ea;
-    y0 += (d0 * c.f[0] + d1 * c.f[1] + d2 * c.f[2]) * h;
-    y1 += (d0 * c.f[3] + d1 * c.f[4] + d2 * c.f[5]) * h;
-    y2 += (d0 * c.f[6] + d1 * c.f[7] + d2 * c.f[8]) * h;
-    x[0] = g * ea;
+    const double y0 = p.m[0] * x[1] + p.m[1] * x[2] + p.m[2] * x[3] + p.j[0] * r + q.g[0] * g;
+    const double y1 = p.m[3] * x[1] + p.m[4] * x[2] + p.m[5] * x[3] + p.j[1] * r + q.g[1] * g;
+    const double y2 = p.m[6] * x[1] + p.m[7] * x[2] + p.m[8] * x[3] + p.j[2] * r + q.g[2] * g;
+    x[0] = g * q.ea;
     x[1] = y0;
     x[2] = y1;
     x[3] = y2;
   }
 };
+
+// advance = make_prop + apply (one sub-segment of Analytical::solve, analytical/mod.rs:363-364)
+template <int ST>
+__device__ __forceinline__ void advance(const typename Structure<ST>::Coef& c, double (&x)[Structure<ST>::NS], double dt,
+                                        double r) {
+  typename Structure<ST>::Prop p;
+  Structure<ST>::make_prop(c, dt, p);
+  Structure<ST>::apply(p, x, r);
+}
 
 }  // namespace pmx

@@ -73,7 +73,7 @@ def test_c2_two_compartment_10k_subjects_one_support_point():
 
 def test_c3_grid_slice():
     m, flat, theta = synth.config_c3(500, 1000)
-    assert_parity(m, flat, theta, TOL_ANALYTICAL, expect_kernel="pmx_analytical_grid")
+    assert_parity(m, flat, theta, TOL_ANALYTICAL, expect_kernel="pmx_analytical_classed")
 
 
 def test_c4_ode_rk4_divergent_schedules_batch():

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Collect PMC counters for the bench kernel in separate rocprofv3 passes (counters only: no trace domains).
+# usage: tools/pmc_run.sh <outdir> [bench args...]
+set -u
+export TMPDIR=/tmp
+OUT=$1; shift
+mkdir -p "$OUT"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline $*"
+i=0
+for set in \
+  "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
+  "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU GRBM_GUI_ACTIVE" \
+  "WRITE_SIZE" \
+  "FETCH_SIZE" \
+  "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_HIT_sum TCC_MISS_sum" ; do
+  i=$((i+1))
+  rocprofv3 --pmc $set --output-format csv -d "$OUT/pass$i" -o pmc -- python3 bench.py $ARGS > "$OUT/pass$i.log" 2>&1
+  echo "pass $i rc=$?"
+done
