@@ -11,7 +11,8 @@ import os
 from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpmx_hip.so")
+# PMX_LIB: developer override for same-device A/B runs of two builds (tools/ab_build.sh)
+LIB_PATH = os.environ.get("PMX_LIB") or os.path.join(_HERE, "lib", "libpmx_hip.so")
 _lib = None
 
 # every symbol include/pmx.h declares: (name, restype, argtypes)

@@ -381,6 +381,12 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
   const int64_t blocks = a.mode == pmx::MODE_GRID ? ((a.S + a.s_chunk - 1) / a.s_chunk) * a.n_ptiles
                                                   : ((batch ? a.S : a.S * a.P) + 255) / 256;
   if (blocks > 0x7fffffffLL) return fail(PMX_ERR_INVALID_ARGUMENT, "grid too large for one launch");
+  if (d_status != nullptr) {
+    // PMX_PAIR_OK == 0: the kernels only write the bytes of failed pairs
+    const int64_t n_status = batch ? a.S : a.S * P;
+    hipError_t me = hipMemsetAsync(d_status, 0, static_cast<size_t>(n_status), static_cast<hipStream_t>(stream));
+    if (me != hipSuccess) return fail(PMX_ERR_HIP, std::string("hipMemsetAsync(status): ") + hipGetErrorString(me));
+  }
   const char* name = "";
   hipError_t e = pmx::launch_predict(a, &name);
   g_kernel_name = name;

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(kBlock) void pmx_analytical_grid(DevModel m, DevOps
         if constexpr (DYN) st = st_lane;  // a new occasion re-derives its coefficients
       }
     }
-    if (status != nullptr && lane_ok) status[s * P + p] = st;
+    if (status != nullptr && lane_ok && st != PMX_PAIR_OK) status[s * P + p] = st;  // array pre-zeroed by the library
   }
 }
 
@@ -253,31 +253,96 @@ struct ClassBatch {
   static constexpr int G = (LaneModel<KID>::NS <= 2) ? 8 : 4;
 };
 
+// Emit one observation row for every member of the chunk: y = x[ST] * inv_vol, stored in PAIRS.
+// Lanes 0-31 of a wave own the even support points of the wave's 64, lanes 32-63 the odd ones; one
+// v_permlane32_swap per dword turns (member A value, member B value) into (two adjacent doubles of A's
+// row | two adjacent doubles of B's row), so a pair of members leaves in ONE 16-byte store per lane.
+template <int ST, int G, int NS>
+__device__ __forceinline__ void classed_emit(const double (&x)[G][NS], double inv_vol, const int64_t (&rbase)[G],
+                                             int64_t kld, int64_t p_even, bool upper, bool pair_full, bool pair_half,
+                                             bool any_half, int32_t n_live, double* __restrict__ pred, uint32_t& bad) {
+#pragma unroll
+  for (int j = 0; j < G; j += 2) {
+    if (j < n_live) {  // wave-uniform
+      const double ya = x[j][ST] * inv_vol;
+      const double yb = x[j + 1][ST] * inv_vol;
+      if (!isfinite(ya)) bad |= (1u << j);
+      if (!isfinite(yb)) bad |= (1u << (j + 1));
+      uint32_t alo = static_cast<uint32_t>(__double_as_longlong(ya));
+      uint32_t ahi = static_cast<uint32_t>(static_cast<uint64_t>(__double_as_longlong(ya)) >> 32);
+      uint32_t blo = static_cast<uint32_t>(__double_as_longlong(yb));
+      uint32_t bhi = static_cast<uint32_t>(static_cast<uint64_t>(__double_as_longlong(yb)) >> 32);
+      const auto r0 = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+      const auto r1 = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+      double2 v;
+      v.x = __longlong_as_double(static_cast<int64_t>((static_cast<uint64_t>(r1[0]) << 32) | r0[0]));
+      v.y = __longlong_as_double(static_cast<int64_t>((static_cast<uint64_t>(r1[1]) << 32) | r0[1]));
+      const bool row_live = upper ? (j + 1 < n_live) : true;
+      int64_t ra = rbase[j], rb = rbase[j + 1];
+      asm volatile("" : "+s"(ra), "+s"(rb));  // keep the two row bases in SGPRs: without this LLVM selects between
+                                              // their ADDRESSES and parks the (wave-uniform) array in LDS
+      const int64_t off = (upper ? rb : ra) + kld + p_even;
+      if (row_live && pair_full) *reinterpret_cast<double2*>(pred + off) = v;
+      if (any_half) {  // wave-uniform: only the wave holding the last slot of an odd-length row
+        if (row_live && pair_half) pred[off] = v.x;
+      }
+    }
+  }
+}
+
+template <int ST, int G, int NS>
+__device__ __forceinline__ void classed_emit_state(int out_state, const double (&x)[G][NS], double inv_vol,
+                                                   const int64_t (&rbase)[G], int64_t kld, int64_t p_even, bool upper,
+                                                   bool pair_full, bool pair_half, bool any_half, int32_t n_live,
+                                                   double* __restrict__ pred, uint32_t& bad) {
+  if (out_state == ST) {
+    classed_emit<ST, G, NS>(x, inv_vol, rbase, kld, p_even, upper, pair_full, pair_half, any_half, n_live, pred, bad);
+  } else if constexpr (ST + 1 < NS) {
+    classed_emit_state<ST + 1, G, NS>(out_state, x, inv_vol, rbase, kld, p_even, upper, pair_full, pair_half, any_half,
+                                      n_live, pred, bad);
+  }
+}
+
 // __launch_bounds__ 2nd argument = waves per SIMD the register allocator must leave room for
 // (4 -> at most 128 VGPRs): the kernel is a latency/bandwidth mix and wants the occupancy.
 template <int KID>
-__global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx_analytical_classed(DevModel m, DevOps ops, DevClassPlan cp,
-                                                                 const double* __restrict__ theta, int64_t P,
-                                                                 int32_t chunks_per_block, int32_t n_ptiles,
-                                                                 double* __restrict__ pred, int64_t ld,
-                                                                 uint8_t* __restrict__ status) {
+__global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx_analytical_classed(
+    DevModel m, DevOps ops, DevClassPlan cp, const double* __restrict__ theta, int64_t P, int32_t chunks_per_block,
+    int32_t n_ptiles, double* __restrict__ pred, int64_t ld, uint8_t* __restrict__ status) {
   using LM = LaneModel<KID>;
   constexpr int NS = LM::NS;
   constexpr int G = ClassBatch<KID>::G;
+  static_assert(G % 2 == 0, "members are stored in pairs");
+  // XCD-aware block -> tile map.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8
+  // share an XCD and its L2).  The n_ptiles column tiles of one chunk-block together write whole
+  // prediction rows; placing them on ONE XCD lets that L2 assemble full rows / whole per-subject
+  // regions before write-back instead of scattering 2 KB pieces of every row over n_ptiles L2s.
+  // (speed only: any placement is correct)
   const int64_t b = blockIdx.x;
-  const int32_t ptile = static_cast<int32_t>(b % n_ptiles);
-  const int64_t cblock = b / n_ptiles;
-  const int64_t p = static_cast<int64_t>(ptile) * kBlock + threadIdx.x;
+  const int64_t group = b / (8 * n_ptiles);
+  const int32_t local = static_cast<int32_t>(b % (8 * n_ptiles));
+  const int32_t ptile = local / 8;
+  const int64_t cblock = group * 8 + (local % 8);
+  if (cblock * chunks_per_block >= cp.n_chunks) return;
+  const uint32_t lane = threadIdx.x & 63u;
+  const bool upper = lane >= 32u;
+  const int64_t p_even = static_cast<int64_t>(ptile) * kBlock + (threadIdx.x & ~63u) + 2u * (lane & 31u);
+  const int64_t p = p_even + (upper ? 1 : 0);
   const bool lane_ok = p < P;
   const int64_t pc = lane_ok ? p : (P - 1);
-  const uint32_t p32 = static_cast<uint32_t>(pc);
+  const bool pair_full = (p_even + 1) < P;   // this lane's 16-byte slot [p_even, p_even+1] is inside the row
+  const bool pair_half = (p_even + 1) == P;  // only its first 8 bytes are (odd n_support, last slot of a row)
+  const bool any_half = __any(pair_half ? 1 : 0) != 0;
 
-  LM L;
-  lane_setup<KID, false>(m, theta + pc * m.nparams, L);
-  if (!L.ok) {  // complex roots: every prediction of this lane is NaN (the reference panics)
-    const double nanv = __longlong_as_double(0x7ff8000000000000LL);
-#pragma unroll
-    for (int q = 0; q < PMX_MAX_OUT; ++q) L.inv_vol[q] = nanv;
+  typename LM::S::Coef coef;
+  double inv_vol0;  // 1/volume of output 0 (NaN for a lane with complex roots: all its predictions are NaN)
+  bool lane_good;
+  {
+    LM L;
+    lane_setup<KID, false>(m, theta + pc * m.nparams, L);
+    coef = L.coef;
+    lane_good = L.ok;
+    inv_vol0 = L.ok ? L.inv_vol[0] : __longlong_as_double(0x7ff8000000000000LL);
   }
   // the plan arrays are read-only for the whole launch and every index below is wave-uniform:
   // constant-address-space pointers make these scalar (s_load) fetches
@@ -290,6 +355,7 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
   const auto chunk_subj = as_const(cp.chunk_subj);
   const auto chunk_row = as_const(cp.chunk_row);
   const auto val = as_const(cp.val);
+  const double* __restrict__ th = theta + pc * m.nparams;
 
   const int64_t c_begin = cblock * chunks_per_block;
   const int64_t c_end = (c_begin + chunks_per_block < cp.n_chunks) ? (c_begin + chunks_per_block) : cp.n_chunks;
@@ -299,7 +365,7 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
     int64_t voff = chunk_val_off[c];
     const int64_t pb = cls_prog_off[cls];
     const int64_t pe = cls_prog_off[cls + 1];
-    int64_t kld = 0;  // (observations emitted so far) * ld
+    int64_t kld = 0;   // (observations emitted so far) * ld
     int64_t rbase[G];  // element offset of each member's first prediction row (wave-uniform)
     {
       const auto rows = chunk_row + c * G;
@@ -307,13 +373,11 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
       for (int j = 0; j < G; ++j) rbase[j] = rows[j] * ld;
     }
     double x[G][NS];
-    double acc[G];  // acc[j] turns NaN as soon as member j emits a non-finite prediction (0*y is NaN iff y is)
 #pragma unroll
-    for (int j = 0; j < G; ++j) {
-      acc[j] = 0.0;
+    for (int j = 0; j < G; ++j)
 #pragma unroll
       for (int i = 0; i < NS; ++i) x[j][i] = 0.0;
-    }
+    uint32_t bad = 0;  // bit j: member j emitted a non-finite prediction
     for (int64_t o = pb; o < pe; ++o, voff += G) {
       const uint32_t meta = prog_meta[o];
       const uint32_t kind = meta & 0xffu;
@@ -321,7 +385,7 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
       if (kind == OP_PROP) {
         const double dt = prog_dt[o];
         typename LM::S::Prop pr;
-        LM::S::make_prop(L.coef, dt, pr);
+        LM::S::make_prop(coef, dt, pr);
 #pragma unroll
         for (int j = 0; j < G; ++j) {
           LM::S::apply(pr, x[j], val[voff + j]);
@@ -330,37 +394,16 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
           if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
         }
       } else if (kind == OP_OBS) {
-        int out_state = 0;
-        double inv_vol = 1.0;
-#pragma unroll
-        for (int q = 0; q < PMX_MAX_OUT; ++q) {
-          if (q == io) {
-            out_state = m.out[q].state;
-            inv_vol = L.inv_vol[q];
-          }
+        int out_state = m.out[0].state;
+        double inv_vol = inv_vol0;
+        if (io != 0) {  // outputs beyond the first: rare, re-derive the volume instead of keeping 4 live
+          out_state = m.out[io].state;
+          const double v = (m.out[io].vol_src == PMX_SRC_PRIMARY) ? th[m.out[io].vol_index] : 1.0;
+          inv_vol = lane_good ? 1.0 / v : inv_vol0;
         }
-        double y[G];
-#pragma unroll
-        for (int j = 0; j < G; ++j) y[j] = 0.0;
-#pragma unroll
-        for (int st = 0; st < NS; ++st) {
-          if (out_state == st) {  // wave-uniform: no per-lane selects
-#pragma unroll
-            for (int j = 0; j < G; ++j) y[j] = x[j][st] * inv_vol;
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < G; ++j) acc[j] = fma(y[j], 0.0, acc[j]);
-        if (lane_ok) {
-          if (n_live == G) {
-#pragma unroll
-            for (int j = 0; j < G; ++j) (pred + (rbase[j] + kld))[p32] = y[j];  // wave-uniform row base + lane
-          } else {
-#pragma unroll
-            for (int j = 0; j < G; ++j)
-              if (j < n_live) (pred + (rbase[j] + kld))[p32] = y[j];
-          }
-        }
+        // wave-uniform: the state is picked by a scalar branch, not per-lane selects
+        classed_emit_state<0, G, NS>(out_state, x, inv_vol, rbase, kld, p_even, upper, pair_full, pair_half, any_half,
+                                     n_live, pred, bad);
         kld += ld;
       } else if (kind == OP_BOLUS) {
 #pragma unroll
@@ -371,18 +414,23 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
         }
       } else {  // OP_RESET
 #pragma unroll
-        for (int j = 0; j < G; ++j)
+        for (int i = 0; i < NS; ++i) {
+          double xi = 0.0;
+          if (io && m.has_init && m.init_param[i] >= 0) xi = th[m.init_param[i]];
 #pragma unroll
-          for (int i = 0; i < NS; ++i) x[j][i] = io ? L.xinit[i] : 0.0;
+          for (int j = 0; j < G; ++j) x[j][i] = xi;
+        }
       }
     }
-    if (status != nullptr && lane_ok) {
+    // status bytes: the library zeroes the array before the launch (PMX_PAIR_OK == 0); only failures are
+    // written here, so the healthy case issues no byte stores at all
+    if (status != nullptr && __any(((bad != 0u || !lane_good) && lane_ok) ? 1 : 0)) {
 #pragma unroll
       for (int j = 0; j < G; ++j) {
         if (j < n_live) {
           const int64_t sid = chunk_subj[c * G + j];
-          const uint8_t st = !L.ok ? PMX_PAIR_COMPLEX_ROOTS : ((acc[j] != acc[j]) ? PMX_PAIR_NONFINITE : PMX_PAIR_OK);
-          (status + sid * P)[p32] = st;
+          const uint8_t st = !lane_good ? PMX_PAIR_COMPLEX_ROOTS : (((bad >> j) & 1u) ? PMX_PAIR_NONFINITE : PMX_PAIR_OK);
+          if (lane_ok && st != PMX_PAIR_OK) status[sid * P + p] = st;
         }
       }
     }
@@ -452,7 +500,7 @@ __global__ __launch_bounds__(kBlock) void pmx_analytical_pair(DevModel m, DevOps
       if constexpr (DYN) st = st_lane;
     }
   }
-  if (status != nullptr && lane_ok) status[batch ? s : (s * P + p)] = st;
+  if (status != nullptr && lane_ok && st != PMX_PAIR_OK) status[batch ? s : (s * P + p)] = st;  // pre-zeroed
 }
 
 // ------------------------------------------------------------------------------------
@@ -657,7 +705,7 @@ __global__ __launch_bounds__(kBlock) void pmx_ode_rk4_grid(DevModel m, DevOps op
         for (int i = 0; i < NS; ++i) x[i] = io ? L.xinit[i] : 0.0;
       }
     }
-    if (status != nullptr && lane_ok) status[s * P + p] = st;
+    if (status != nullptr && lane_ok && st != PMX_PAIR_OK) status[s * P + p] = st;  // array pre-zeroed by the library
   }
 }
 
@@ -721,7 +769,7 @@ __global__ __launch_bounds__(kBlock) void pmx_ode_rk4_pair(DevModel m, DevOps op
       ++o;
     }
   }
-  if (status != nullptr && lane_ok) status[batch ? s : (s * P + p)] = st;
+  if (status != nullptr && lane_ok && st != PMX_PAIR_OK) status[batch ? s : (s * P + p)] = st;  // pre-zeroed
 }
 
 // ------------------------------------------------------------------------------------
@@ -743,7 +791,7 @@ hipError_t launch_analytical(const LaunchArgs& a, const char** name) {
         int64_t cpb = (a.cls.n_chunks * a.n_ptiles) / 8192;
         if (cpb < 1) cpb = 1;
         if (cpb > 8) cpb = 8;
-        const int64_t cblocks = (a.cls.n_chunks + cpb - 1) / cpb;
+        const int64_t cblocks = ((a.cls.n_chunks + cpb - 1) / cpb + 7) / 8 * 8;  // whole XCD groups
         hipLaunchKernelGGL((pmx_analytical_classed<KID>), dim3(static_cast<uint32_t>(cblocks * a.n_ptiles)), dim3(kBlock),
                            0, st, a.m, a.ops, a.cls, a.theta, a.P, static_cast<int32_t>(cpb), a.n_ptiles, a.pred, a.ld,
                            a.status);
