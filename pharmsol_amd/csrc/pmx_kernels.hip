@@ -257,17 +257,21 @@ struct ClassBatch {
 // Lanes 0-31 of a wave own the even support points of the wave's 64, lanes 32-63 the odd ones; one
 // v_permlane32_swap per dword turns (member A value, member B value) into (two adjacent doubles of A's
 // row | two adjacent doubles of B's row), so a pair of members leaves in ONE 16-byte store per lane.
+// `slot[h]` is this lane's 16-byte slot in the first prediction row of pair h (lower half-wave: member
+// 2h, upper half-wave: member 2h+1).  Non-finite predictions are caught with one FMA per value
+// (0*y is NaN iff y is inf/NaN) and resolved to members only in the rare wave that saw one.
 template <int ST, int G, int NS>
-__device__ __forceinline__ void classed_emit(const double (&x)[G][NS], double inv_vol, const int64_t (&rbase)[G],
-                                             int64_t kld, int64_t p_even, bool upper, bool pair_full, bool pair_half,
-                                             bool any_half, int32_t n_live, double* __restrict__ pred, uint32_t& bad) {
+__device__ __forceinline__ void classed_emit(const double (&x)[G][NS], double inv_vol, double* const (&slot)[G / 2],
+                                             int64_t kld, bool upper, bool pair_full, bool pair_half, bool any_half,
+                                             int32_t n_live, uint32_t& bad) {
+  double nanacc = 0.0;
 #pragma unroll
-  for (int j = 0; j < G; j += 2) {
-    if (j < n_live) {  // wave-uniform
-      const double ya = x[j][ST] * inv_vol;
-      const double yb = x[j + 1][ST] * inv_vol;
-      if (!isfinite(ya)) bad |= (1u << j);
-      if (!isfinite(yb)) bad |= (1u << (j + 1));
+  for (int h = 0; h < G / 2; ++h) {
+    if (2 * h < n_live) {  // wave-uniform
+      const double ya = x[2 * h][ST] * inv_vol;
+      const double yb = x[2 * h + 1][ST] * inv_vol;
+      nanacc = fma(ya, 0.0, nanacc);
+      nanacc = fma(yb, 0.0, nanacc);
       uint32_t alo = static_cast<uint32_t>(__double_as_longlong(ya));
       uint32_t ahi = static_cast<uint32_t>(static_cast<uint64_t>(__double_as_longlong(ya)) >> 32);
       uint32_t blo = static_cast<uint32_t>(__double_as_longlong(yb));
@@ -277,29 +281,30 @@ __device__ __forceinline__ void classed_emit(const double (&x)[G][NS], double in
       double2 v;
       v.x = __longlong_as_double(static_cast<int64_t>((static_cast<uint64_t>(r1[0]) << 32) | r0[0]));
       v.y = __longlong_as_double(static_cast<int64_t>((static_cast<uint64_t>(r1[1]) << 32) | r0[1]));
-      const bool row_live = upper ? (j + 1 < n_live) : true;
-      int64_t ra = rbase[j], rb = rbase[j + 1];
-      asm volatile("" : "+s"(ra), "+s"(rb));  // keep the two row bases in SGPRs: without this LLVM selects between
-                                              // their ADDRESSES and parks the (wave-uniform) array in LDS
-      const int64_t off = (upper ? rb : ra) + kld + p_even;
-      if (row_live && pair_full) *reinterpret_cast<double2*>(pred + off) = v;
+      const bool row_live = (2 * h + 1 < n_live) || !upper;  // the last pair of a partial chunk has no member B
+      double* dst = slot[h] + kld;
+      if (row_live && pair_full) *reinterpret_cast<double2*>(dst) = v;
       if (any_half) {  // wave-uniform: only the wave holding the last slot of an odd-length row
-        if (row_live && pair_half) pred[off] = v.x;
+        if (row_live && pair_half) *dst = v.x;
       }
     }
+  }
+  if (__any((nanacc != nanacc) ? 1 : 0)) {  // rare: find out which members
+#pragma unroll
+    for (int j = 0; j < G; ++j)
+      if (j < n_live && !isfinite(x[j][ST] * inv_vol)) bad |= (1u << j);
   }
 }
 
 template <int ST, int G, int NS>
 __device__ __forceinline__ void classed_emit_state(int out_state, const double (&x)[G][NS], double inv_vol,
-                                                   const int64_t (&rbase)[G], int64_t kld, int64_t p_even, bool upper,
-                                                   bool pair_full, bool pair_half, bool any_half, int32_t n_live,
-                                                   double* __restrict__ pred, uint32_t& bad) {
+                                                   double* const (&slot)[G / 2], int64_t kld, bool upper, bool pair_full,
+                                                   bool pair_half, bool any_half, int32_t n_live, uint32_t& bad) {
   if (out_state == ST) {
-    classed_emit<ST, G, NS>(x, inv_vol, rbase, kld, p_even, upper, pair_full, pair_half, any_half, n_live, pred, bad);
+    classed_emit<ST, G, NS>(x, inv_vol, slot, kld, upper, pair_full, pair_half, any_half, n_live, bad);
   } else if constexpr (ST + 1 < NS) {
-    classed_emit_state<ST + 1, G, NS>(out_state, x, inv_vol, rbase, kld, p_even, upper, pair_full, pair_half, any_half,
-                                      n_live, pred, bad);
+    classed_emit_state<ST + 1, G, NS>(out_state, x, inv_vol, slot, kld, upper, pair_full, pair_half, any_half, n_live,
+                                      bad);
   }
 }
 
@@ -366,11 +371,15 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
     const int64_t pb = cls_prog_off[cls];
     const int64_t pe = cls_prog_off[cls + 1];
     int64_t kld = 0;   // (observations emitted so far) * ld
-    int64_t rbase[G];  // element offset of each member's first prediction row (wave-uniform)
+    double* slot[G / 2];  // this lane's 16-byte slot in the first prediction row of each member pair
     {
       const auto rows = chunk_row + c * G;
 #pragma unroll
-      for (int j = 0; j < G; ++j) rbase[j] = rows[j] * ld;
+      for (int h = 0; h < G / 2; ++h) {
+        int64_t ra = rows[2 * h] * ld, rb = rows[2 * h + 1] * ld;
+        asm volatile("" : "+s"(ra), "+s"(rb));  // (keeps LLVM from selecting between the two ADDRESSES)
+        slot[h] = pred + ((upper ? rb : ra) + p_even);
+      }
     }
     double x[G][NS];
 #pragma unroll
@@ -402,8 +411,8 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
           inv_vol = lane_good ? 1.0 / v : inv_vol0;
         }
         // wave-uniform: the state is picked by a scalar branch, not per-lane selects
-        classed_emit_state<0, G, NS>(out_state, x, inv_vol, rbase, kld, p_even, upper, pair_full, pair_half, any_half,
-                                     n_live, pred, bad);
+        classed_emit_state<0, G, NS>(out_state, x, inv_vol, slot, kld, upper, pair_full, pair_half, any_half, n_live,
+                                     bad);
         kld += ld;
       } else if (kind == OP_BOLUS) {
 #pragma unroll
