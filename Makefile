@@ -34,3 +34,8 @@ clean:
 	rm -rf $(CSRC)/build pharmsol_amd/lib oracle/_build
 
 .PHONY: all oracle clean
+
+# C++ host-facade test binary (links the product library and, as the checker, the CPU oracle)
+tests/cpp/facade_test: tests/cpp/facade_test.cpp include/pharmsol_hip.hpp include/pmx.h $(LIB) oracle
+	g++ -O1 -std=c++17 -Wall -Wextra -o $@ tests/cpp/facade_test.cpp -Lpharmsol_amd/lib -lpmx_hip -Loracle/_build -lpmx_oracle \
+	    -Wl,-rpath,'$$ORIGIN/../../pharmsol_amd/lib' -Wl,-rpath,'$$ORIGIN/../../oracle/_build' -Wl,-rpath,/opt/rocm/lib
