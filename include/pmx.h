@@ -59,7 +59,8 @@ typedef enum pmx_status {
 enum {
   PMX_PAIR_OK = 0,
   PMX_PAIR_COMPLEX_ROOTS = 1, /* reference panics: two_compartment_models.rs:20-22, three_compartment_models.rs:32-34 */
-  PMX_PAIR_NONFINITE = 2      /* a prediction is NaN/inf (PharmsolError::NonFiniteLikelihood-style guard) */
+  PMX_PAIR_NONFINITE = 2,     /* a prediction is NaN/inf (PharmsolError::NonFiniteLikelihood-style guard) */
+  PMX_PAIR_BAD_LAG = 3        /* the support point gives a negative or NaN lag time: its predictions are NaN */
 };
 
 /* ---- events ---------------------------------------------------------------- */

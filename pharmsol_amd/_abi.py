@@ -33,6 +33,7 @@ PMX_ERR_PAIR_FAILED = 8
 PMX_PAIR_OK = 0
 PMX_PAIR_COMPLEX_ROOTS = 1
 PMX_PAIR_NONFINITE = 2
+PMX_PAIR_BAD_LAG = 3
 
 PMX_EV_OBSERVATION = 0
 PMX_EV_BOLUS = 1

@@ -202,10 +202,17 @@ int32_t pmx_model_create(const pmx_model_desc* d, pmx_model** out) {
       } else
         return fail(PMX_ERR_INVALID_ARGUMENT, "bind.src must be PRIMARY or DERIVED");
     }
-    for (int i = 0; i < PMX_MAX_INPUTS; ++i)
-      if (d->lag_param[i] >= 0 || d->fa_param[i] >= 0)
-        return fail(PMX_ERR_UNSUPPORTED,
-                    "lag / bioavailability (theta-dependent event rewrite, structs.rs:611-666) is not on the device path yet");
+    int n_lag = 0;
+    for (int i = 0; i < PMX_MAX_INPUTS; ++i) {
+      if (d->lag_param[i] >= d->nparams || d->fa_param[i] >= d->nparams)
+        return fail(PMX_ERR_INVALID_ARGUMENT, "lag_param / fa_param out of range");
+      if (d->lag_param[i] >= 0) ++n_lag;
+    }
+    if (n_lag > pmx::kMaxLagSlots)
+      return fail(PMX_ERR_UNSUPPORTED, "more than 4 lagged inputs are not supported on the device path");
+    if (n_lag > 0 && (m->dyn || pm))
+      return fail(PMX_ERR_UNSUPPORTED,
+                  "lag time together with covariate-derived rate constants or pm_* indexing is not on the device path yet");
   } else if (d->eq_kind == PMX_EQ_ODE) {
     if (ode_nstates(d->kernel) < 0) return fail(PMX_ERR_INVALID_ARGUMENT, "unknown ODE model");
     if (d->nstates < ode_nstates(d->kernel)) return fail(PMX_ERR_INVALID_ARGUMENT, "model has fewer states than its diffeq");
@@ -214,7 +221,8 @@ int32_t pmx_model_create(const pmx_model_desc* d, pmx_model** out) {
     if (d->n_derived > 0 || d->n_bind > 0 || pm)
       return fail(PMX_ERR_UNSUPPORTED, "derived parameters / pm indexing are not supported for ODE models yet");
     for (int i = 0; i < PMX_MAX_INPUTS; ++i) {
-      if (d->lag_param[i] >= 0 || d->fa_param[i] >= 0) return fail(PMX_ERR_UNSUPPORTED, "lag / bioavailability not on the device path yet");
+      if (d->lag_param[i] >= 0) return fail(PMX_ERR_UNSUPPORTED, "lag time is not on the device path for ODE models yet");
+      if (d->fa_param[i] >= d->nparams) return fail(PMX_ERR_INVALID_ARGUMENT, "fa_param out of range");
       if (d->bolus_dest[i] >= d->nstates || d->infusion_dest[i] >= d->nstates)
         return fail(PMX_ERR_INVALID_ARGUMENT, "route destination out of range");
     }
@@ -251,9 +259,14 @@ pmx::CompileKey key_for(const pmx_model* m) {
     k.n_rate = 1;
     k.rate_input = m->d.pmetrics_indexing ? 1 : 0;
     // classed fast path: theta-only coefficients, no covariates, plain indexing
+    bool has_fa = false;
+    for (int i = 0; i < PMX_MAX_INPUTS; ++i) {
+      if (m->d.lag_param[i] >= 0) k.lag_mask |= (1u << i);
+      if (m->d.fa_param[i] >= 0) has_fa = true;  // per-lane bolus amounts: the classed kernel's values are wave-uniform
+    }
     const char* off = std::getenv("PMX_DISABLE_CLASSING");
     const bool disabled = off && off[0] && off[0] != '0';
-    if (!disabled && !m->dyn && !m->d.pmetrics_indexing && m->d.n_covariates == 0) {
+    if (!disabled && !m->dyn && !m->d.pmetrics_indexing && m->d.n_covariates == 0 && k.lag_mask == 0 && !has_fa) {
       const int st = pmx::kernel_structure(m->d.kernel);
       k.class_g = (st == pmx::S_ONE || st == pmx::S_ONE_ABS || st == pmx::S_TWO) ? 8 : 4;  // == ClassBatch<KID>::G
     }
@@ -292,6 +305,11 @@ int32_t get_stream(pmx_population* pop, const pmx::CompileKey& key, DeviceStream
   if ((rc = upload(os.op_n, &ds->dev.op_n, &ds->allocs)) != PMX_OK) return rc;
   if ((rc = upload(os.op_rate, &ds->dev.op_rate, &ds->allocs)) != PMX_OK) return rc;
   if ((rc = upload(os.op_cov, &ds->dev.op_cov, &ds->allocs)) != PMX_OK) return rc;
+  if ((rc = upload(os.op_t0, &ds->dev.op_t0, &ds->allocs)) != PMX_OK) return rc;
+  if ((rc = upload(os.op_t1, &ds->dev.op_t1, &ds->allocs)) != PMX_OK) return rc;
+  if ((rc = upload(os.lagb_off, &ds->dev.lagb_off, &ds->allocs)) != PMX_OK) return rc;
+  if ((rc = upload(os.lagb_time, &ds->dev.lagb_time, &ds->allocs)) != PMX_OK) return rc;
+  if ((rc = upload(os.lagb_amount, &ds->dev.lagb_amount, &ds->allocs)) != PMX_OK) return rc;
   ds->dev.n_rate = key.n_rate;
   if (key.class_g > 0) {
     pmx::ClassPlan cp;
@@ -352,6 +370,15 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
   std::memcpy(a.m.init_param, d.init_param, sizeof(d.init_param));
   std::memcpy(a.m.bolus_dest, d.bolus_dest, sizeof(d.bolus_dest));
   std::memcpy(a.m.infusion_dest, d.infusion_dest, sizeof(d.infusion_dest));
+  std::memcpy(a.m.fa_param, d.fa_param, sizeof(d.fa_param));
+  for (int i = 0; i < PMX_MAX_INPUTS; ++i) {
+    if (d.fa_param[i] >= 0) a.m.has_fa = 1;
+    if (d.lag_param[i] >= 0 && a.m.n_lag_slots < pmx::kMaxLagSlots) {
+      a.m.lag_input[a.m.n_lag_slots] = i;
+      a.m.lag_param[a.m.n_lag_slots] = d.lag_param[i];
+      a.m.n_lag_slots++;
+    }
+  }
   a.ops = ds->dev;
   a.theta = d_theta;
   a.P = batch ? 1 : P;

@@ -183,7 +183,19 @@ int32_t compile_ops(const HostPopulation& hp, const CompileKey& key, OpStream* o
   os->op_n.clear();
   os->op_rate.clear();
   os->op_cov.clear();
+  os->op_t0.clear();
+  os->op_t1.clear();
+  os->lagb_off.clear();
+  os->lagb_time.clear();
+  os->lagb_amount.clear();
   os->n_prop = 0;
+  const uint32_t lag_mask = ode ? 0u : key.lag_mask;
+  int32_t slot_of_input[PMX_MAX_INPUTS];
+  int32_t n_slots = 0;
+  for (int i = 0; i < PMX_MAX_INPUTS; ++i) slot_of_input[i] = ((lag_mask >> i) & 1u) ? n_slots++ : -1;
+  os->n_lag_slots = n_slots;
+  std::vector<std::vector<std::pair<double, double>>> lagb(n_slots > 0 ? n_slots : 1);  // per slot, this occasion
+  if (n_slots > 0) os->lagb_off.push_back(0);
 
   std::vector<double> covv(nc > 0 ? nc : 1, 0.0);
   std::vector<double> rate(n_rate > 0 ? n_rate : 1, 0.0);
@@ -194,6 +206,10 @@ int32_t compile_ops(const HostPopulation& hp, const CompileKey& key, OpStream* o
     os->op_meta.push_back(make_meta(kind, io));
     os->op_a.push_back(a);
     os->op_b.push_back(b);
+    if (n_slots > 0) {
+      os->op_t0.push_back(0.0);
+      os->op_t1.push_back(0.0);
+    }
     if (ode) {
       os->op_n.push_back(n);
       for (int32_t r = 0; r < n_rate; ++r) os->op_rate.push_back(rates ? rates[r] : 0.0);
@@ -215,11 +231,38 @@ int32_t compile_ops(const HostPopulation& hp, const CompileKey& key, OpStream* o
     for (int64_t oc = hp.subj_occ_off[s]; oc < hp.subj_occ_off[s + 1]; ++oc) {
       const int64_t e0 = hp.occ_ev_off[oc], e1 = hp.occ_ev_off[oc + 1];
       // initial_state: zeros, init only for occasion index 0 (analytical/mod.rs:409-426)
-      push(OP_RESET, hp.occ_index[oc] == 0 ? 1u : 0u, 0.0, 0.0, 0, nullptr, oc, 0.0, false);
+      push(OP_RESET, hp.occ_index[oc] == 0 ? 1u : 0u, static_cast<double>(oc), 0.0, 0, nullptr, oc, 0.0, false);
+      const size_t reset_op = os->op_meta.size() - 1;
       inf.clear();
+      if (!ode && n_slots > 0) {
+        // Lagged boluses leave the event list (the device merges them at t + lag(theta)); what remains is
+        // walked exactly like before.  ev_keep = indices of the remaining events, still sorted.
+        for (auto& v : lagb) v.clear();
+        double t_first = std::numeric_limits<double>::infinity();
+        for (int64_t e = e0; e < e1; ++e) {
+          const bool lagged = hp.ev_kind[e] == PMX_EV_BOLUS && hp.ev_io[e] < PMX_MAX_INPUTS && slot_of_input[hp.ev_io[e]] >= 0;
+          if (lagged) {
+            max_input_used = std::max<int32_t>(max_input_used, hp.ev_io[e]);
+            lagb[slot_of_input[hp.ev_io[e]]].emplace_back(hp.ev_time[e], hp.ev_value[e]);
+          } else if (t_first == std::numeric_limits<double>::infinity()) {
+            t_first = hp.ev_time[e];
+          }
+        }
+        os->op_t0[reset_op] = t_first;
+        for (int32_t k = 0; k < n_slots; ++k) {
+          for (const auto& tb : lagb[k]) {
+            os->lagb_time.push_back(tb.first);
+            os->lagb_amount.push_back(tb.second);
+          }
+          os->lagb_off.push_back(static_cast<int64_t>(os->lagb_time.size()));
+        }
+      }
       if (!ode) {
+        int64_t prev = -1;  // previous event that stays in the list
         for (int64_t e = e0; e < e1; ++e) {  // simulate_event, equation/mod.rs:300-358
           const uint8_t k = hp.ev_kind[e];
+          if (n_slots > 0 && k == PMX_EV_BOLUS && hp.ev_io[e] < PMX_MAX_INPUTS && slot_of_input[hp.ev_io[e]] >= 0) continue;
+          (void)prev;
           if (k == PMX_EV_BOLUS) {
             max_input_used = std::max<int32_t>(max_input_used, hp.ev_io[e]);
             push(OP_BOLUS, hp.ev_io[e], hp.ev_value[e], 0.0, 0, nullptr, oc, 0.0, false);
@@ -228,8 +271,13 @@ int32_t compile_ops(const HostPopulation& hp, const CompileKey& key, OpStream* o
           } else {
             push(OP_OBS, hp.ev_io[e], hp.ev_time[e], 0.0, 0, nullptr, oc, hp.ev_time[e], true);
           }
-          if (e + 1 < e1) {  // Analytical::solve, analytical/mod.rs:299-370
-            const double ti = hp.ev_time[e], tf = hp.ev_time[e + 1];
+          int64_t en = e + 1;  // next event that stays in the list
+          if (n_slots > 0)
+            while (en < e1 && hp.ev_kind[en] == PMX_EV_BOLUS && hp.ev_io[en] < PMX_MAX_INPUTS &&
+                   slot_of_input[hp.ev_io[en]] >= 0)
+              ++en;
+          if (en < e1) {  // Analytical::solve, analytical/mod.rs:299-370
+            const double ti = hp.ev_time[e], tf = hp.ev_time[en];
             if (ti == tf) continue;  // :308-310
             ts.clear();
             ts.push_back(ti);
@@ -260,6 +308,10 @@ int32_t compile_ops(const HostPopulation& hp, const CompileKey& key, OpStream* o
               const double dt = nxt - cur;
               const double t_cov = key.cov_time_mode == PMX_COV_TIME_SEGMENT_END_ABS ? nxt : dt;
               push(OP_PROP, 0, dt, r0, 0, nullptr, oc, t_cov, true);
+              if (n_slots > 0) {
+                os->op_t0.back() = cur;
+                os->op_t1.back() = nxt;
+              }
               os->n_prop++;
               cur = nxt;
             }

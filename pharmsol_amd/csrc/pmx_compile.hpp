@@ -62,9 +62,11 @@ struct CompileKey {
   int32_t rate_input = 0;  // analytical: the input whose rate the closed form reads (1 under pm_* indexing,
                            // where rateiv slot 0 is a dead pad: analytical/mod.rs:86-88)
   int32_t class_g = 0;     // analytical GRID: members per chunk of the classed kernel (0 = no class plan)
+  uint32_t lag_mask = 0;   // bit i: boluses on input i are delayed by a theta-dependent lag -> kept OUT of the
+                           // op stream and merged per lane on the device (Occasion::add_lagtime, structs.rs:611-643)
   bool operator==(const CompileKey& o) const {
     return eq_kind == o.eq_kind && cov_time_mode == o.cov_time_mode && rk4_h_max == o.rk4_h_max &&
-           n_rate == o.n_rate && rate_input == o.rate_input && class_g == o.class_g;
+           n_rate == o.n_rate && rate_input == o.rate_input && class_g == o.class_g && lag_mask == o.lag_mask;
   }
 };
 
@@ -78,6 +80,13 @@ struct OpStream {
   std::vector<int32_t> op_n;         // ODE PROP: RK4 step count (empty for analytical)
   std::vector<double> op_rate;       // ODE: [n_ops * n_rate] rateiv per PROP (empty for analytical)
   std::vector<double> op_cov;        // [n_ops * n_cov] covariates seen by the op (empty if n_cov == 0)
+  // lag models only (key.lag_mask != 0):
+  std::vector<double> op_t0, op_t1;  // absolute [start, end] of every PROP; RESET: op_t0 = time of the occasion's
+                                     // first remaining event (+inf if none), op_a = global occasion index
+  int32_t n_lag_slots = 0;           // number of lagged inputs (slot k = k-th set bit of lag_mask)
+  std::vector<int64_t> lagb_off;     // [(n_occasions * n_lag_slots) + 1] lagged boluses per (occasion, slot)
+  std::vector<double> lagb_time;     // original (un-lagged) bolus time, sorted per (occasion, slot)
+  std::vector<double> lagb_amount;
   std::vector<int32_t> subj_order;   // subjects sorted by op count (desc), for the lane-per-pair kernels
   int32_t max_ops_per_subject = 0;
   int64_t n_prop = 0;

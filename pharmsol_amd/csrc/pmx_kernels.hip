@@ -171,10 +171,120 @@ __device__ __forceinline__ double lane_out(const DevModel& m, const LaneModel<KI
   return xs * inv;
 }
 
+
+// ------------------------------------------------------------------------------------
+// theta-dependent event rewrite on the device: lag time and bioavailability
+// (Occasion::add_lagtime / add_bioavailability, src/data/structs.rs:611-666).
+// Lagged boluses are NOT in the op stream; each lane merges them at t + lag(theta): a bolus that lands
+// inside a PROP [t0, t1) splits it exactly where the reference's re-sorted event list would
+// (solve(prev, tau), bolus, solve(tau, next)), a bolus that lands before the occasion's first remaining
+// event opens the occasion.  At equal times an observation precedes the bolus (event.rs:292-304): a
+// bolus landing exactly on an event time is applied at the START of the next PROP.
+// ------------------------------------------------------------------------------------
+struct LagState {
+  double lag[kMaxLagSlots];
+  int32_t cur[kMaxLagSlots];
+  int32_t end[kMaxLagSlots];
+};
+
+__device__ __forceinline__ double fa_of(const DevModel& m, const double* __restrict__ th, int input) {
+  double f = 1.0;
+  if (m.has_fa) {  // wave-uniform; models without bioavailability never enter
+    int fp = -1;
+#pragma unroll
+    for (int i = 0; i < PMX_MAX_INPUTS; ++i) fp = (i == input) ? m.fa_param[i] : fp;
+    if (fp >= 0) f = th[fp];
+  }
+  return f;
+}
+
+// earliest pending lagged bolus: returns its landing time (inf if none) and slot
+__device__ __forceinline__ double lag_next(const DevModel& m, const DevOps& ops, const LagState& ls, int& which) {
+  double tau = __longlong_as_double(0x7ff0000000000000LL);
+  which = -1;
+#pragma unroll
+  for (int k = 0; k < kMaxLagSlots; ++k) {
+    if (k < m.n_lag_slots && ls.cur[k] < ls.end[k]) {
+      const double tk = ops.lagb_time[ls.cur[k]] + ls.lag[k];
+      if (tk < tau) {
+        tau = tk;
+        which = k;
+      }
+    }
+  }
+  return tau;
+}
+
+template <int NS>
+__device__ __forceinline__ void lag_apply_bolus(const DevModel& m, const DevOps& ops, LagState& ls, int which,
+                                                const double* __restrict__ th, double (&x)[NS]) {
+  int32_t idx = 0;
+  int input = 0;
+#pragma unroll
+  for (int k = 0; k < kMaxLagSlots; ++k) {
+    if (k == which) {
+      idx = ls.cur[k];
+      input = m.lag_input[k];
+      ls.cur[k] += 1;
+    }
+  }
+  const double amt = ops.lagb_amount[idx] * fa_of(m, th, input);
+#pragma unroll
+  for (int i = 0; i < NS; ++i) x[i] += (i == input) ? amt : 0.0;
+}
+
+// RESET of a lag model: point the cursors at this occasion's lists and run the boluses that land before the
+// occasion's first remaining event (they become the first events of the re-sorted list).
+template <int ST, int NS>
+__device__ __forceinline__ void lag_open_occasion(const DevModel& m, const DevOps& ops, LagState& ls, int64_t occ,
+                                                  double t_first, const typename Structure<ST>::Coef& coef,
+                                                  const double* __restrict__ th, double (&x)[NS]) {
+#pragma unroll
+  for (int k = 0; k < kMaxLagSlots; ++k) {
+    if (k < m.n_lag_slots) {
+      ls.cur[k] = static_cast<int32_t>(ops.lagb_off[occ * m.n_lag_slots + k]);
+      ls.end[k] = static_cast<int32_t>(ops.lagb_off[occ * m.n_lag_slots + k + 1]);
+    } else {
+      ls.cur[k] = ls.end[k] = 0;
+    }
+  }
+  bool started = false;
+  double t = 0.0;
+  for (;;) {
+    int which;
+    const double tau = lag_next(m, ops, ls, which);
+    if (!(tau < t_first)) break;
+    if (started && tau > t) advance<ST>(coef, x, tau - t, 0.0);
+    t = tau;
+    started = true;
+    lag_apply_bolus<NS>(m, ops, ls, which, th, x);
+  }
+  if (started && t_first > t && t_first < __longlong_as_double(0x7ff0000000000000LL)) advance<ST>(coef, x, t_first - t, 0.0);
+}
+
+// PROP [t0, t1) of a lag model
+template <int ST, int NS>
+__device__ __forceinline__ void lag_prop(const DevModel& m, const DevOps& ops, LagState& ls, double t0, double t1, double r,
+                                         const typename Structure<ST>::Coef& coef, const double* __restrict__ th,
+                                         double (&x)[NS]) {
+  double t = t0;
+  for (;;) {
+    int which;
+    const double tau = lag_next(m, ops, ls, which);
+    if (!(tau < t1)) break;
+    if (tau > t) {
+      advance<ST>(coef, x, tau - t, r);
+      t = tau;
+    }
+    lag_apply_bolus<NS>(m, ops, ls, which, th, x);
+  }
+  if (t1 > t) advance<ST>(coef, x, t1 - t, r);
+}
+
 // ------------------------------------------------------------------------------------
 // GRID kernel (analytical)
 // ------------------------------------------------------------------------------------
-template <int KID, bool DYN>
+template <int KID, bool DYN, bool LAG>
 __global__ __launch_bounds__(kBlock) void pmx_analytical_grid(DevModel m, DevOps ops, const double* __restrict__ theta,
                                                               int64_t P, int64_t S, int32_t s_chunk, int32_t n_ptiles,
                                                               double* __restrict__ pred, int64_t ld,
@@ -192,7 +302,17 @@ __global__ __launch_bounds__(kBlock) void pmx_analytical_grid(DevModel m, DevOps
 
   LM L;
   lane_setup<KID, DYN>(m, th, L);
-  const uint8_t st_lane = L.ok ? PMX_PAIR_OK : PMX_PAIR_COMPLEX_ROOTS;
+  uint8_t st_lane0 = L.ok ? PMX_PAIR_OK : PMX_PAIR_COMPLEX_ROOTS;
+  LagState ls;
+  if constexpr (LAG) {
+#pragma unroll
+    for (int k = 0; k < kMaxLagSlots; ++k) {
+      ls.lag[k] = (k < m.n_lag_slots) ? th[m.lag_param[k]] : 0.0;
+      ls.cur[k] = ls.end[k] = 0;
+      if (k < m.n_lag_slots && !(ls.lag[k] >= 0.0) && st_lane0 == PMX_PAIR_OK) st_lane0 = PMX_PAIR_BAD_LAG;
+    }
+  }
+  const uint8_t st_lane = st_lane0;
   const double nanv = __longlong_as_double(0x7ff8000000000000LL);
 
   const int64_t s_begin = chunk * s_chunk;
@@ -218,24 +338,31 @@ __global__ __launch_bounds__(kBlock) void pmx_analytical_grid(DevModel m, DevOps
         if constexpr (DYN) {
           if (!lane_prepare_dyn<KID>(m, L, cov)) st = PMX_PAIR_COMPLEX_ROOTS;
         }
-        advance<LM::ST>(L.coef, x, a, r);
+        if constexpr (LAG) {
+          lag_prop<LM::ST, NS>(m, ops, ls, uniformf64(ops.op_t0[o]), uniformf64(ops.op_t1[o]), r, L.coef, th, x);
+        } else {
+          advance<LM::ST>(L.coef, x, a, r);
+        }
         xpad = 0.0;  // pm_* wrappers re-pad slot 0 with 0 after every kernel call (analytical/mod.rs:70-75)
       } else if (kind == OP_OBS) {
         double y = lane_out<KID>(m, L, x, xpad, io, cov);
-        if (st == PMX_PAIR_COMPLEX_ROOTS) y = nanv;
+        if (st == PMX_PAIR_COMPLEX_ROOTS || st == PMX_PAIR_BAD_LAG) y = nanv;
         if (st == PMX_PAIR_OK && !isfinite(y)) st = PMX_PAIR_NONFINITE;
         if (lane_ok) pred[row * ld + p] = y;
         ++row;
       } else if (kind == OP_BOLUS) {
         const int k = io - m.pm;
+        const double amt = a * fa_of(m, th, io);
 #pragma unroll
-        for (int i = 0; i < NS; ++i) x[i] += (i == k) ? a : 0.0;
-        if (m.pm && io == 0) xpad += a;
+        for (int i = 0; i < NS; ++i) x[i] += (i == k) ? amt : 0.0;
+        if (m.pm && io == 0) xpad += amt;
       } else {  // OP_RESET
 #pragma unroll
         for (int i = 0; i < NS; ++i) x[i] = io ? L.xinit[i] : 0.0;
         xpad = 0.0;
         if constexpr (DYN) st = st_lane;  // a new occasion re-derives its coefficients
+        if constexpr (LAG)
+          lag_open_occasion<LM::ST, NS>(m, ops, ls, static_cast<int64_t>(a), uniformf64(ops.op_t0[o]), L.coef, th, x);
       }
     }
     if (status != nullptr && lane_ok && st != PMX_PAIR_OK) status[s * P + p] = st;  // array pre-zeroed by the library
@@ -417,7 +544,7 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
       } else if (kind == OP_BOLUS) {
 #pragma unroll
         for (int j = 0; j < G; ++j) {
-          const double a = val[voff + j];
+          const double a = val[voff + j];  // (models with bioavailability are never classed: pmx_api.cpp key_for)
 #pragma unroll
           for (int i = 0; i < NS; ++i) x[j][i] += (i == io) ? a : 0.0;
         }
@@ -449,7 +576,7 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
 // ------------------------------------------------------------------------------------
 // PAIR kernel (analytical): lane = (subject, support point), divergent schedules
 // ------------------------------------------------------------------------------------
-template <int KID, bool DYN>
+template <int KID, bool DYN, bool LAG>
 __global__ __launch_bounds__(kBlock) void pmx_analytical_pair(DevModel m, DevOps ops, const double* __restrict__ theta,
                                                               int64_t P, int64_t S, int32_t batch,
                                                               double* __restrict__ pred, int64_t ld,
@@ -466,7 +593,17 @@ __global__ __launch_bounds__(kBlock) void pmx_analytical_pair(DevModel m, DevOps
 
   LM L;
   lane_setup<KID, DYN>(m, th, L);
-  const uint8_t st_lane = L.ok ? PMX_PAIR_OK : PMX_PAIR_COMPLEX_ROOTS;
+  uint8_t st_lane0 = L.ok ? PMX_PAIR_OK : PMX_PAIR_COMPLEX_ROOTS;
+  LagState ls;
+  if constexpr (LAG) {
+#pragma unroll
+    for (int k = 0; k < kMaxLagSlots; ++k) {
+      ls.lag[k] = (k < m.n_lag_slots) ? th[m.lag_param[k]] : 0.0;
+      ls.cur[k] = ls.end[k] = 0;
+      if (k < m.n_lag_slots && !(ls.lag[k] >= 0.0) && st_lane0 == PMX_PAIR_OK) st_lane0 = PMX_PAIR_BAD_LAG;
+    }
+  }
+  const uint8_t st_lane = st_lane0;
   const double nanv = __longlong_as_double(0x7ff8000000000000LL);
 
   int64_t o = ops.subj_op_off[s];
@@ -489,24 +626,30 @@ __global__ __launch_bounds__(kBlock) void pmx_analytical_pair(DevModel m, DevOps
       if constexpr (DYN) {
         if (!lane_prepare_dyn<KID>(m, L, cov)) st = PMX_PAIR_COMPLEX_ROOTS;
       }
-      advance<LM::ST>(L.coef, x, a, r);
+      if constexpr (LAG) {
+        lag_prop<LM::ST, NS>(m, ops, ls, ops.op_t0[o], ops.op_t1[o], r, L.coef, th, x);
+      } else {
+        advance<LM::ST>(L.coef, x, a, r);
+      }
       xpad = 0.0;
     } else if (kind == OP_OBS) {
       double y = lane_out<KID>(m, L, x, xpad, io, cov);
-      if (st == PMX_PAIR_COMPLEX_ROOTS) y = nanv;
+      if (st == PMX_PAIR_COMPLEX_ROOTS || st == PMX_PAIR_BAD_LAG) y = nanv;
       if (st == PMX_PAIR_OK && !isfinite(y)) st = PMX_PAIR_NONFINITE;
       pred[row * ld + p] = y;
       ++row;
     } else if (kind == OP_BOLUS) {
       const int k = io - m.pm;
+      const double amt = a * fa_of(m, th, io);
 #pragma unroll
-      for (int j = 0; j < NS; ++j) x[j] += (j == k) ? a : 0.0;
-      if (m.pm && io == 0) xpad += a;
+      for (int j = 0; j < NS; ++j) x[j] += (j == k) ? amt : 0.0;
+      if (m.pm && io == 0) xpad += amt;
     } else {
 #pragma unroll
       for (int j = 0; j < NS; ++j) x[j] = io ? L.xinit[j] : 0.0;
       xpad = 0.0;
       if constexpr (DYN) st = st_lane;
+      if constexpr (LAG) lag_open_occasion<LM::ST, NS>(m, ops, ls, static_cast<int64_t>(a), ops.op_t0[o], L.coef, th, x);
     }
   }
   if (status != nullptr && lane_ok && st != PMX_PAIR_OK) status[batch ? s : (s * P + p)] = st;  // pre-zeroed
@@ -707,8 +850,9 @@ __global__ __launch_bounds__(kBlock) void pmx_ode_rk4_grid(DevModel m, DevOps op
         ++row;
       } else if (kind == OP_BOLUS) {
         const int dest = (m.bolus_dest[io] >= 0) ? m.bolus_dest[io] : io;
+        const double amt = a * fa_of(m, theta + pc * m.nparams, io);
 #pragma unroll
-        for (int i = 0; i < NS; ++i) x[i] += (i == dest) ? a : 0.0;
+        for (int i = 0; i < NS; ++i) x[i] += (i == dest) ? amt : 0.0;
       } else {
 #pragma unroll
         for (int i = 0; i < NS; ++i) x[i] = io ? L.xinit[i] : 0.0;
@@ -769,8 +913,9 @@ __global__ __launch_bounds__(kBlock) void pmx_ode_rk4_pair(DevModel m, DevOps op
         ++row;
       } else if (kind == OP_BOLUS) {
         const int dest = (m.bolus_dest[io] >= 0) ? m.bolus_dest[io] : io;
+        const double amt = a * fa_of(m, theta + (batch ? s : p) * m.nparams, io);
 #pragma unroll
-        for (int j = 0; j < NS; ++j) x[j] += (j == dest) ? a : 0.0;
+        for (int j = 0; j < NS; ++j) x[j] += (j == dest) ? amt : 0.0;
       } else {
 #pragma unroll
         for (int j = 0; j < NS; ++j) x[j] = io ? L.xinit[j] : 0.0;
@@ -784,16 +929,16 @@ __global__ __launch_bounds__(kBlock) void pmx_ode_rk4_pair(DevModel m, DevOps op
 // ------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------
-template <int KID, bool DYN>
+template <int KID, bool DYN, bool LAG>
 hipError_t launch_analytical(const LaunchArgs& a, const char** name) {
-  static const char* const kNameGrid = DYN ? "pmx_analytical_grid<dyn>" : "pmx_analytical_grid";
-  static const char* const kNamePair = DYN ? "pmx_analytical_pair<dyn>" : "pmx_analytical_pair";
+  static const char* const kNameGrid = DYN ? "pmx_analytical_grid<dyn>" : (LAG ? "pmx_analytical_grid<lag>" : "pmx_analytical_grid");
+  static const char* const kNamePair = DYN ? "pmx_analytical_pair<dyn>" : (LAG ? "pmx_analytical_pair<lag>" : "pmx_analytical_pair");
   hipStream_t st = static_cast<hipStream_t>(a.stream);
   if (a.mode == MODE_GRID) {
     int64_t n_walk = a.S;
     const int32_t* list = nullptr;
     *name = kNameGrid;
-    if constexpr (!DYN) {
+    if constexpr (!DYN && !LAG) {
       if (a.use_classes && a.cls.n_chunks > 0) {
         *name = "pmx_analytical_classed";
         // enough blocks to fill the chip several times over, few enough that lane_setup stays amortised
@@ -818,13 +963,13 @@ hipError_t launch_analytical(const LaunchArgs& a, const char** name) {
     }
     const int64_t n_chunks = (n_walk + s_chunk - 1) / s_chunk;
     const int64_t blocks = n_chunks * a.n_ptiles;
-    hipLaunchKernelGGL((pmx_analytical_grid<KID, DYN>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlock), 0, st, a.m,
+    hipLaunchKernelGGL((pmx_analytical_grid<KID, DYN, LAG>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlock), 0, st, a.m,
                        a.ops, a.theta, a.P, n_walk, s_chunk, a.n_ptiles, a.pred, a.ld, a.status, list);
   } else {
     *name = kNamePair;
     const int64_t n_pairs = a.batch ? a.S : a.S * a.P;
     const int64_t blocks = (n_pairs + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL((pmx_analytical_pair<KID, DYN>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlock), 0, st, a.m,
+    hipLaunchKernelGGL((pmx_analytical_pair<KID, DYN, LAG>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlock), 0, st, a.m,
                        a.ops, a.theta, a.P, a.S, a.batch, a.pred, a.ld, a.status);
   }
   return hipGetLastError();
@@ -851,7 +996,8 @@ hipError_t launch_ode(const LaunchArgs& a, const char** name) {
 
 template <int KID>
 hipError_t launch_analytical_k(const LaunchArgs& a, const char** name) {
-  return a.dyn ? launch_analytical<KID, true>(a, name) : launch_analytical<KID, false>(a, name);
+  if (a.m.n_lag_slots > 0) return launch_analytical<KID, false, true>(a, name);  // (lag + covariate-derived constants is rejected at model_create)
+  return a.dyn ? launch_analytical<KID, true, false>(a, name) : launch_analytical<KID, false, false>(a, name);
 }
 
 }  // namespace

@@ -22,7 +22,13 @@ struct DevModel {
   int32_t init_param[PMX_MAX_STATES];
   int32_t bolus_dest[PMX_MAX_INPUTS];
   int32_t infusion_dest[PMX_MAX_INPUTS];
+  int32_t fa_param[PMX_MAX_INPUTS];   // bioavailability: amount *= theta[fa_param[input]]  (structs.rs:645-666)
+  int32_t n_lag_slots;                // lagged inputs (<= kMaxLagSlots)
+  int32_t has_fa;
+  int32_t lag_input[4];               // slot -> input
+  int32_t lag_param[4];               // slot -> theta index of the lag time
 };
+constexpr int kMaxLagSlots = 4;
 
 // Device mirror of an OpStream (all pointers are device pointers).
 struct DevOps {
@@ -35,6 +41,11 @@ struct DevOps {
   const int32_t* op_n;          // [n_ops] (ODE)
   const double* op_rate;        // [n_ops*n_rate] (ODE)
   const double* op_cov;         // [n_ops*n_cov]
+  const double* op_t0;          // lag models: absolute start of each PROP / first event time of a RESET's occasion
+  const double* op_t1;          // lag models: absolute end of each PROP
+  const int64_t* lagb_off;      // [(n_occasions*n_lag_slots)+1]
+  const double* lagb_time;
+  const double* lagb_amount;
   int32_t n_rate;
   int32_t pad_;
 };

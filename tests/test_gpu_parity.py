@@ -225,6 +225,79 @@ def test_init_and_multiple_occasions():
                                rtol=1e-12)
 
 
+def _lag_subjects(rng, n, two_inputs=False):
+    subs = []
+    for i in range(n):
+        b = Subject.builder(f"lag{i}")
+        n_occ = 1 + int(rng.integers(0, 2))
+        for occ in range(n_occ):
+            if occ:
+                b = b.reset()
+            for _ in range(int(rng.integers(1, 4))):
+                b = b.bolus(float(np.round(rng.uniform(0, 24), 1)), float(rng.uniform(50, 300)),
+                            int(rng.integers(0, 2)) if two_inputs else 0)
+            if rng.random() < 0.5:
+                b = b.infusion(float(np.round(rng.uniform(0, 12), 1)), float(rng.uniform(50, 300)), 1 if two_inputs else 0,
+                               float(np.round(rng.uniform(0.5, 4), 1)))
+            for _ in range(int(rng.integers(2, 9))):
+                # times on a 0.5 grid: a lagged bolus regularly lands EXACTLY on an observation / dose time
+                b = b.missing_observation(float(np.round(rng.uniform(0, 36) * 2) / 2), 0)
+        subs.append(b.build())
+    subs.append(Subject.builder("early").bolus(0.0, 100.0, 0).missing_observation(2.0, 0).missing_observation(4.0, 0).build())
+    subs.append(Subject.builder("late").missing_observation(1.0, 0).bolus(3.0, 100.0, 0).missing_observation(3.2, 0).build())
+    return subs
+
+
+@pytest.mark.parametrize("n_support,batch", [(70, False), (3, False), (0, True)])
+def test_lag_time_and_bioavailability(n_support, batch):
+    """structs.rs:611-666 on the device: the bolus is re-timed per support point (lag), then scaled (fa).  Lags on a
+    0.5 grid make boluses land exactly on observation times (observation first, event.rs:292-304), cross other
+    doses and infusion boundaries, fall before the first event of an occasion and after its last one."""
+    rng = np.random.default_rng(77)
+    m = Analytical.new("one_compartment_with_absorption", {0: Ratio(1, 2)}, nparams=5, lag={0: 3}, fa={0: 4}).with_nstates(
+        2).with_ndrugs(1).with_nout(1)
+    subs = _lag_subjects(rng, 60)
+    flat = m.flatten(Data(subs))
+    n = len(subs) if batch else n_support
+    th = np.stack([rng.uniform(1.0, 2.0, n), rng.uniform(0.05, 0.3, n), rng.uniform(10, 50, n),
+                   np.round(rng.uniform(0, 3, n) * 2) / 2, rng.uniform(0.3, 1.0, n)], axis=1)
+    th[0, 3] = 0.0  # zero lag: the bolus keeps its place (structs.rs:631)
+    kernel = "pmx_analytical_pair<lag>" if (batch or n_support < 32) else "pmx_analytical_grid<lag>"
+    assert_parity(m, flat, th, TOL_ANALYTICAL, batch=batch, expect_kernel=kernel)
+
+
+def test_two_lagged_inputs_with_different_lags():
+    rng = np.random.default_rng(78)
+    m = Analytical.new("two_compartments", {0: Ratio(0, 3)}, nparams=6, lag={0: 4, 1: 5}).with_nstates(2).with_ndrugs(
+        2).with_nout(1)
+    flat = m.flatten(Data(_lag_subjects(rng, 40, two_inputs=True)))
+    th = np.concatenate([synth.theta_c3(64), rng.uniform(0, 2.5, (64, 2))], axis=1)
+    assert_parity(m, flat, th, TOL_ANALYTICAL, expect_kernel="pmx_analytical_grid<lag>")
+
+
+def test_bioavailability_alone_and_on_ode():
+    from pharmsol_amd import ODE
+
+    rng = np.random.default_rng(79)
+    subs = _lag_subjects(rng, 30)
+    m = Analytical.new("one_compartment", {0: Ratio(0, 1)}, nparams=3, fa={0: 2}).with_nstates(1).with_ndrugs(1).with_nout(1)
+    th = np.stack([rng.uniform(0.05, 0.5, 40), rng.uniform(5, 50, 40), rng.uniform(0.2, 1.0, 40)], axis=1)
+    assert_parity(m, m.flatten(Data(subs)), th, TOL_ANALYTICAL, expect_kernel="pmx_analytical_grid")
+    mo = ODE.new("one_cmt_iv", {0: Ratio(0, 1)}, nparams=3, h_max=0.01).with_nstates(1).with_ndrugs(1).with_nout(1)
+    mo.fa = {"0": 2}
+    assert_parity(mo, mo.flatten(Data(subs)), th, TOL_ODE, expect_kernel="pmx_ode_rk4_grid")
+
+
+def test_negative_lag_is_flagged():
+    m = Analytical.new("one_compartment", {0: Ratio(0, 1)}, nparams=3, lag={0: 2}).with_nstates(1).with_ndrugs(1).with_nout(1)
+    s = Subject.builder("neg").bolus(1.0, 10.0, 0).missing_observation(2.0, 0).build()
+    th = np.array([[0.1, 5.0, 0.5]] * 40)
+    th[7, 2] = -0.25
+    got, st = gpu_predict(m, m.flatten(s), th)
+    assert st[0, 7] == _abi.PMX_PAIR_BAD_LAG and np.isnan(got[0, 7])
+    assert (np.delete(st, 7, axis=1) == 0).all() and np.isfinite(np.delete(got, 7, axis=1)).all()
+
+
 def test_pmetrics_one_based_wrappers():
     # pm_* kernels: state/rateiv slot 0 is a dead pad (analytical/mod.rs:62-90)
     m = Analytical.new("pm_two_compartments", {0: Ratio(1, 3)}, nparams=4).with_nstates(3).with_ndrugs(2).with_nout(1)

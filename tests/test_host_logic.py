@@ -145,6 +145,17 @@ def test_ode_op_stream_pieces_and_step_counts():
     np.testing.assert_allclose(ops["b"][prop] * n, ops["a"][prop], rtol=1e-15)
 
 
+def test_lagged_boluses_leave_the_op_stream():
+    # structs.rs:611-643: a lagged bolus is re-timed per support point, so it cannot sit in the shared stream
+    m = Analytical.new("one_compartment", {0: Ratio(0, 1)}, nparams=3, lag={0: 2}).with_nstates(1).with_ndrugs(2).with_nout(1)
+    s = (Subject.builder("lag").bolus(0.0, 100.0, 0).bolus(0.0, 7.0, 1).missing_observation(0.5, 0)
+         .missing_observation(2.0, 0).build())
+    ops = runtime.compile_ops(m, m.flatten(s))
+    bol = ops["kind"] == _abi.PMX_OP_BOLUS
+    assert bol.sum() == 1 and ops["io"][bol][0] == 1 and ops["a"][bol][0] == 7.0  # only the un-lagged input stays
+    assert ops["max_input_used"] == 1
+
+
 def test_pair_kernel_lane_order_sorts_subjects_by_work():
     m, flat, theta = synth.config_c4(200)
     ops = runtime.compile_ops(m, flat)
@@ -183,7 +194,15 @@ def test_model_validation_errors():
     assert create(d) == _abi.PMX_ERR_INVALID_ARGUMENT
     d = models.handwritten_analytical("two_compartments", 0, 4).desc()
     d.lag_param[0] = 1
-    assert create(d) == _abi.PMX_ERR_UNSUPPORTED  # theta-dependent event rewrite: not on the device path yet
+    assert create(d) == _abi.PMX_OK  # lag time: merged per lane on the device
+    d.lag_param[1] = 9
+    assert create(d) == _abi.PMX_ERR_INVALID_ARGUMENT
+    d = models.readme_analytical().desc()  # covariate-derived rate constant + lag: not on the device path yet
+    d.lag_param[0] = 0
+    assert create(d) == _abi.PMX_ERR_UNSUPPORTED
+    d = models.handwritten_ode("one_cmt_iv", 0, 2).desc()
+    d.lag_param[0] = 1
+    assert create(d) == _abi.PMX_ERR_UNSUPPORTED
     d = models.handwritten_ode("one_cmt_iv", 0, 2).desc()
     d.rk4_h_max = 0.0
     assert create(d) == _abi.PMX_ERR_INVALID_ARGUMENT
