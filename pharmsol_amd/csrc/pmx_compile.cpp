@@ -470,10 +470,32 @@ void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, i
       continue;
     }
     const int64_t r0 = os.subj_op_off[cls_rep[c]], r1 = os.subj_op_off[cls_rep[c] + 1];
-    const int64_t L = r1 - r0;
+    // Program steps: every OBS op is FUSED into the step before it (bit 24 = "emit a row after this step",
+    // bits 25.. = its outeq), so a PROP+OBS pair costs one trip of the device loop.  A second observation
+    // at the same instant gets a step of its own (kind OP_OBS = no state change).
+    std::vector<int32_t> step_of_op(static_cast<size_t>(r1 - r0), -1);
+    std::vector<uint32_t> step_meta;
+    std::vector<double> step_dt;
     for (int64_t o = r0; o < r1; ++o) {
-      cp->prog_meta.push_back(os.op_meta[o]);
-      cp->prog_dt.push_back((os.op_meta[o] & 0xffu) == OP_PROP ? os.op_a[o] : 0.0);
+      const uint32_t kind = os.op_meta[o] & 0xffu;
+      const uint32_t io = (os.op_meta[o] >> 8) & 0xffffu;
+      if (kind == OP_OBS) {
+        if (!step_meta.empty() && ((step_meta.back() >> 24) & 1u) == 0u) {
+          step_meta.back() |= (1u << 24) | (io << 25);
+        } else {
+          step_meta.push_back(make_meta(OP_OBS, 0) | (1u << 24) | (io << 25));
+          step_dt.push_back(0.0);
+        }
+      } else {
+        step_meta.push_back(make_meta(kind, io));
+        step_dt.push_back(kind == OP_PROP ? os.op_a[o] : 0.0);
+        step_of_op[static_cast<size_t>(o - r0)] = static_cast<int32_t>(step_meta.size()) - 1;
+      }
+    }
+    const int64_t L = static_cast<int64_t>(step_meta.size());
+    for (int64_t i = 0; i < L; ++i) {
+      cp->prog_meta.push_back(step_meta[static_cast<size_t>(i)]);
+      cp->prog_dt.push_back(step_dt[static_cast<size_t>(i)]);
     }
     cp->cls_prog_off.push_back(static_cast<int64_t>(cp->prog_meta.size()));
     for (size_t m0 = 0; m0 < mem.size(); m0 += G) {
@@ -489,12 +511,14 @@ void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, i
       cp->val.resize(base + static_cast<size_t>(L) * G, 0.0);
       for (int32_t j = 0; j < n; ++j) {
         const int64_t s0 = os.subj_op_off[mem[m0 + j]];
-        for (int64_t i = 0; i < L; ++i) {
+        for (int64_t i = 0; i < r1 - r0; ++i) {
+          const int32_t st = step_of_op[static_cast<size_t>(i)];
+          if (st < 0) continue;
           const uint32_t kind = os.op_meta[s0 + i] & 0xffu;
           double v = 0.0;
           if (kind == OP_BOLUS) v = os.op_a[s0 + i];
           if (kind == OP_PROP) v = os.op_b[s0 + i];
-          cp->val[base + static_cast<size_t>(i) * G + j] = v;
+          cp->val[base + static_cast<size_t>(st) * G + j] = v;
         }
       }
       cp->n_classed_subjects += n;

@@ -106,7 +106,7 @@ struct ClassPlan {
   int32_t G = 0;                       // members per chunk (register batch of the classed kernel)
   int64_t n_chunks = 0;
   int64_t n_classed_subjects = 0;
-  std::vector<uint32_t> prog_meta;     // concatenated class programs: kind | io<<8
+  std::vector<uint32_t> prog_meta;     // concatenated class programs: kind | io<<8 | obs_after<<24 | outeq<<25
   std::vector<double> prog_dt;         // PROP: dt
   std::vector<int64_t> cls_prog_off;   // [n_classes+1]
   std::vector<int32_t> chunk_cls;      // [n_chunks]

@@ -529,18 +529,6 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
           // every member at once: +2*NS*G registers, one wave per SIMD less)
           if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
         }
-      } else if (kind == OP_OBS) {
-        int out_state = m.out[0].state;
-        double inv_vol = inv_vol0;
-        if (io != 0) {  // outputs beyond the first: rare, re-derive the volume instead of keeping 4 live
-          out_state = m.out[io].state;
-          const double v = (m.out[io].vol_src == PMX_SRC_PRIMARY) ? th[m.out[io].vol_index] : 1.0;
-          inv_vol = lane_good ? 1.0 / v : inv_vol0;
-        }
-        // wave-uniform: the state is picked by a scalar branch, not per-lane selects
-        classed_emit_state<0, G, NS>(out_state, x, inv_vol, slot, kld, upper, pair_full, pair_half, any_half, n_live,
-                                     bad);
-        kld += ld;
       } else if (kind == OP_BOLUS) {
 #pragma unroll
         for (int j = 0; j < G; ++j) {
@@ -548,7 +536,7 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
 #pragma unroll
           for (int i = 0; i < NS; ++i) x[j][i] += (i == io) ? a : 0.0;
         }
-      } else {  // OP_RESET
+      } else if (kind == OP_RESET) {
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
           double xi = 0.0;
@@ -556,6 +544,20 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
 #pragma unroll
           for (int j = 0; j < G; ++j) x[j][i] = xi;
         }
+      }  // (kind == OP_OBS: a second observation at the same instant, no state change)
+      if ((meta >> 24) & 1u) {  // the observation fused into this step (pmx_compile.cpp build_class_plan)
+        const int oq = static_cast<int>(meta >> 25);
+        int out_state = m.out[0].state;
+        double inv_vol = inv_vol0;
+        if (oq != 0) {  // outputs beyond the first: rare, re-derive the volume instead of keeping 4 live
+          out_state = m.out[oq].state;
+          const double v = (m.out[oq].vol_src == PMX_SRC_PRIMARY) ? th[m.out[oq].vol_index] : 1.0;
+          inv_vol = lane_good ? 1.0 / v : inv_vol0;
+        }
+        // wave-uniform: the state is picked by a scalar branch, not per-lane selects
+        classed_emit_state<0, G, NS>(out_state, x, inv_vol, slot, kld, upper, pair_full, pair_half, any_half, n_live,
+                                     bad);
+        kld += ld;
       }
     }
     // status bytes: the library zeroes the array before the launch (PMX_PAIR_OK == 0); only failures are
