@@ -52,6 +52,14 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make`).  pharmsol_amd has no CPU fallback.")
+        # PyTorch bundles its own libamdhip64 (same SONAME as /opt/rocm's).  If libpmx_hip.so were loaded
+        # first, the process would end up with TWO HIP runtimes and torch would see no GPU; loading torch
+        # first makes the dynamic loader hand torch's runtime to this library too, so device pointers and
+        # streams are shared.  (Pure C/C++ clients link /opt/rocm's runtime and never meet torch.)
+        try:
+            import torch  # noqa: F401
+        except ImportError:  # the C ABI itself does not need torch
+            pass
         L = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(L, name)  # AttributeError if the symbol is not exported
