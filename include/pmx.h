@@ -50,6 +50,7 @@ typedef enum pmx_status {
   PMX_ERR_NO_DEVICE = 5,           /* no HIP device / kernel image: the library never falls back to a CPU path */
   PMX_ERR_HIP = 6,                 /* a HIP runtime call failed (message has the hipError string) */
   PMX_ERR_OUT_OF_MEMORY = 7,
+  PMX_ERR_ERROR_MODEL = 9,         /* ErrorModelError: MissingErrorModel / NegativeSigma / NonFiniteSigma (error_model.rs:1045-1080) */
   PMX_ERR_PAIR_FAILED = 8          /* at least one (subject, support point) pair failed; see the status array.
                                       Mirrors log_likelihood_matrix aborting on the first error (matrix.rs:83,104);
                                       predictions of the healthy pairs are still written. */
@@ -265,6 +266,37 @@ int32_t pmx_predict_batch(const pmx_model* model, const pmx_population* pop, con
                           uint8_t* status);
 int32_t pmx_predict_batch_device(const pmx_model* model, const pmx_population* pop, const double* d_theta,
                                  double* d_pred, uint8_t* d_status, void* stream);
+
+/* ---- fused log-likelihood ----------------------------------------------
+ * log_likelihood_matrix(eq, &Data, &theta, &AssayErrorModels, progress) (likelihood/matrix.rs:52-106):
+ *   ll[s][p] = sum over the subject's observations that carry a value of
+ *              lognormpdf(obs, pred, sigma) = -0.5*ln(2 pi) - ln(sigma) - (obs-pred)^2 / (2 sigma^2)
+ *              (likelihood/distributions.rs:31-34; SubjectPredictions::log_likelihood, subject.rs:63-78;
+ *               missing observations contribute 0, prediction.rs:105-111)
+ * sigma comes from the OBSERVATION through the assay error polynomial of its output equation
+ * (AssayErrorModel::sigma, src/data/error_model.rs:1045-1080):
+ *   alpha = c0 + c1 y + c2 y^2 + c3 y^3;  additive: sqrt(alpha^2 + lambda^2);  proportional: gamma * alpha
+ * It does not depend on the support point, so the library evaluates it once per observation on the host;
+ * the device folds each prediction into its subject's sum instead of storing it (output S x P doubles
+ * instead of S x O x P).  Censored observations (BLOQ/ALOQ) are not in the flattened descriptor yet. */
+enum { PMX_EM_NONE = 0, PMX_EM_ADDITIVE = 1, PMX_EM_PROPORTIONAL = 2 };
+typedef struct pmx_error_model {
+  int32_t kind;   /* PMX_EM_* ; NONE + an observation on that outeq = MissingErrorModel error */
+  int32_t reserved;
+  double c[4];    /* ErrorPoly c0..c3 */
+  double scalar;  /* lambda (additive) | gamma (proportional) */
+} pmx_error_model;
+
+/*   em   [model.nout] error model per output equation
+ *   ll   [n_subjects x ld_ll], ll[s*ld_ll + p]  (the reference's Array2 (n_subjects, n_support); it stores
+ *        that matrix column-major, matrix.rs:60 — same logical matrix, support point fastest here)
+ *   status [n_subjects x n_support] as for pmx_predict; a non-finite sum sets PMX_PAIR_NONFINITE
+ *        (PharmsolError::NonFiniteLikelihood, prediction.rs:119-124) */
+int32_t pmx_loglik(const pmx_model* model, const pmx_population* pop, const pmx_error_model* em,
+                   const double* theta, int64_t n_support, double* ll, int64_t ld_ll, uint8_t* status);
+int32_t pmx_loglik_device(const pmx_model* model, const pmx_population* pop, const pmx_error_model* em,
+                          const double* d_theta, int64_t n_support, double* d_ll, int64_t ld_ll,
+                          uint8_t* d_status, void* stream);
 
 /* Name of the device kernel family the last pmx_predict* call on this thread launched
  * (for matching rocprofv3 rows). */

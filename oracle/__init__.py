@@ -52,6 +52,13 @@ def lib():
         L.pmx_oracle_cov_interpolate.restype = C.c_int32
         L.pmx_oracle_cov_interpolate.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_double,
                                                  C.POINTER(C.c_double)]
+        L.pmx_oracle_loglik.restype = C.c_int32
+        L.pmx_oracle_loglik.argtypes = [C.POINTER(_abi.pmx_model_desc), C.POINTER(_abi.pmx_population_desc),
+                                        C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32]
+        L.pmx_oracle_sigma.restype = C.c_int32
+        L.pmx_oracle_sigma.argtypes = [C.POINTER(_abi.pmx_error_model), C.c_double, C.POINTER(C.c_double)]
+        L.pmx_oracle_lognormpdf.restype = C.c_double
+        L.pmx_oracle_lognormpdf.argtypes = [C.c_double, C.c_double, C.c_double]
         L.pmx_oracle_last_error.restype = C.c_char_p
         L.pmx_oracle_max_threads.restype = C.c_int32
         L.pmx_oracle_sizeof_model_desc.restype = C.c_int64
@@ -129,3 +136,39 @@ def cov_interpolate(knots_t, knots_v, t: float, fixed: bool = False) -> float:
     if rc != 0:
         raise _abi.PmxError(rc, "MissingSegments")
     return v.value
+
+
+def loglik(model, flat, error_models, theta: np.ndarray, nthreads: int = 0, allow_pair_failures: bool = True
+           ) -> Tuple[np.ndarray, np.ndarray]:
+    """Oracle twin of ``pmx_loglik``: returns ``(ll[S, P], status[S, P])``."""
+    L = lib()
+    theta = np.ascontiguousarray(theta, dtype=np.float64)
+    if theta.ndim == 1:
+        theta = theta.reshape(1, -1)
+    md = _model_desc(model)
+    P = theta.shape[0]
+    pd = flat.desc()
+    em = error_models.to_c(model)
+    ll = np.full((flat.n_subjects, P), np.nan, dtype=np.float64)
+    status = np.zeros((flat.n_subjects, P), dtype=np.uint8)
+    rc = L.pmx_oracle_loglik(C.byref(md), C.byref(pd), C.cast(em, C.c_void_p), theta.ctypes.data, P, ll.ctypes.data, P,
+                             status.ctypes.data, nthreads)
+    if rc != _abi.PMX_OK and not (rc == _abi.PMX_ERR_PAIR_FAILED and allow_pair_failures):
+        raise _abi.PmxError(rc, L.pmx_oracle_last_error().decode())
+    return ll, status
+
+
+def sigma(em, observation: float) -> float:
+    """``AssayErrorModel::sigma`` for one observed value (em: pharmsol_amd.error_model.AssayErrorModel)."""
+    c = _abi.pmx_error_model()
+    c.kind, c.scalar = em.kind, em.scalar
+    c.c[0], c.c[1], c.c[2], c.c[3] = em.poly.c0, em.poly.c1, em.poly.c2, em.poly.c3
+    out = C.c_double()
+    rc = lib().pmx_oracle_sigma(C.byref(c), float(observation), C.byref(out))
+    if rc != 0:
+        raise _abi.PmxError(rc, "ErrorModelError")
+    return out.value
+
+
+def lognormpdf(obs: float, pred: float, sigma_: float) -> float:
+    return float(lib().pmx_oracle_lognormpdf(float(obs), float(pred), float(sigma_)))

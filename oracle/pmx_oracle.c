@@ -1061,5 +1061,124 @@ int32_t pmx_oracle_predict_batch(const pmx_model_desc* model, const pmx_populati
   return PMX_OK;
 }
 
+/* ------------------------------------------------------------------------- */
+/* log-likelihood: likelihood/{distributions,prediction,subject,matrix}.rs      */
+/* ------------------------------------------------------------------------- */
+#define PMX_LOG_2PI 1.8378770664093453 /* distributions.rs:12 */
+
+/* lognormpdf, distributions.rs:31-34 */
+double pmx_oracle_lognormpdf(double obs, double pred, double sigma) {
+  double diff = obs - pred;
+  return -0.5 * PMX_LOG_2PI - log(sigma) - (diff * diff) / (2.0 * sigma * sigma);
+}
+
+/* AssayErrorModel::sigma, error_model.rs:1045-1080 */
+int32_t pmx_oracle_sigma(const pmx_error_model* em, double y, double* sigma) {
+  double alpha = em->c[0] + em->c[1] * y + em->c[2] * (y * y) + em->c[3] * (y * y * y);
+  double s;
+  if (em->kind == PMX_EM_ADDITIVE)
+    s = sqrt(alpha * alpha + em->scalar * em->scalar);
+  else if (em->kind == PMX_EM_PROPORTIONAL)
+    s = em->scalar * alpha;
+  else
+    return PMX_ERR_ERROR_MODEL; /* MissingErrorModel */
+  if (s < 0.0) return PMX_ERR_ERROR_MODEL;   /* NegativeSigma */
+  if (!isfinite(s)) return PMX_ERR_ERROR_MODEL; /* NonFiniteSigma */
+  *sigma = s;
+  return PMX_OK;
+}
+
+int32_t pmx_oracle_loglik(const pmx_model_desc* model, const pmx_population_desc* pop, const pmx_error_model* em,
+                          const double* theta, int64_t n_support, double* ll, int64_t ld_ll, uint8_t* status,
+                          int32_t nthreads) {
+  g_err[0] = 0;
+  int rc = validate(model, pop);
+  if (rc) return rc;
+  if (ld_ll < n_support) FAIL(PMX_ERR_INVALID_ARGUMENT, "ld_ll < n_support");
+  int64_t* off = obs_offsets(pop);
+  int64_t n_obs = off[pop->n_subjects];
+  /* observation values / outeqs in prediction order (occasions are sorted like simulate does) */
+  double* yv = (double*)malloc(sizeof(double) * (size_t)(n_obs + 1));
+  int* oq = (int*)malloc(sizeof(int) * (size_t)(n_obs + 1));
+  {
+    scratch_t sc;
+    scratch_init(&sc, pop);
+    int64_t row = 0;
+    for (int64_t oc = 0; oc < pop->n_occasions; oc++) {
+      int64_t e0 = pop->occ_ev_off[oc], n = pop->occ_ev_off[oc + 1] - e0;
+      for (int64_t i = 0; i < n; i++) {
+        sc.ev[i].time = pop->ev_time[e0 + i];
+        sc.ev[i].value = pop->ev_value[e0 + i];
+        sc.ev[i].kind = pop->ev_kind[e0 + i];
+        sc.ev[i].io = pop->ev_io[e0 + i];
+      }
+      if (!pop->presorted) ev_sort(sc.ev, n);
+      for (int64_t i = 0; i < n; i++)
+        if (sc.ev[i].kind == PMX_EV_OBSERVATION) {
+          yv[row] = sc.ev[i].value;
+          oq[row] = sc.ev[i].io;
+          row++;
+        }
+    }
+    scratch_free(&sc);
+  }
+  int failed = PMX_OK, any_pair_failed = 0;
+#ifdef _OPENMP
+  if (nthreads <= 0) nthreads = omp_get_max_threads();
+#else
+  nthreads = 1;
+#endif
+#pragma omp parallel num_threads(nthreads)
+  {
+    scratch_t sc;
+    scratch_init(&sc, pop);
+    int64_t max_rows = 1;
+    for (int64_t s = 0; s < pop->n_subjects; s++)
+      if (off[s + 1] - off[s] > max_rows) max_rows = off[s + 1] - off[s];
+    double* pr = (double*)malloc(sizeof(double) * (size_t)max_rows);
+#pragma omp for schedule(dynamic)
+    for (int64_t s = 0; s < pop->n_subjects; s++) {
+      sc.cov = subject_cov(pop, s);
+      for (int64_t p = 0; p < n_support; p++) { /* estimate_log_likelihood_dense, equation/mod.rs:468-477 */
+        uint8_t st = 0;
+        int r = simulate_pair(model, pop, s, theta + p * model->nparams, pr, 1, &st, &sc);
+        double total = 0.0; /* SubjectPredictions::log_likelihood, subject.rs:63-78 */
+        for (int64_t k = 0; k < off[s + 1] - off[s] && r == PMX_OK; k++) {
+          double y = yv[off[s] + k];
+          if (isnan(y)) continue; /* observation is None: contributes 0, prediction.rs:107-111 */
+          int q = oq[off[s] + k];
+          double sigma;
+          if (q >= model->nout || pmx_oracle_sigma(&em[q], y, &sigma) != PMX_OK) {
+            r = PMX_ERR_ERROR_MODEL;
+            break;
+          }
+          total += pmx_oracle_lognormpdf(y, pr[k], sigma);
+        }
+        if (st == PMX_PAIR_OK && !isfinite(total)) st = PMX_PAIR_NONFINITE; /* NonFiniteLikelihood, prediction.rs:119-124 */
+        if (st == PMX_PAIR_COMPLEX_ROOTS) total = NAN;
+        ll[s * ld_ll + p] = total;
+        if (status) status[s * n_support + p] = st;
+        if (st) {
+#pragma omp atomic write
+          any_pair_failed = 1;
+        }
+        if (r != PMX_OK) {
+#pragma omp atomic write
+          failed = r;
+        }
+      }
+      subject_cov_free(pop, s, sc.cov);
+    }
+    free(pr);
+    scratch_free(&sc);
+  }
+  free(off);
+  free(yv);
+  free(oq);
+  if (failed != PMX_OK) FAIL(failed, "log-likelihood failed with status %d", failed);
+  if (any_pair_failed) FAIL(PMX_ERR_PAIR_FAILED, "at least one (subject, support point) pair failed");
+  return PMX_OK;
+}
+
 int64_t pmx_oracle_sizeof_model_desc(void) { return (int64_t)sizeof(pmx_model_desc); }
 int64_t pmx_oracle_sizeof_population_desc(void) { return (int64_t)sizeof(pmx_population_desc); }

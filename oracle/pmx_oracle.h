@@ -43,6 +43,16 @@ int32_t pmx_oracle_predict(const pmx_model_desc* model, const pmx_population_des
 int32_t pmx_oracle_predict_batch(const pmx_model_desc* model, const pmx_population_desc* pop, const double* theta,
                                  double* pred, uint8_t* status, int32_t nthreads);
 
+/* Same contract as pmx_loglik (include/pmx.h): estimate_log_likelihood_dense per (subject, support point)
+ * (equation/mod.rs:468-477) in the loop nest of log_likelihood_matrix (matrix.rs:79-98). */
+int32_t pmx_oracle_loglik(const pmx_model_desc* model, const pmx_population_desc* pop, const pmx_error_model* em,
+                          const double* theta, int64_t n_support, double* ll, int64_t ld_ll, uint8_t* status,
+                          int32_t nthreads);
+/* AssayErrorModel::sigma for an observed value (error_model.rs:1045-1080); returns PMX_OK or PMX_ERR_ERROR_MODEL. */
+int32_t pmx_oracle_sigma(const pmx_error_model* em, double observation, double* sigma);
+/* lognormpdf (likelihood/distributions.rs:31-34) */
+double pmx_oracle_lognormpdf(double obs, double pred, double sigma);
+
 /* One call of a closed-form kernel: xout = kernel(x, p, t, rateiv)
  * (AnalyticalEq, src/simulator/mod.rs:54).  pm != 0 selects the pm_* wrapper
  * (analytical/mod.rs:78-90).  Returns 0, or PMX_PAIR_COMPLEX_ROOTS. */

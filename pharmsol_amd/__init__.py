@@ -10,6 +10,7 @@ test infrastructure only).
 from .data import Bolus, Covariates, Data, Event, Infusion, Observation, Occasion, Subject, SubjectBuilder
 from .equation import (ODE, Analytical, Equation, LabelError, Lin, Pow, Ratio, Route, Scaled, analytical, bolus,
                        infusion, ode)
+from .error_model import AssayErrorModel, AssayErrorModels, ErrorPoly
 from .flatten import FlatPopulation, flatten
 from .parameters import Parameters
 from .predictions import Prediction, SubjectPredictions
@@ -18,5 +19,5 @@ from ._abi import PmxError
 __all__ = [
     "Bolus", "Covariates", "Data", "Event", "Infusion", "Observation", "Occasion", "Subject", "SubjectBuilder",
     "ODE", "Analytical", "Equation", "LabelError", "Lin", "Pow", "Ratio", "Route", "Scaled", "analytical", "bolus",
-    "infusion", "ode", "FlatPopulation", "flatten", "Parameters", "Prediction", "SubjectPredictions", "PmxError",
+    "infusion", "ode", "AssayErrorModel", "AssayErrorModels", "ErrorPoly", "FlatPopulation", "flatten", "Parameters", "Prediction", "SubjectPredictions", "PmxError",
 ]

@@ -29,6 +29,7 @@ PMX_ERR_NO_DEVICE = 5
 PMX_ERR_HIP = 6
 PMX_ERR_OUT_OF_MEMORY = 7
 PMX_ERR_PAIR_FAILED = 8
+PMX_ERR_ERROR_MODEL = 9
 
 PMX_PAIR_OK = 0
 PMX_PAIR_COMPLEX_ROOTS = 1
@@ -125,6 +126,7 @@ STATUS_NAMES = {
     PMX_ERR_HIP: "HipError",
     PMX_ERR_OUT_OF_MEMORY: "OutOfMemory",
     PMX_ERR_PAIR_FAILED: "PairFailed",
+    PMX_ERR_ERROR_MODEL: "ErrorModelError",
 }
 
 
@@ -189,6 +191,13 @@ class pmx_model_desc(C.Structure):
         ("infusion_dest", C.c_int32 * PMX_MAX_INPUTS),
         ("rk4_h_max", C.c_double),
     ]
+
+
+PMX_EM_NONE, PMX_EM_ADDITIVE, PMX_EM_PROPORTIONAL = 0, 1, 2
+
+
+class pmx_error_model(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("c", C.c_double * 4), ("scalar", C.c_double)]
 
 
 class pmx_op_stream_view(C.Structure):

@@ -37,6 +37,10 @@ SYMBOLS = [
      [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     ("pmx_predict_batch", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("pmx_predict_batch_device", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("pmx_loglik", C.c_int32,
+     [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+    ("pmx_loglik_device", C.c_int32,
+     [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     ("pmx_last_kernel_name", C.c_char_p, []),
     ("pmx_last_error", C.c_char_p, []),
     ("pmx_debug_compile", C.c_int32, [_PD, _MD, C.POINTER(_abi.pmx_op_stream_view)]),

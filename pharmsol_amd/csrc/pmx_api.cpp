@@ -58,6 +58,18 @@ struct DeviceStream {
   pmx::DevOps dev{};
   pmx::DevClassPlan cls{};
   int64_t n_classed_subjects = 0;
+  // host copies for the log-likelihood's per-chunk observation blocks
+  std::vector<int64_t> h_chunk_row;      // [n_chunks*G]
+  std::vector<int32_t> h_chunk_nobs;     // [n_chunks] observations per member of the chunk's class
+  std::vector<int32_t> h_chunk_n;        // [n_chunks] live members
+  // per error-model cache of the sigma terms (they depend on (population, error model) only)
+  struct LLCache {
+    std::vector<pmx_error_model> em;
+    const double* d_obs = nullptr;        // [n_obs][4]
+    const double* d_cobs = nullptr;       // classed blocks
+    const int64_t* d_chunk_obs_off = nullptr;
+  };
+  std::vector<LLCache> ll_cache;
   std::vector<void*> allocs;
   int32_t max_input_used = -1;
   int64_t n_ops = 0, n_prop = 0;
@@ -325,6 +337,15 @@ int32_t get_stream(pmx_population* pop, const pmx::CompileKey& key, DeviceStream
       if ((rc = upload(cp.chunk_row, &ds->cls.chunk_row, &ds->allocs)) != PMX_OK) return rc;
       if ((rc = upload(cp.val, &ds->cls.val, &ds->allocs)) != PMX_OK) return rc;
       if ((rc = upload(cp.generic_subjects, &ds->cls.generic_subjects, &ds->allocs)) != PMX_OK) return rc;
+      ds->h_chunk_row = cp.chunk_row;
+      ds->h_chunk_n = cp.chunk_n;
+      ds->h_chunk_nobs.resize(static_cast<size_t>(cp.n_chunks));
+      for (int64_t c = 0; c < cp.n_chunks; ++c) {
+        const int32_t cl = cp.chunk_cls[static_cast<size_t>(c)];
+        int32_t nobs = 0;
+        for (int64_t o = cp.cls_prog_off[cl]; o < cp.cls_prog_off[cl + 1]; ++o) nobs += (cp.prog_meta[static_cast<size_t>(o)] >> 24) & 1u;
+        ds->h_chunk_nobs[static_cast<size_t>(c)] = nobs;
+      }
       ds->cls.n_chunks = cp.n_chunks;
       ds->cls.n_generic = static_cast<int64_t>(cp.generic_subjects.size());
       ds->cls.G = cp.G;
@@ -336,8 +357,83 @@ int32_t get_stream(pmx_population* pop, const pmx::CompileKey& key, DeviceStream
   return PMX_OK;
 }
 
+// Sigma terms of every observation for one error-model set (AssayErrorModel::sigma, error_model.rs:1045-1080;
+// lognormpdf's sigma-only parts, distributions.rs:31-34), cached per (population flavour, error models).
+int32_t get_ll_cache(const pmx_model* model, pmx_population* pop, DeviceStream* ds, const pmx_error_model* em,
+                     const DeviceStream::LLCache** out) {
+  constexpr double kLog2Pi = 1.8378770664093453;  // distributions.rs:12
+  const int nout = model->d.nout;
+  std::lock_guard<std::mutex> lock(pop->mu);
+  for (const auto& c : ds->ll_cache)
+    if (static_cast<int>(c.em.size()) == nout && std::memcmp(c.em.data(), em, sizeof(pmx_error_model) * nout) == 0) {
+      *out = &c;
+      return PMX_OK;
+    }
+  const auto& hp = pop->hp;
+  std::vector<double> obs4(static_cast<size_t>(hp.n_obs) * 4, 0.0);
+  for (int64_t r = 0; r < hp.n_obs; ++r) {
+    const double y = hp.obs_value[static_cast<size_t>(r)];
+    if (std::isnan(y)) continue;  // observation is None: weight 0
+    const int q = hp.obs_outeq[static_cast<size_t>(r)];
+    if (q >= nout) return fail(PMX_ERR_OUTEQ_OUT_OF_RANGE, "observation outeq >= nout");
+    const pmx_error_model& e = em[q];
+    const double alpha = e.c[0] + e.c[1] * y + e.c[2] * (y * y) + e.c[3] * (y * y * y);
+    double sigma;
+    if (e.kind == PMX_EM_ADDITIVE) sigma = std::sqrt(alpha * alpha + e.scalar * e.scalar);
+    else if (e.kind == PMX_EM_PROPORTIONAL) sigma = e.scalar * alpha;
+    else return fail(PMX_ERR_ERROR_MODEL, "MissingErrorModel: output " + std::to_string(q) + " has observations but no error model");
+    if (sigma < 0.0) return fail(PMX_ERR_ERROR_MODEL, "NegativeSigma");
+    if (!std::isfinite(sigma)) return fail(PMX_ERR_ERROR_MODEL, "NonFiniteSigma");
+    obs4[static_cast<size_t>(r) * 4 + 0] = y;
+    obs4[static_cast<size_t>(r) * 4 + 1] = -0.5 * kLog2Pi - std::log(sigma);
+    obs4[static_cast<size_t>(r) * 4 + 2] = 1.0 / (2.0 * sigma * sigma);
+  }
+  DeviceStream::LLCache c;
+  c.em.assign(em, em + nout);
+  int32_t rc;
+  if ((rc = upload(obs4, &c.d_obs, &ds->allocs)) != PMX_OK) return rc;
+  if (ds->cls.n_chunks > 0) {  // classed blocks: per chunk [observation k][value | const | weight][G]
+    const int G = ds->cls.G;
+    std::vector<int64_t> off(static_cast<size_t>(ds->cls.n_chunks));
+    std::vector<double> cobs;
+    for (int64_t ch = 0; ch < ds->cls.n_chunks; ++ch) {
+      off[static_cast<size_t>(ch)] = static_cast<int64_t>(cobs.size());
+      const int32_t nobs = ds->h_chunk_nobs[static_cast<size_t>(ch)];
+      const size_t base = cobs.size();
+      cobs.resize(base + static_cast<size_t>(nobs) * 3 * G, 0.0);
+      for (int j = 0; j < G; ++j) {
+        const int64_t row0 = ds->h_chunk_row[static_cast<size_t>(ch * G + j)];
+        // padding members have row 0 and must stay weight 0: recognise them through chunk_n at launch time instead
+        for (int32_t k = 0; k < nobs; ++k) {
+          const size_t r = static_cast<size_t>(row0 + k);
+          for (int f = 0; f < 3; ++f) cobs[base + (static_cast<size_t>(k) * 3 + f) * G + j] = obs4[r * 4 + f];
+        }
+      }
+    }
+    // zero the padding members (they alias row 0)
+    {
+      const std::vector<int32_t>& n_live = ds->h_chunk_n;
+      for (int64_t ch = 0; ch < ds->cls.n_chunks; ++ch)
+        for (int j = n_live[static_cast<size_t>(ch)]; j < G; ++j)
+          for (int32_t k = 0; k < ds->h_chunk_nobs[static_cast<size_t>(ch)]; ++k)
+            for (int f = 0; f < 3; ++f) cobs[static_cast<size_t>(off[static_cast<size_t>(ch)]) + (static_cast<size_t>(k) * 3 + f) * G + j] = 0.0;
+    }
+    if ((rc = upload(cobs, &c.d_cobs, &ds->allocs)) != PMX_OK) return rc;
+    if ((rc = upload(off, &c.d_chunk_obs_off, &ds->allocs)) != PMX_OK) return rc;
+  }
+  ds->ll_cache.push_back(std::move(c));
+  *out = &ds->ll_cache.back();
+  return PMX_OK;
+}
+
+struct LLRequest {
+  const pmx_error_model* em = nullptr;
+  double* d_ll = nullptr;
+  int64_t ld = 0;
+};
+
 int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_theta, int64_t P, int batch,
-                double* d_pred, int64_t ld, uint8_t* d_status, void* stream) {
+                double* d_pred, int64_t ld, uint8_t* d_status, void* stream, const LLRequest* llreq = nullptr) {
   const pmx_model_desc& d = model->d;
   if (d.n_covariates != pop->hp.n_cov)
     return fail(PMX_ERR_INVALID_ARGUMENT, "model declares " + std::to_string(d.n_covariates) +
@@ -352,7 +448,7 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
   if (pop->hp.max_outeq >= d.nout)
     return fail(PMX_ERR_OUTEQ_OUT_OF_RANGE,
                 "outeq " + std::to_string(pop->hp.max_outeq) + " >= nout " + std::to_string(d.nout));
-  if (pop->hp.n_subjects == 0 || (pop->hp.n_obs == 0 && d_status == nullptr)) return PMX_OK;
+  if (pop->hp.n_subjects == 0) return PMX_OK;
 
   pmx::LaunchArgs a{};
   a.m.eq_kind = d.eq_kind;
@@ -391,6 +487,16 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
   a.stream = stream;
   a.cls = ds->cls;
   a.use_classes = ds->cls.n_chunks > 0 ? 1 : 0;
+  if (llreq != nullptr) {
+    const DeviceStream::LLCache* lc = nullptr;
+    rc = get_ll_cache(model, pop, ds, llreq->em, &lc);
+    if (rc != PMX_OK) return rc;
+    a.ops.ll_obs = lc->d_obs;
+    a.ops.ll_out = llreq->d_ll;
+    a.ops.ll_ld = llreq->ld;
+    a.cls.cobs = lc->d_cobs;
+    a.cls.chunk_obs_off = lc->d_chunk_obs_off;
+  }
   if (!batch && P >= 32) {
     a.mode = pmx::MODE_GRID;
     a.n_ptiles = static_cast<int32_t>((P + 255) / 256);
@@ -548,6 +654,64 @@ void pmx_debug_free(pmx_op_stream_view* view) {
   if (!view || !view->owner) return;
   delete static_cast<DebugOwner*>(view->owner);
   std::memset(view, 0, sizeof(*view));
+}
+
+}  // extern "C"
+
+// ---- fused log-likelihood -------------------------------------------------------------------------
+extern "C" {
+
+int32_t pmx_loglik_device(const pmx_model* model, const pmx_population* cpop, const pmx_error_model* em,
+                          const double* d_theta, int64_t n_support, double* d_ll, int64_t ld_ll, uint8_t* d_status,
+                          void* stream) {
+  g_err.clear();
+  if (!model || !cpop || !em || !d_theta || !d_ll) return fail(PMX_ERR_INVALID_ARGUMENT, "null argument");
+  if (n_support <= 0 || ld_ll < n_support) return fail(PMX_ERR_INVALID_ARGUMENT, "n_support must be > 0 and ld_ll >= n_support");
+  pmx_population* pop = const_cast<pmx_population*>(cpop);
+  DeviceGuard g;
+  PMX_HIP(g.enter(pop->device));
+  LLRequest req{em, d_ll, ld_ll};
+  // pred is not written in log-likelihood mode; pass the ll buffer as a non-null placeholder
+  return enqueue(model, pop, d_theta, n_support, 0, d_ll, ld_ll, d_status, stream, &req);
+}
+
+int32_t pmx_loglik(const pmx_model* model, const pmx_population* cpop, const pmx_error_model* em, const double* theta,
+                   int64_t n_support, double* ll, int64_t ld_ll, uint8_t* status) {
+  g_err.clear();
+  if (!model || !cpop || !em || !theta || !ll) return fail(PMX_ERR_INVALID_ARGUMENT, "null argument");
+  if (n_support <= 0 || ld_ll < n_support) return fail(PMX_ERR_INVALID_ARGUMENT, "n_support must be > 0 and ld_ll >= n_support");
+  pmx_population* pop = const_cast<pmx_population*>(cpop);
+  const int64_t S = pop->hp.n_subjects;
+  DeviceGuard g;
+  PMX_HIP(g.enter(pop->device));
+  double *d_theta = nullptr, *d_ll = nullptr;
+  uint8_t* d_status = nullptr;
+  struct Free {
+    void** p;
+    ~Free() {
+      if (*p) (void)hipFree(*p);
+    }
+  };
+  Free f1{reinterpret_cast<void**>(&d_theta)}, f2{reinterpret_cast<void**>(&d_ll)}, f3{reinterpret_cast<void**>(&d_status)};
+  const size_t theta_bytes = static_cast<size_t>(n_support) * model->d.nparams * sizeof(double);
+  const size_t ll_bytes = static_cast<size_t>(S) * ld_ll * sizeof(double);
+  const size_t st_bytes = static_cast<size_t>(S) * n_support;
+  PMX_HIP(hipMalloc(reinterpret_cast<void**>(&d_theta), theta_bytes > 0 ? theta_bytes : 8));
+  PMX_HIP(hipMalloc(reinterpret_cast<void**>(&d_ll), ll_bytes > 0 ? ll_bytes : 8));
+  PMX_HIP(hipMalloc(reinterpret_cast<void**>(&d_status), st_bytes > 0 ? st_bytes : 8));
+  PMX_HIP(hipMemcpy(d_theta, theta, theta_bytes, hipMemcpyHostToDevice));
+  PMX_HIP(hipMemcpy(d_ll, ll, ll_bytes, hipMemcpyHostToDevice));  // keeps the caller's padding columns
+  LLRequest req{em, d_ll, ld_ll};
+  int32_t rc = enqueue(model, pop, d_theta, n_support, 0, d_ll, ld_ll, d_status, nullptr, &req);
+  if (rc != PMX_OK) return rc;
+  PMX_HIP(hipDeviceSynchronize());
+  PMX_HIP(hipMemcpy(ll, d_ll, ll_bytes, hipMemcpyDeviceToHost));
+  std::vector<uint8_t> hst(st_bytes);
+  PMX_HIP(hipMemcpy(hst.data(), d_status, st_bytes, hipMemcpyDeviceToHost));
+  if (status) std::memcpy(status, hst.data(), hst.size());
+  for (uint8_t s : hst)
+    if (s != PMX_PAIR_OK) return fail(PMX_ERR_PAIR_FAILED, "at least one (subject, support point) pair failed; see the status array");
+  return PMX_OK;
 }
 
 }  // extern "C"

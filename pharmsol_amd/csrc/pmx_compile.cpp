@@ -120,6 +120,7 @@ int32_t build_host_population(const pmx_population_desc* d, HostPopulation* hp, 
     for (int64_t e = e0; e < e1; ++e)
       if (hp->ev_kind[e] == PMX_EV_OBSERVATION) {
         hp->obs_time.push_back(hp->ev_time[e]);
+        hp->obs_value.push_back(hp->ev_value[e]);
         hp->obs_outeq.push_back(hp->ev_io[e]);
         hp->obs_subject.push_back(s);
       }

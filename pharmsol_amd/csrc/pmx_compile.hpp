@@ -41,6 +41,7 @@ struct HostPopulation {
   std::vector<int64_t> subj_obs_off;  // [S+1]
   // observation bookkeeping in prediction order
   std::vector<double> obs_time;
+  std::vector<double> obs_value;   // observed value (NaN = missing), for the log-likelihood
   std::vector<int32_t> obs_outeq;
   std::vector<int64_t> obs_subject;
   int32_t max_outeq = -1;  // over all observations (range check vs model.nout)

@@ -281,6 +281,18 @@ __device__ __forceinline__ void lag_prop(const DevModel& m, const DevOps& ops, L
   if (t1 > t) advance<ST>(coef, x, t1 - t, r);
 }
 
+
+// One observation in log-likelihood mode: acc += lognormpdf(obs, y, sigma) with the sigma-only parts
+// precomputed on the host (likelihood/distributions.rs:31-34; sigma from the observation,
+// error_model.rs:1045-1080).  `q` = {obs, -0.5 ln(2 pi) - ln sigma, 1/(2 sigma^2), -}.
+__device__ __forceinline__ void ll_accumulate(const double* __restrict__ q, double y, double& acc) {
+  const double w = q[2];
+  if (w != 0.0) {  // weight 0 = missing observation: contributes 0 whatever the prediction (prediction.rs:107-111)
+    const double d = q[0] - y;
+    acc += q[1] - (d * d) * w;
+  }
+}
+
 // ------------------------------------------------------------------------------------
 // GRID kernel (analytical)
 // ------------------------------------------------------------------------------------
@@ -326,6 +338,7 @@ __global__ __launch_bounds__(kBlock) void pmx_analytical_grid(DevModel m, DevOps
 #pragma unroll
     for (int i = 0; i < NS; ++i) x[i] = 0.0;
     double xpad = 0.0;
+    double ll_acc = 0.0;
     uint8_t st = st_lane;
     for (int64_t o = o0; o < o1; ++o) {
       const uint32_t meta = uniform32(ops.op_meta[o]);
@@ -347,8 +360,12 @@ __global__ __launch_bounds__(kBlock) void pmx_analytical_grid(DevModel m, DevOps
       } else if (kind == OP_OBS) {
         double y = lane_out<KID>(m, L, x, xpad, io, cov);
         if (st == PMX_PAIR_COMPLEX_ROOTS || st == PMX_PAIR_BAD_LAG) y = nanv;
-        if (st == PMX_PAIR_OK && !isfinite(y)) st = PMX_PAIR_NONFINITE;
-        if (lane_ok) pred[row * ld + p] = y;
+        if (ops.ll_obs != nullptr) {
+          ll_accumulate(ops.ll_obs + row * 4, y, ll_acc);
+        } else {
+          if (st == PMX_PAIR_OK && !isfinite(y)) st = PMX_PAIR_NONFINITE;
+          if (lane_ok) pred[row * ld + p] = y;
+        }
         ++row;
       } else if (kind == OP_BOLUS) {
         const int k = io - m.pm;
@@ -364,6 +381,10 @@ __global__ __launch_bounds__(kBlock) void pmx_analytical_grid(DevModel m, DevOps
         if constexpr (LAG)
           lag_open_occasion<LM::ST, NS>(m, ops, ls, static_cast<int64_t>(a), uniformf64(ops.op_t0[o]), L.coef, th, x);
       }
+    }
+    if (ops.ll_obs != nullptr) {
+      if (st == PMX_PAIR_OK && !isfinite(ll_acc)) st = PMX_PAIR_NONFINITE;  // NonFiniteLikelihood (prediction.rs:119-124)
+      if (lane_ok) ops.ll_out[s * ops.ll_ld + p] = (st == PMX_PAIR_OK || st == PMX_PAIR_NONFINITE) ? ll_acc : nanv;
     }
     if (status != nullptr && lane_ok && st != PMX_PAIR_OK) status[s * P + p] = st;  // array pre-zeroed by the library
   }
@@ -437,7 +458,7 @@ __device__ __forceinline__ void classed_emit_state(int out_state, const double (
 
 // __launch_bounds__ 2nd argument = waves per SIMD the register allocator must leave room for
 // (4 -> at most 128 VGPRs): the kernel is a latency/bandwidth mix and wants the occupancy.
-template <int KID>
+template <int KID, bool LL>
 __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx_analytical_classed(
     DevModel m, DevOps ops, DevClassPlan cp, const double* __restrict__ theta, int64_t P, int32_t chunks_per_block,
     int32_t n_ptiles, double* __restrict__ pred, int64_t ld, uint8_t* __restrict__ status) {
@@ -499,7 +520,13 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
     const int64_t pe = cls_prog_off[cls + 1];
     int64_t kld = 0;   // (observations emitted so far) * ld
     double* slot[G / 2];  // this lane's 16-byte slot in the first prediction row of each member pair
-    {
+    double ll_acc[G];     // log-likelihood mode: running sum of each member
+    int64_t cobs_off = 0;  // log-likelihood mode: the chunk's {value, const, weight} block, advanced per observation
+    if constexpr (LL) {
+      cobs_off = as_const(cp.chunk_obs_off)[c];
+#pragma unroll
+      for (int j = 0; j < G; ++j) ll_acc[j] = 0.0;
+    } else {
       const auto rows = chunk_row + c * G;
 #pragma unroll
       for (int h = 0; h < G / 2; ++h) {
@@ -554,10 +581,36 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
           const double v = (m.out[oq].vol_src == PMX_SRC_PRIMARY) ? th[m.out[oq].vol_index] : 1.0;
           inv_vol = lane_good ? 1.0 / v : inv_vol0;
         }
-        // wave-uniform: the state is picked by a scalar branch, not per-lane selects
-        classed_emit_state<0, G, NS>(out_state, x, inv_vol, slot, kld, upper, pair_full, pair_half, any_half, n_live,
-                                     bad);
-        kld += ld;
+        if constexpr (LL) {
+          // fold the G predictions into the members' sums instead of storing them (ll_accumulate, per member;
+          // the observed values and sigma terms are wave-uniform scalar fetches)
+          const auto ov = as_const(cp.cobs) + cobs_off;
+#pragma unroll
+          for (int j = 0; j < G; ++j) {
+            const double w = ov[2 * G + j];
+            if (w != 0.0) {  // wave-uniform; weight 0 = missing observation (or chunk padding)
+              const double y = select_state<NS>(x[j], out_state) * inv_vol;
+              const double d = ov[j] - y;
+              ll_acc[j] += ov[G + j] - (d * d) * w;
+            }
+          }
+          cobs_off += 3 * G;
+        } else {
+          // wave-uniform: the state is picked by a scalar branch, not per-lane selects
+          classed_emit_state<0, G, NS>(out_state, x, inv_vol, slot, kld, upper, pair_full, pair_half, any_half, n_live,
+                                       bad);
+          kld += ld;
+        }
+      }
+    }
+    if constexpr (LL) {
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        if (j < n_live) {
+          const int64_t sid = chunk_subj[c * G + j];
+          if (!isfinite(ll_acc[j])) bad |= (1u << j);  // NonFiniteLikelihood (prediction.rs:119-124)
+          if (lane_ok) ops.ll_out[sid * ops.ll_ld + p] = ll_acc[j];  // (NaN already for a lane with complex roots)
+        }
       }
     }
     // status bytes: the library zeroes the array before the launch (PMX_PAIR_OK == 0); only failures are
@@ -615,6 +668,7 @@ __global__ __launch_bounds__(kBlock) void pmx_analytical_pair(DevModel m, DevOps
 #pragma unroll
   for (int k = 0; k < NS; ++k) x[k] = 0.0;
   double xpad = 0.0;
+  double ll_acc = 0.0;
   uint8_t st = st_lane;
   // exec-masked loop: runs while ANY lane of the wave still has ops (each lane exits at its own o1)
   for (; o < o1; ++o) {
@@ -637,8 +691,12 @@ __global__ __launch_bounds__(kBlock) void pmx_analytical_pair(DevModel m, DevOps
     } else if (kind == OP_OBS) {
       double y = lane_out<KID>(m, L, x, xpad, io, cov);
       if (st == PMX_PAIR_COMPLEX_ROOTS || st == PMX_PAIR_BAD_LAG) y = nanv;
-      if (st == PMX_PAIR_OK && !isfinite(y)) st = PMX_PAIR_NONFINITE;
-      pred[row * ld + p] = y;
+      if (ops.ll_obs != nullptr) {
+        ll_accumulate(ops.ll_obs + row * 4, y, ll_acc);
+      } else {
+        if (st == PMX_PAIR_OK && !isfinite(y)) st = PMX_PAIR_NONFINITE;
+        pred[row * ld + p] = y;
+      }
       ++row;
     } else if (kind == OP_BOLUS) {
       const int k = io - m.pm;
@@ -653,6 +711,10 @@ __global__ __launch_bounds__(kBlock) void pmx_analytical_pair(DevModel m, DevOps
       if constexpr (DYN) st = st_lane;
       if constexpr (LAG) lag_open_occasion<LM::ST, NS>(m, ops, ls, static_cast<int64_t>(a), ops.op_t0[o], L.coef, th, x);
     }
+  }
+  if (ops.ll_obs != nullptr) {
+    if (st == PMX_PAIR_OK && !isfinite(ll_acc)) st = PMX_PAIR_NONFINITE;
+    if (lane_ok) ops.ll_out[batch ? s : (s * ops.ll_ld + p)] = (st == PMX_PAIR_OK || st == PMX_PAIR_NONFINITE) ? ll_acc : nanv;
   }
   if (status != nullptr && lane_ok && st != PMX_PAIR_OK) status[batch ? s : (s * P + p)] = st;  // pre-zeroed
 }
@@ -834,6 +896,7 @@ __global__ __launch_bounds__(kBlock) void pmx_ode_rk4_grid(DevModel m, DevOps op
 #pragma unroll
     for (int i = 0; i < NS; ++i) x[i] = 0.0;
     uint8_t st = PMX_PAIR_OK;
+    double ll_acc = 0.0;
     for (int64_t o = o0; o < o1; ++o) {
       const uint32_t meta = uniform32(ops.op_meta[o]);
       const uint32_t kind = meta & 0xffu;
@@ -847,8 +910,12 @@ __global__ __launch_bounds__(kBlock) void pmx_ode_rk4_grid(DevModel m, DevOps op
         for (int32_t k = 0; k < n; ++k) rk4_step<MODEL>(L.kp, x, rs, h);
       } else if (kind == OP_OBS) {
         const double y = ode_out<MODEL>(m, L, x, io);
-        if (st == PMX_PAIR_OK && !isfinite(y)) st = PMX_PAIR_NONFINITE;
-        if (lane_ok) pred[row * ld + p] = y;
+        if (ops.ll_obs != nullptr) {
+          ll_accumulate(ops.ll_obs + row * 4, y, ll_acc);
+        } else {
+          if (st == PMX_PAIR_OK && !isfinite(y)) st = PMX_PAIR_NONFINITE;
+          if (lane_ok) pred[row * ld + p] = y;
+        }
         ++row;
       } else if (kind == OP_BOLUS) {
         const int dest = (m.bolus_dest[io] >= 0) ? m.bolus_dest[io] : io;
@@ -859,6 +926,10 @@ __global__ __launch_bounds__(kBlock) void pmx_ode_rk4_grid(DevModel m, DevOps op
 #pragma unroll
         for (int i = 0; i < NS; ++i) x[i] = io ? L.xinit[i] : 0.0;
       }
+    }
+    if (ops.ll_obs != nullptr) {
+      if (st == PMX_PAIR_OK && !isfinite(ll_acc)) st = PMX_PAIR_NONFINITE;
+      if (lane_ok) ops.ll_out[s * ops.ll_ld + p] = ll_acc;
     }
     if (status != nullptr && lane_ok && st != PMX_PAIR_OK) status[s * P + p] = st;  // array pre-zeroed by the library
   }
@@ -894,6 +965,7 @@ __global__ __launch_bounds__(kBlock) void pmx_ode_rk4_pair(DevModel m, DevOps op
   }
   int32_t rem = 0;
   double h = 0.0;
+  double ll_acc = 0.0;
   uint8_t st = PMX_PAIR_OK;
   while (rem > 0 || o < o1) {
     if (rem > 0) {
@@ -910,8 +982,12 @@ __global__ __launch_bounds__(kBlock) void pmx_ode_rk4_pair(DevModel m, DevOps op
         ode_rates<MODEL>(m, ops.op_rate, o, ops.n_rate, rs);
       } else if (kind == OP_OBS) {
         const double y = ode_out<MODEL>(m, L, x, io);
-        if (st == PMX_PAIR_OK && !isfinite(y)) st = PMX_PAIR_NONFINITE;
-        pred[row * ld + p] = y;
+        if (ops.ll_obs != nullptr) {
+          ll_accumulate(ops.ll_obs + row * 4, y, ll_acc);
+        } else {
+          if (st == PMX_PAIR_OK && !isfinite(y)) st = PMX_PAIR_NONFINITE;
+          pred[row * ld + p] = y;
+        }
         ++row;
       } else if (kind == OP_BOLUS) {
         const int dest = (m.bolus_dest[io] >= 0) ? m.bolus_dest[io] : io;
@@ -924,6 +1000,10 @@ __global__ __launch_bounds__(kBlock) void pmx_ode_rk4_pair(DevModel m, DevOps op
       }
       ++o;
     }
+  }
+  if (ops.ll_obs != nullptr) {
+    if (st == PMX_PAIR_OK && !isfinite(ll_acc)) st = PMX_PAIR_NONFINITE;
+    if (lane_ok) ops.ll_out[batch ? s : (s * ops.ll_ld + p)] = ll_acc;
   }
   if (status != nullptr && lane_ok && st != PMX_PAIR_OK) status[batch ? s : (s * P + p)] = st;  // pre-zeroed
 }
@@ -948,9 +1028,16 @@ hipError_t launch_analytical(const LaunchArgs& a, const char** name) {
         if (cpb < 1) cpb = 1;
         if (cpb > 8) cpb = 8;
         const int64_t cblocks = ((a.cls.n_chunks + cpb - 1) / cpb + 7) / 8 * 8;  // whole XCD groups
-        hipLaunchKernelGGL((pmx_analytical_classed<KID>), dim3(static_cast<uint32_t>(cblocks * a.n_ptiles)), dim3(kBlock),
-                           0, st, a.m, a.ops, a.cls, a.theta, a.P, static_cast<int32_t>(cpb), a.n_ptiles, a.pred, a.ld,
-                           a.status);
+        if (a.ops.ll_obs != nullptr) {
+          *name = "pmx_analytical_classed<ll>";
+          hipLaunchKernelGGL((pmx_analytical_classed<KID, true>), dim3(static_cast<uint32_t>(cblocks * a.n_ptiles)),
+                             dim3(kBlock), 0, st, a.m, a.ops, a.cls, a.theta, a.P, static_cast<int32_t>(cpb), a.n_ptiles,
+                             a.pred, a.ld, a.status);
+        } else {
+          hipLaunchKernelGGL((pmx_analytical_classed<KID, false>), dim3(static_cast<uint32_t>(cblocks * a.n_ptiles)),
+                             dim3(kBlock), 0, st, a.m, a.ops, a.cls, a.theta, a.P, static_cast<int32_t>(cpb), a.n_ptiles,
+                             a.pred, a.ld, a.status);
+        }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         n_walk = a.cls.n_generic;

@@ -46,6 +46,11 @@ struct DevOps {
   const int64_t* lagb_off;      // [(n_occasions*n_lag_slots)+1]
   const double* lagb_time;
   const double* lagb_amount;
+  // fused log-likelihood (pmx_loglik): nullptr = prediction mode
+  const double* ll_obs;         // [n_observations][4] = {observed value, -0.5 ln(2pi) - ln(sigma), 1/(2 sigma^2), 0};
+                                //   weight 0 marks a missing observation (contributes nothing)
+  double* ll_out;               // [n_subjects x ll_ld]
+  int64_t ll_ld;
   int32_t n_rate;
   int32_t pad_;
 };
@@ -61,6 +66,8 @@ struct DevClassPlan {
   const int32_t* chunk_subj;
   const int64_t* chunk_row;  // [n_chunks*G] first prediction row of each member (0 for padding)
   const double* val;
+  const double* cobs;               // log-likelihood mode: per chunk [observation k][3][G] = value, const term, weight
+  const int64_t* chunk_obs_off;     // [n_chunks] offset of the chunk's block in cobs
   const int32_t* generic_subjects;  // subjects the generic GRID kernel still has to walk
   int64_t n_chunks;
   int64_t n_generic;

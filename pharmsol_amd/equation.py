@@ -301,6 +301,14 @@ class Equation:
         return runtime.predict_host(self, flat, np.ascontiguousarray(theta, dtype=np.float64))
 
 
+    def log_likelihood_matrix(self, data, theta: np.ndarray, error_models):
+        """``log_likelihood_matrix(eq, &data, &theta, &error_models, progress)`` (likelihood/matrix.rs:52-106):
+        ``(ll[n_subjects, n_support], status)``; the predictions never leave the GPU."""
+        flat = data if isinstance(data, FlatPopulation) else self.flatten(data)
+        from . import runtime
+        return runtime.loglik_host(self, flat, error_models, np.ascontiguousarray(theta, dtype=np.float64))
+
+
 class Analytical(Equation):
     """Closed-form model (src/simulator/equation/analytical/mod.rs:48-59)."""
 

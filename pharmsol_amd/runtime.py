@@ -138,6 +138,51 @@ def predict(model, pop: DevicePopulation, theta, pred=None, status=None, batch: 
     return pred, status
 
 
+def loglik_host(model, flat: FlatPopulation, error_models, theta: np.ndarray, device: int = 0,
+                raise_on_pair_failure: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+    """Host-pointer form of the fused log-likelihood (``pmx_loglik``): ``(ll[S, P], status[S, P])``."""
+    L = _ffi.lib()
+    dm = _as_model(model)
+    pop = DevicePopulation(flat, device)
+    theta = np.ascontiguousarray(theta, dtype=np.float64)
+    if theta.ndim == 1:
+        theta = theta.reshape(1, -1)
+    P = theta.shape[0]
+    em = error_models.to_c(model)
+    ll = np.full((pop.n_subjects, P), np.nan)
+    status = np.zeros((pop.n_subjects, P), dtype=np.uint8)
+    rc = L.pmx_loglik(dm.handle, pop.handle, C.cast(em, C.c_void_p), theta.ctypes.data, P, ll.ctypes.data, P,
+                      status.ctypes.data)
+    _ffi.check(rc, allow_pair_failures=not raise_on_pair_failure)
+    return ll, status
+
+
+def loglik(model, pop: DevicePopulation, error_models, theta, ll=None, status=None, want_status: bool = True):
+    """Device-pointer form (``pmx_loglik_device``): torch CUDA tensors on torch's current stream, not
+    synchronised.  Returns ``(ll[S, P], status[S, P])`` — the matrix ``log_likelihood_matrix`` returns
+    (likelihood/matrix.rs:52-106), support point fastest."""
+    import torch
+
+    L = _ffi.lib()
+    dm = _as_model(model)
+    dev = torch.device("cuda", pop.device)
+    if not (isinstance(theta, torch.Tensor) and theta.is_cuda):
+        theta = torch.as_tensor(np.ascontiguousarray(theta, dtype=np.float64), device=dev)
+    theta = theta.contiguous()
+    P = int(theta.shape[0])
+    if ll is None:
+        ll = torch.empty((pop.n_subjects, P), dtype=torch.float64, device=dev)
+    if status is None and want_status:
+        status = torch.zeros((pop.n_subjects, P), dtype=torch.uint8, device=dev)
+    em = error_models if not hasattr(error_models, "to_c") else error_models.to_c(model)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    rc = L.pmx_loglik_device(dm.handle, pop.handle, C.cast(em, C.c_void_p), theta.data_ptr(), P, ll.data_ptr(),
+                             int(ll.stride(0)) if ll.shape[0] > 1 else P,
+                             status.data_ptr() if status is not None else None, stream)
+    _ffi.check(rc)
+    return ll, status
+
+
 def last_kernel_name() -> str:
     return _ffi.lib().pmx_last_kernel_name().decode()
 

@@ -1,0 +1,145 @@
+"""GPU parity of the fused log-likelihood (pmx_loglik_device) against the CPU oracle's
+estimate_log_likelihood_dense restatement.  Tolerance 1e-9 relative on the per-(subject, support point) sums
+(the predictions inside agree to ~1e-13; the sums are O(10..1e4))."""
+import numpy as np
+import pytest
+
+import oracle
+from pharmsol_amd import (ODE, Analytical, AssayErrorModel, AssayErrorModels, Data, ErrorPoly, Ratio, Subject, _abi,
+                          runtime, synth)
+from tests import models
+
+pytestmark = pytest.mark.gpu
+TOL_LL = 1e-9
+
+
+def with_observed_values(model, flat, theta_true, rng, missing_frac=0.15, batch=False):
+    """Fill the observation slots with 'measured' values = oracle prediction at theta_true x lognormal noise;
+    a fraction stays missing (NaN)."""
+    pred, _ = (oracle.predict_batch(model, flat, theta_true) if batch else oracle.predict(model, flat, theta_true))
+    pred = pred.reshape(flat.n_observations, -1)[:, 0]
+    vals = np.abs(pred) * np.exp(rng.normal(0, 0.2, pred.shape)) + 0.05
+    vals[rng.random(pred.shape) < missing_frac] = np.nan
+    is_obs = flat.ev_kind == _abi.PMX_EV_OBSERVATION
+    # observation rows follow the library's per-occasion sort; these populations are already sorted per occasion
+    flat.ev_value = flat.ev_value.copy()
+    flat.ev_value[is_obs] = vals
+    return flat
+
+
+def gpu_loglik(model, flat, em, theta):
+    import torch
+
+    pop = runtime.DevicePopulation(flat, 0)
+    ll, st = runtime.loglik(model, pop, em, np.ascontiguousarray(theta, dtype=np.float64))
+    torch.cuda.synchronize()
+    return ll.cpu().numpy(), st.cpu().numpy()
+
+
+def assert_ll_parity(model, flat, em, theta, expect_kernel=None):
+    got, st = gpu_loglik(model, flat, em, theta)
+    if expect_kernel:
+        assert runtime.last_kernel_name().startswith(expect_kernel), runtime.last_kernel_name()
+    want, wst = oracle.loglik(model, flat, em, theta)
+    np.testing.assert_array_equal(st, wst)
+    ok = np.isfinite(want)
+    np.testing.assert_array_equal(np.isfinite(got), ok)
+    err = np.abs(got[ok] - want[ok]) / np.maximum(np.abs(want[ok]), 1.0)
+    assert err.max() <= TOL_LL, err.max()
+    return got, want
+
+
+EM_ADD = AssayErrorModels.empty().add(0, AssayErrorModel.additive(ErrorPoly(0.05, 0.1, 0.0, 0.0), 0.1))
+EM_PROP = AssayErrorModels.empty().add(0, AssayErrorModel.proportional(ErrorPoly(0.02, 0.15, 0.001, 0.0), 1.3))
+
+
+@pytest.mark.parametrize("em", [EM_ADD, EM_PROP])
+def test_c3_shared_design_classed_kernel(em):
+    rng = np.random.default_rng(1)
+    m, flat, theta = synth.config_c3(333, 1000)  # 333: the last chunk of 8 is partial
+    flat = with_observed_values(m, flat, theta[:1], rng)
+    assert_ll_parity(m, flat, em, theta, expect_kernel="pmx_analytical_classed<ll>")
+
+
+def test_ragged_population_generic_and_pair_kernels():
+    rng = np.random.default_rng(2)
+    subs = [models.random_subject(rng, multi_occasion=True) for _ in range(150)]
+    subs.insert(9, Subject.builder("empty").build())
+    m = models.handwritten_analytical("two_compartments", 0, 4).with_ndrugs(1)
+    flat = m.flatten(Data(subs))
+    theta = synth.theta_c3(70)
+    flat = with_observed_values(m, flat, theta[:1], rng)
+    assert_ll_parity(m, flat, EM_ADD, theta, expect_kernel="pmx_analytical_grid")
+    assert_ll_parity(m, flat, EM_PROP, theta[:5], expect_kernel="pmx_analytical_pair")
+
+
+def test_covariate_model_c5():
+    rng = np.random.default_rng(3)
+    m, flat, theta = synth.config_c5(120, 64)
+    flat = with_observed_values(m, flat, theta[:1], rng)
+    assert_ll_parity(m, flat, EM_ADD, theta, expect_kernel="pmx_analytical_grid<dyn>")
+
+
+def test_ode_model():
+    rng = np.random.default_rng(4)
+    m = models.handwritten_ode("two_cmt_iv", 0, 4, h_max=0.02).with_ndrugs(1)
+    subs = [models.random_subject(rng) for _ in range(60)]
+    flat = m.flatten(Data(subs))
+    theta = synth.theta_c3(40)
+    flat = with_observed_values(m, flat, theta[:1], rng)
+    assert_ll_parity(m, flat, EM_PROP, theta, expect_kernel="pmx_ode_rk4_grid")
+
+
+def test_two_outputs_with_their_own_error_models():
+    rng = np.random.default_rng(5)
+    m = Analytical.new("two_compartments", {0: Ratio(0, 3), 1: Ratio(1, 4)}, nparams=5).with_nstates(2).with_ndrugs(
+        1).with_nout(2)
+    subs = []
+    for i in range(40):
+        b = Subject.builder(str(i)).infusion(0.0, 300.0 + i, 0, 1.0)
+        for t in (0.5, 1.0, 2.0, 4.0, 8.0):
+            b = b.observation(t, float(rng.uniform(0.5, 9.0)), int(rng.integers(0, 2)))
+        subs.append(b.build())
+    em = (AssayErrorModels.empty().add(0, AssayErrorModel.additive(ErrorPoly(0.1, 0.1, 0.0, 0.0), 0.0))
+          .add(1, AssayErrorModel.proportional(ErrorPoly(0.2, 0.05, 0.0, 0.0), 2.0)))
+    theta = np.concatenate([synth.theta_c3(48), rng.uniform(20, 80, (48, 1))], axis=1)
+    assert_ll_parity(m, m.flatten(Data(subs)), em, theta)
+
+
+def test_missing_error_model_and_non_finite_sums():
+    m, flat, theta = synth.config_c3(16, 40)
+    flat = with_observed_values(m, flat, theta[:1], np.random.default_rng(6), missing_frac=0.0)
+    pop = runtime.DevicePopulation(flat, 0)
+    with pytest.raises(_abi.PmxError) as e:
+        runtime.loglik(m, pop, AssayErrorModels.empty(), theta)
+    assert e.value.status == _abi.PMX_ERR_ERROR_MODEL
+    th = theta.copy()
+    th[3, 3] = 0.0  # v = 0: predictions inf -> the sum is non-finite for that support point only
+    got, st = gpu_loglik(m, flat, EM_ADD, th)
+    want, wst = oracle.loglik(m, flat, EM_ADD, th)
+    np.testing.assert_array_equal(st, wst)
+    assert (st[:, 3] == _abi.PMX_PAIR_NONFINITE).all() and (np.delete(st, 3, axis=1) == 0).all()
+
+
+def test_matches_predictions_then_host_reduction():
+    """The fused path equals 'predict, then sum lognormpdf on the host' (what a caller without the fused entry does)."""
+    rng = np.random.default_rng(7)
+    m, flat, theta = synth.config_c3(64, 96)
+    flat = with_observed_values(m, flat, theta[:1], rng)
+    ll, _ = gpu_loglik(m, flat, EM_ADD, theta)
+    pred, _ = runtime.predict_host(m, flat, theta)
+    y = flat.ev_value[flat.ev_kind == _abi.PMX_EV_OBSERVATION]
+    sig = np.sqrt((0.05 + 0.1 * y) ** 2 + 0.1 ** 2)
+    term = -0.5 * 1.8378770664093453 - np.log(sig)[:, None] - (y[:, None] - pred) ** 2 / (2 * sig[:, None] ** 2)
+    term[np.isnan(y)] = 0.0
+    want = term.reshape(64, 7, 96).sum(axis=1)
+    assert np.abs(ll - want).max() / np.abs(want).max() < 1e-12
+
+
+def test_host_pointer_form_through_the_equation_api():
+    rng = np.random.default_rng(8)
+    m, flat, theta = synth.config_c3(40, 33)
+    flat = with_observed_values(m, flat, theta[:1], rng)
+    ll, st = m.log_likelihood_matrix(flat, theta, EM_PROP)
+    want, _ = oracle.loglik(m, flat, EM_PROP, theta)
+    assert ll.shape == (40, 33) and np.abs(ll - want).max() / np.abs(want).max() < TOL_LL
