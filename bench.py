@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
     ap.add_argument("--gather", action="store_true", help="N>1: also time the optional RCCL all-gather")
     ap.add_argument("--no-status", action="store_true", help="do not write the per-pair status bytes")
+    ap.add_argument("--loglik", action="store_true",
+                    help="time the fused log-likelihood entry (pmx_loglik_device) instead of predictions: output S x P")
     ap.add_argument("--no-class", action="store_true",
                     help="A/B: disable the classed kernel (shared-design propagator reuse); every subject walks the generic kernel")
     args = ap.parse_args()
@@ -122,16 +124,38 @@ def main():
         theta = theta_all[s0:s1]
     k = theta.shape[1]
 
+    em = None
+    if args.loglik:
+        assert not batch, "--loglik is defined for the matrix shape (subjects x support points)"
+        from pharmsol_amd import AssayErrorModel, AssayErrorModels, ErrorPoly, _abi
+
+        # 'measured' values: this rank's predictions at the first support point x deterministic lognormal noise
+        pop0 = runtime.DevicePopulation(flat, device_index)
+        p0, _ = runtime.predict(model, pop0, theta[:1])
+        torch.cuda.synchronize()
+        rng = synth.SplitMix64(synth.SEED ^ 0x11 ^ rank)
+        noise = np.exp(0.2 * (rng.uniform(pop0.n_observations) - 0.5))
+        vals = np.abs(p0.cpu().numpy()[:, 0]) * noise + 0.05
+        flat.ev_value = flat.ev_value.copy()
+        flat.ev_value[flat.ev_kind == _abi.PMX_EV_OBSERVATION] = vals
+        del pop0, p0
+        em = AssayErrorModels.empty().add(0, AssayErrorModel.additive(ErrorPoly(0.05, 0.1, 0.0, 0.0), 0.1))
+        label += " -> fused log-likelihood (additive error, sigma from the observation)"
     pop = runtime.DevicePopulation(flat, device_index)
     d_theta = torch.as_tensor(np.ascontiguousarray(theta), device=dev)
     n_obs = pop.n_observations
-    pred = torch.empty((n_obs,) if batch else (n_obs, P), dtype=torch.float64, device=dev)
+    pred = torch.empty((n_obs,) if batch else ((pop.n_subjects, P) if args.loglik else (n_obs, P)), dtype=torch.float64,
+                       device=dev)
+    em_c = em.to_c(model) if em is not None else None
     status = None if args.no_status else torch.zeros((pop.n_subjects,) if batch else (pop.n_subjects, P),
                                                      dtype=torch.uint8, device=dev)
     steps_per_pass_local = pop.n_events * (1 if batch else P)
 
     def one_pass():
-        runtime.predict(model, pop, d_theta, pred=pred, status=status, batch=batch, want_status=not args.no_status)
+        if args.loglik:
+            runtime.loglik(model, pop, em_c, d_theta, ll=pred, status=status, want_status=not args.no_status)
+        else:
+            runtime.predict(model, pop, d_theta, pred=pred, status=status, batch=batch, want_status=not args.no_status)
 
     for _ in range(args.warmup):
         one_pass()
@@ -187,7 +211,10 @@ def main():
         import oracle  # test infrastructure: the checker / the timed CPU baseline, never the product path
 
         cores = oracle.max_threads()
-        run = (lambda f, th: oracle.predict_batch(model, f, th)) if batch else (lambda f, th: oracle.predict(model, f, th))
+        if args.loglik:
+            run = lambda f, th: oracle.loglik(model, f, em, th)
+        else:
+            run = (lambda f, th: oracle.predict_batch(model, f, th)) if batch else (lambda f, th: oracle.predict(model, f, th))
         per_subject = max(flat.n_events / max(flat.n_subjects, 1) * (1 if batch else P), 1.0)
 
         def timed(n):
@@ -227,6 +254,8 @@ def main():
         O_tot = n_obs
         # per-launch algorithmic bytes of THIS rank's kernel (S*O = n_obs rows, S*E = n_events)
         b_alg = 8 * O_tot * (1 if batch else P) + 8 * theta.shape[0] * k + 26 * E_tot
+        if args.loglik:  # S x P sums out, 24 B of {value, const, weight} per observation in
+            b_alg = 8 * pop.n_subjects * P + 8 * theta.shape[0] * k + 26 * E_tot + 24 * O_tot
         achieved = b_alg / (kernel_ms_mean * 1e-3) / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
