@@ -327,13 +327,25 @@ __global__ __launch_bounds__(kBlock) void pmx_analytical_grid(DevModel m, DevOps
   const uint8_t st_lane = st_lane0;
   const double nanv = __longlong_as_double(0x7ff8000000000000LL);
 
+  // the op stream is read-only for the launch and indexed wave-uniformly: constant-address-space pointers
+  // turn these into scalar (s_load) fetches
+  const auto c_subj_op_off = as_const(ops.subj_op_off);
+  const auto c_subj_obs_off = as_const(ops.subj_obs_off);
+  const auto c_op_meta = as_const(ops.op_meta);
+  const auto c_op_a = as_const(ops.op_a);
+  const auto c_op_b = as_const(ops.op_b);
+  const auto c_op_t0 = as_const(ops.op_t0);
+  const auto c_op_t1 = as_const(ops.op_t1);
+  (void)c_op_t0;
+  (void)c_op_t1;
+
   const int64_t s_begin = chunk * s_chunk;
   const int64_t s_end = (s_begin + s_chunk < S) ? (s_begin + s_chunk) : S;
   for (int64_t si = s_begin; si < s_end; ++si) {
-    const int64_t s = subj_list ? static_cast<int64_t>(uniform32(static_cast<uint32_t>(subj_list[si]))) : si;
-    const int64_t o0 = uniform64(ops.subj_op_off[s]);
-    const int64_t o1 = uniform64(ops.subj_op_off[s + 1]);
-    int64_t row = uniform64(ops.subj_obs_off[s]);
+    const int64_t s = subj_list ? static_cast<int64_t>(as_const(subj_list)[si]) : si;
+    const int64_t o0 = c_subj_op_off[s];
+    const int64_t o1 = c_subj_op_off[s + 1];
+    int64_t row = c_subj_obs_off[s];
     double x[NS];
 #pragma unroll
     for (int i = 0; i < NS; ++i) x[i] = 0.0;
@@ -341,18 +353,18 @@ __global__ __launch_bounds__(kBlock) void pmx_analytical_grid(DevModel m, DevOps
     double ll_acc = 0.0;
     uint8_t st = st_lane;
     for (int64_t o = o0; o < o1; ++o) {
-      const uint32_t meta = uniform32(ops.op_meta[o]);
+      const uint32_t meta = c_op_meta[o];
       const uint32_t kind = meta & 0xffu;
       const int io = static_cast<int>((meta >> 8) & 0xffffu);
-      const double a = uniformf64(ops.op_a[o]);
+      const double a = c_op_a[o];
       const double* cov = ops.op_cov + o * m.n_cov;
       if (kind == OP_PROP) {
-        const double r = uniformf64(ops.op_b[o]);
+        const double r = c_op_b[o];
         if constexpr (DYN) {
           if (!lane_prepare_dyn<KID>(m, L, cov)) st = PMX_PAIR_COMPLEX_ROOTS;
         }
         if constexpr (LAG) {
-          lag_prop<LM::ST, NS>(m, ops, ls, uniformf64(ops.op_t0[o]), uniformf64(ops.op_t1[o]), r, L.coef, th, x);
+          lag_prop<LM::ST, NS>(m, ops, ls, c_op_t0[o], c_op_t1[o], r, L.coef, th, x);
         } else {
           advance<LM::ST>(L.coef, x, a, r);
         }
@@ -379,7 +391,7 @@ __global__ __launch_bounds__(kBlock) void pmx_analytical_grid(DevModel m, DevOps
         xpad = 0.0;
         if constexpr (DYN) st = st_lane;  // a new occasion re-derives its coefficients
         if constexpr (LAG)
-          lag_open_occasion<LM::ST, NS>(m, ops, ls, static_cast<int64_t>(a), uniformf64(ops.op_t0[o]), L.coef, th, x);
+          lag_open_occasion<LM::ST, NS>(m, ops, ls, static_cast<int64_t>(a), c_op_t0[o], L.coef, th, x);
       }
     }
     if (ops.ll_obs != nullptr) {
