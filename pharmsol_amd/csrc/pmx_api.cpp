@@ -232,9 +232,14 @@ int32_t pmx_model_create(const pmx_model_desc* d, pmx_model** out) {
     if (!(d->rk4_h_max > 0.0)) return fail(PMX_ERR_INVALID_ARGUMENT, "rk4_h_max must be > 0");
     if (d->n_derived > 0 || d->n_bind > 0 || pm)
       return fail(PMX_ERR_UNSUPPORTED, "derived parameters / pm indexing are not supported for ODE models yet");
+    {
+      int n_lag = 0;
+      for (int i = 0; i < PMX_MAX_INPUTS; ++i) n_lag += d->lag_param[i] >= 0;
+      if (n_lag > pmx::kMaxLagSlots) return fail(PMX_ERR_UNSUPPORTED, "more than 4 lagged inputs are not supported on the device path");
+    }
     for (int i = 0; i < PMX_MAX_INPUTS; ++i) {
-      if (d->lag_param[i] >= 0) return fail(PMX_ERR_UNSUPPORTED, "lag time is not on the device path for ODE models yet");
-      if (d->fa_param[i] >= d->nparams) return fail(PMX_ERR_INVALID_ARGUMENT, "fa_param out of range");
+      if (d->lag_param[i] >= d->nparams || d->fa_param[i] >= d->nparams)
+        return fail(PMX_ERR_INVALID_ARGUMENT, "lag_param / fa_param out of range");
       if (d->bolus_dest[i] >= d->nstates || d->infusion_dest[i] >= d->nstates)
         return fail(PMX_ERR_INVALID_ARGUMENT, "route destination out of range");
     }
@@ -287,6 +292,8 @@ pmx::CompileKey key_for(const pmx_model* m) {
     k.rk4_h_max = m->d.rk4_h_max;
     k.n_rate = m->d.ndrugs > 0 ? m->d.ndrugs : 1;
     k.rate_input = 0;
+    for (int i = 0; i < PMX_MAX_INPUTS; ++i)
+      if (m->d.lag_param[i] >= 0) k.lag_mask |= (1u << i);
   }
   return k;
 }
@@ -460,6 +467,7 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
   a.m.nout = d.nout;
   a.m.pm = d.pmetrics_indexing ? 1 : 0;
   a.m.has_init = model->has_init ? 1 : 0;
+  a.m.rk4_h_max = d.rk4_h_max;
   std::memcpy(a.m.derived, d.derived, sizeof(d.derived));
   std::memcpy(a.m.bind, d.bind, sizeof(d.bind));
   std::memcpy(a.m.out, d.out, sizeof(d.out));
@@ -472,6 +480,7 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
     if (d.lag_param[i] >= 0 && a.m.n_lag_slots < pmx::kMaxLagSlots) {
       a.m.lag_input[a.m.n_lag_slots] = i;
       a.m.lag_param[a.m.n_lag_slots] = d.lag_param[i];
+      a.m.lag_dest[a.m.n_lag_slots] = (d.eq_kind == PMX_EQ_ODE && d.bolus_dest[i] >= 0) ? d.bolus_dest[i] : i;
       a.m.n_lag_slots++;
     }
   }

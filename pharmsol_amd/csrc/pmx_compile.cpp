@@ -190,7 +190,7 @@ int32_t compile_ops(const HostPopulation& hp, const CompileKey& key, OpStream* o
   os->lagb_time.clear();
   os->lagb_amount.clear();
   os->n_prop = 0;
-  const uint32_t lag_mask = ode ? 0u : key.lag_mask;
+  const uint32_t lag_mask = key.lag_mask;
   int32_t slot_of_input[PMX_MAX_INPUTS];
   int32_t n_slots = 0;
   for (int i = 0; i < PMX_MAX_INPUTS; ++i) slot_of_input[i] = ((lag_mask >> i) & 1u) ? n_slots++ : -1;
@@ -235,7 +235,7 @@ int32_t compile_ops(const HostPopulation& hp, const CompileKey& key, OpStream* o
       push(OP_RESET, hp.occ_index[oc] == 0 ? 1u : 0u, static_cast<double>(oc), 0.0, 0, nullptr, oc, 0.0, false);
       const size_t reset_op = os->op_meta.size() - 1;
       inf.clear();
-      if (!ode && n_slots > 0) {
+      if (n_slots > 0) {
         // Lagged boluses leave the event list (the device merges them at t + lag(theta)); what remains is
         // walked exactly like before.  ev_keep = indices of the remaining events, still sorted.
         for (auto& v : lagb) v.clear();
@@ -332,22 +332,32 @@ int32_t compile_ops(const HostPopulation& hp, const CompileKey& key, OpStream* o
         }
         std::sort(bounds.begin(), bounds.end());
         bounds.erase(std::unique(bounds.begin(), bounds.end()), bounds.end());  // exact dedup, closure.rs:143-148
-        double t = 0.0;  // Occasion::initial_time, structs.rs:782-793
-        if (e1 > e0) {
-          t = hp.ev_time[e0];
-          for (int64_t e = e0 + 1; e < e1; ++e) t = std::min(t, hp.ev_time[e]);
+        auto is_lagged = [&](int64_t e) {
+          return n_slots > 0 && hp.ev_kind[e] == PMX_EV_BOLUS && hp.ev_io[e] < PMX_MAX_INPUTS && slot_of_input[hp.ev_io[e]] >= 0;
+        };
+        double t = 0.0;  // Occasion::initial_time over the events that stay in the list, structs.rs:782-793
+        {
+          bool any = false;
+          for (int64_t e = e0; e < e1; ++e) {
+            if (is_lagged(e)) continue;
+            t = any ? std::min(t, hp.ev_time[e]) : hp.ev_time[e];
+            any = true;
+          }
         }
         size_t bcur = 0;
         for (int64_t e = e0; e < e1; ++e) {
           const uint8_t k = hp.ev_kind[e];
+          if (is_lagged(e)) continue;
           if (k == PMX_EV_BOLUS) {
             max_input_used = std::max<int32_t>(max_input_used, hp.ev_io[e]);
             push(OP_BOLUS, hp.ev_io[e], hp.ev_value[e], 0.0, 0, nullptr, oc, 0.0, false);
           } else if (k == PMX_EV_OBSERVATION) {
             push(OP_OBS, hp.ev_io[e], hp.ev_time[e], 0.0, 0, nullptr, oc, hp.ev_time[e], true);
           }
-          if (e + 1 < e1) {
-            const double next_t = hp.ev_time[e + 1];
+          int64_t en = e + 1;
+          while (en < e1 && is_lagged(en)) ++en;
+          if (en < e1) {
+            const double next_t = hp.ev_time[en];
             while (next_t > t) {  // ode/mod.rs:721-739
               while (bcur < bounds.size() && bounds[bcur] <= t) ++bcur;
               double stop = next_t;
@@ -367,6 +377,10 @@ int32_t compile_ops(const HostPopulation& hp, const CompileKey& key, OpStream* o
                 }
                 const int32_t n = static_cast<int32_t>(nf);
                 push(OP_PROP, 0, dt, dt / static_cast<double>(n), n, rate.data(), oc, t, true);
+                if (n_slots > 0) {
+                  os->op_t0.back() = t;
+                  os->op_t1.back() = stop;
+                }
                 os->n_prop++;
               }
               t = stop;

@@ -219,18 +219,19 @@ template <int NS>
 __device__ __forceinline__ void lag_apply_bolus(const DevModel& m, const DevOps& ops, LagState& ls, int which,
                                                 const double* __restrict__ th, double (&x)[NS]) {
   int32_t idx = 0;
-  int input = 0;
+  int input = 0, dest = 0;
 #pragma unroll
   for (int k = 0; k < kMaxLagSlots; ++k) {
     if (k == which) {
       idx = ls.cur[k];
       input = m.lag_input[k];
+      dest = m.lag_dest[k];
       ls.cur[k] += 1;
     }
   }
   const double amt = ops.lagb_amount[idx] * fa_of(m, th, input);
 #pragma unroll
-  for (int i = 0; i < NS; ++i) x[i] += (i == input) ? amt : 0.0;
+  for (int i = 0; i < NS; ++i) x[i] += (i == dest) ? amt : 0.0;
 }
 
 // RESET of a lag model: point the cursors at this occasion's lists and run the boluses that land before the
@@ -883,7 +884,75 @@ __device__ __forceinline__ void ode_rates(const DevModel& m, const double* __res
   }
 }
 
+// One constant-rate piece [t0, t1] whose length is only known on the device (a lagged bolus split it):
+// n = ceil(dt / h_max) classic RK4 steps, the host compiler's rule (pmx_compile.cpp, ODE PROP ops).
 template <int MODEL>
+__device__ __forceinline__ void ode_piece(const DevModel& m, const double* kp, double (&x)[OdeModel<MODEL>::NS],
+                                          const double (&rs)[OdeModel<MODEL>::NS], double t0, double t1) {
+  const double dt = t1 - t0;
+  if (!(dt > 0.0)) return;
+  double nf = ceil(dt / m.rk4_h_max);
+  if (!(nf >= 1.0)) nf = 1.0;
+  if (nf > 1.0e7) nf = 1.0e7;  // a lane with an absurd lag must still terminate
+  const int32_t n = static_cast<int32_t>(nf);
+  const double h = dt / static_cast<double>(n);
+  for (int32_t k = 0; k < n; ++k) rk4_step<MODEL>(kp, x, rs, h);
+}
+
+// lag_open_occasion / lag_prop of the ODE back-end: same merge rule, RK4 pieces instead of closed forms.
+// Between an early lagged bolus and the occasion's first remaining event no infusion can be active
+// (infusions are events of the occasion), so those pieces run with zero rates.
+template <int MODEL>
+__device__ __forceinline__ void ode_lag_open_occasion(const DevModel& m, const DevOps& ops, LagState& ls, int64_t occ,
+                                                      double t_first, const double* kp, const double* __restrict__ th,
+                                                      double (&x)[OdeModel<MODEL>::NS]) {
+  constexpr int NS = OdeModel<MODEL>::NS;
+#pragma unroll
+  for (int k = 0; k < kMaxLagSlots; ++k) {
+    if (k < m.n_lag_slots) {
+      ls.cur[k] = static_cast<int32_t>(ops.lagb_off[occ * m.n_lag_slots + k]);
+      ls.end[k] = static_cast<int32_t>(ops.lagb_off[occ * m.n_lag_slots + k + 1]);
+    } else {
+      ls.cur[k] = ls.end[k] = 0;
+    }
+  }
+  double zero[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) zero[i] = 0.0;
+  bool started = false;
+  double t = 0.0;
+  for (;;) {
+    int which;
+    const double tau = lag_next(m, ops, ls, which);
+    if (!(tau < t_first)) break;
+    if (started) ode_piece<MODEL>(m, kp, x, zero, t, tau);
+    t = tau;
+    started = true;
+    lag_apply_bolus<NS>(m, ops, ls, which, th, x);
+  }
+  if (started && t_first < __longlong_as_double(0x7ff0000000000000LL)) ode_piece<MODEL>(m, kp, x, zero, t, t_first);
+}
+
+template <int MODEL>
+__device__ __forceinline__ void ode_lag_prop(const DevModel& m, const DevOps& ops, LagState& ls, double t0, double t1,
+                                             const double* kp, const double (&rs)[OdeModel<MODEL>::NS],
+                                             const double* __restrict__ th, double (&x)[OdeModel<MODEL>::NS]) {
+  constexpr int NS = OdeModel<MODEL>::NS;
+  double t = t0;
+  for (;;) {
+    int which;
+    const double tau = lag_next(m, ops, ls, which);
+    if (!(tau < t1)) break;
+    if (tau > t) {
+      ode_piece<MODEL>(m, kp, x, rs, t, tau);
+      t = tau;
+    }
+    lag_apply_bolus<NS>(m, ops, ls, which, th, x);
+  }
+  ode_piece<MODEL>(m, kp, x, rs, t, t1);
+}
+
+template <int MODEL, bool LAG>
 __global__ __launch_bounds__(kBlock) void pmx_ode_rk4_grid(DevModel m, DevOps ops, const double* __restrict__ theta,
                                                            int64_t P, int64_t S, int32_t s_chunk, int32_t n_ptiles,
                                                            double* __restrict__ pred, int64_t ld,
@@ -896,8 +965,23 @@ __global__ __launch_bounds__(kBlock) void pmx_ode_rk4_grid(DevModel m, DevOps op
   const int64_t p = static_cast<int64_t>(ptile) * kBlock + threadIdx.x;
   const bool lane_ok = p < P;
   const int64_t pc = lane_ok ? p : (P - 1);
+  const double* __restrict__ th = theta + pc * m.nparams;
   OdeLane<MODEL> L;
-  ode_lane_setup<MODEL>(m, theta + pc * m.nparams, L);
+  ode_lane_setup<MODEL>(m, th, L);
+  uint8_t st_lane = PMX_PAIR_OK;
+  LagState ls;
+  if constexpr (LAG) {
+#pragma unroll
+    for (int k = 0; k < kMaxLagSlots; ++k) {
+      ls.lag[k] = (k < m.n_lag_slots) ? th[m.lag_param[k]] : 0.0;
+      ls.cur[k] = ls.end[k] = 0;
+      if (k < m.n_lag_slots && !(ls.lag[k] >= 0.0)) {
+        st_lane = PMX_PAIR_BAD_LAG;
+        ls.lag[k] = 0.0;  // keep the walk finite; every output of this lane is NaN anyway
+      }
+    }
+  }
+  const double nanv = __longlong_as_double(0x7ff8000000000000LL);
   const int64_t s_begin = chunk * s_chunk;
   const int64_t s_end = (s_begin + s_chunk < S) ? (s_begin + s_chunk) : S;
   for (int64_t s = s_begin; s < s_end; ++s) {
@@ -907,7 +991,7 @@ __global__ __launch_bounds__(kBlock) void pmx_ode_rk4_grid(DevModel m, DevOps op
     double x[NS];
 #pragma unroll
     for (int i = 0; i < NS; ++i) x[i] = 0.0;
-    uint8_t st = PMX_PAIR_OK;
+    uint8_t st = st_lane;
     double ll_acc = 0.0;
     for (int64_t o = o0; o < o1; ++o) {
       const uint32_t meta = uniform32(ops.op_meta[o]);
@@ -915,13 +999,18 @@ __global__ __launch_bounds__(kBlock) void pmx_ode_rk4_grid(DevModel m, DevOps op
       const int io = static_cast<int>((meta >> 8) & 0xffffu);
       const double a = uniformf64(ops.op_a[o]);
       if (kind == OP_PROP) {
-        const double h = uniformf64(ops.op_b[o]);
-        const int32_t n = static_cast<int32_t>(uniform32(static_cast<uint32_t>(ops.op_n[o])));
         double rs[NS];
         ode_rates<MODEL>(m, ops.op_rate, o, ops.n_rate, rs);
-        for (int32_t k = 0; k < n; ++k) rk4_step<MODEL>(L.kp, x, rs, h);
+        if constexpr (LAG) {
+          ode_lag_prop<MODEL>(m, ops, ls, uniformf64(ops.op_t0[o]), uniformf64(ops.op_t1[o]), L.kp, rs, th, x);
+        } else {
+          const double h = uniformf64(ops.op_b[o]);
+          const int32_t n = static_cast<int32_t>(uniform32(static_cast<uint32_t>(ops.op_n[o])));
+          for (int32_t k = 0; k < n; ++k) rk4_step<MODEL>(L.kp, x, rs, h);
+        }
       } else if (kind == OP_OBS) {
-        const double y = ode_out<MODEL>(m, L, x, io);
+        double y = ode_out<MODEL>(m, L, x, io);
+        if (LAG && st == PMX_PAIR_BAD_LAG) y = nanv;
         if (ops.ll_obs != nullptr) {
           ll_accumulate(ops.ll_obs + row * 4, y, ll_acc);
         } else {
@@ -931,17 +1020,19 @@ __global__ __launch_bounds__(kBlock) void pmx_ode_rk4_grid(DevModel m, DevOps op
         ++row;
       } else if (kind == OP_BOLUS) {
         const int dest = (m.bolus_dest[io] >= 0) ? m.bolus_dest[io] : io;
-        const double amt = a * fa_of(m, theta + pc * m.nparams, io);
+        const double amt = a * fa_of(m, th, io);
 #pragma unroll
         for (int i = 0; i < NS; ++i) x[i] += (i == dest) ? amt : 0.0;
       } else {
 #pragma unroll
         for (int i = 0; i < NS; ++i) x[i] = io ? L.xinit[i] : 0.0;
+        if constexpr (LAG)
+          ode_lag_open_occasion<MODEL>(m, ops, ls, static_cast<int64_t>(a), uniformf64(ops.op_t0[o]), L.kp, th, x);
       }
     }
     if (ops.ll_obs != nullptr) {
       if (st == PMX_PAIR_OK && !isfinite(ll_acc)) st = PMX_PAIR_NONFINITE;
-      if (lane_ok) ops.ll_out[s * ops.ll_ld + p] = ll_acc;
+      if (lane_ok) ops.ll_out[s * ops.ll_ld + p] = (st == PMX_PAIR_OK || st == PMX_PAIR_NONFINITE) ? ll_acc : nanv;
     }
     if (status != nullptr && lane_ok && st != PMX_PAIR_OK) status[s * P + p] = st;  // array pre-zeroed by the library
   }
@@ -950,7 +1041,7 @@ __global__ __launch_bounds__(kBlock) void pmx_ode_rk4_grid(DevModel m, DevOps op
 // PAIR: each lane is a small state machine {cursor o, remaining RK4 steps}; one trip of the
 // wave loop performs either one RK4 step or one op per lane, so lanes in different segments
 // of different subjects still step in lock-step (divergent timelines, C4).
-template <int MODEL>
+template <int MODEL, bool LAG>
 __global__ __launch_bounds__(kBlock) void pmx_ode_rk4_pair(DevModel m, DevOps ops, const double* __restrict__ theta,
                                                            int64_t P, int64_t S, int32_t batch,
                                                            double* __restrict__ pred, int64_t ld,
@@ -963,8 +1054,24 @@ __global__ __launch_bounds__(kBlock) void pmx_ode_rk4_pair(DevModel m, DevOps op
   const int64_t ic = lane_ok ? i : (n_pairs - 1);
   const int64_t s = ops.subj_order[batch ? ic : (ic / P)];
   const int64_t p = batch ? 0 : (ic % P);
+  const double* __restrict__ th = theta + (batch ? s : p) * m.nparams;
   OdeLane<MODEL> L;
-  ode_lane_setup<MODEL>(m, theta + (batch ? s : p) * m.nparams, L);
+  ode_lane_setup<MODEL>(m, th, L);
+  uint8_t st = PMX_PAIR_OK;
+  LagState ls;
+  if constexpr (LAG) {
+#pragma unroll
+    for (int k = 0; k < kMaxLagSlots; ++k) {
+      ls.lag[k] = (k < m.n_lag_slots) ? th[m.lag_param[k]] : 0.0;
+      ls.cur[k] = ls.end[k] = 0;
+      if (k < m.n_lag_slots && !(ls.lag[k] >= 0.0)) {
+        st = PMX_PAIR_BAD_LAG;
+        ls.lag[k] = 0.0;
+      }
+    }
+  }
+  const double nanv = __longlong_as_double(0x7ff8000000000000LL);
+  const double inf = __longlong_as_double(0x7ff0000000000000LL);
 
   int64_t o = ops.subj_op_off[s];
   const int64_t o1 = lane_ok ? ops.subj_op_off[s + 1] : o;
@@ -978,44 +1085,99 @@ __global__ __launch_bounds__(kBlock) void pmx_ode_rk4_pair(DevModel m, DevOps op
   int32_t rem = 0;
   double h = 0.0;
   double ll_acc = 0.0;
-  uint8_t st = PMX_PAIR_OK;
+  // LAG: an open PROP (or occasion opening) [t_cur, t_stop) that lagged boluses may still split
+  bool in_prop = false;
+  double t_cur = 0.0, t_stop = 0.0;
   while (rem > 0 || o < o1) {
     if (rem > 0) {
       rk4_step<MODEL>(L.kp, x, rs, h);
       --rem;
-    } else {
-      const uint32_t meta = ops.op_meta[o];
-      const uint32_t kind = meta & 0xffu;
-      const int io = static_cast<int>((meta >> 8) & 0xffffu);
-      const double a = ops.op_a[o];
-      if (kind == OP_PROP) {
+      continue;
+    }
+    if constexpr (LAG) {
+      if (in_prop) {
+        int which;
+        const double tau = lag_next(m, ops, ls, which);
+        const bool bol = tau < t_stop;
+        const double stop = bol ? tau : t_stop;
+        if (stop > t_cur) {  // next sub-piece; n = ceil(dt / h_max) as ode_piece
+          const double dt = stop - t_cur;
+          double nf = ceil(dt / m.rk4_h_max);
+          if (!(nf >= 1.0)) nf = 1.0;
+          if (nf > 1.0e7) nf = 1.0e7;
+          rem = static_cast<int32_t>(nf);
+          h = dt / static_cast<double>(rem);
+          t_cur = stop;
+        } else if (bol) {
+          lag_apply_bolus<NS>(m, ops, ls, which, th, x);
+        } else {
+          in_prop = false;
+          ++o;
+        }
+        continue;
+      }
+    }
+    const uint32_t meta = ops.op_meta[o];
+    const uint32_t kind = meta & 0xffu;
+    const int io = static_cast<int>((meta >> 8) & 0xffffu);
+    const double a = ops.op_a[o];
+    if (kind == OP_PROP) {
+      ode_rates<MODEL>(m, ops.op_rate, o, ops.n_rate, rs);
+      if constexpr (LAG) {
+        in_prop = true;
+        t_cur = ops.op_t0[o];
+        t_stop = ops.op_t1[o];
+        continue;  // the open-PROP branch above walks it and advances o
+      } else {
         h = ops.op_b[o];
         rem = ops.op_n[o];
-        ode_rates<MODEL>(m, ops.op_rate, o, ops.n_rate, rs);
-      } else if (kind == OP_OBS) {
-        const double y = ode_out<MODEL>(m, L, x, io);
-        if (ops.ll_obs != nullptr) {
-          ll_accumulate(ops.ll_obs + row * 4, y, ll_acc);
-        } else {
-          if (st == PMX_PAIR_OK && !isfinite(y)) st = PMX_PAIR_NONFINITE;
-          pred[row * ld + p] = y;
-        }
-        ++row;
-      } else if (kind == OP_BOLUS) {
-        const int dest = (m.bolus_dest[io] >= 0) ? m.bolus_dest[io] : io;
-        const double amt = a * fa_of(m, theta + (batch ? s : p) * m.nparams, io);
-#pragma unroll
-        for (int j = 0; j < NS; ++j) x[j] += (j == dest) ? amt : 0.0;
-      } else {
-#pragma unroll
-        for (int j = 0; j < NS; ++j) x[j] = io ? L.xinit[j] : 0.0;
       }
-      ++o;
+    } else if (kind == OP_OBS) {
+      double y = ode_out<MODEL>(m, L, x, io);
+      if (LAG && st == PMX_PAIR_BAD_LAG) y = nanv;
+      if (ops.ll_obs != nullptr) {
+        ll_accumulate(ops.ll_obs + row * 4, y, ll_acc);
+      } else {
+        if (st == PMX_PAIR_OK && !isfinite(y)) st = PMX_PAIR_NONFINITE;
+        pred[row * ld + p] = y;
+      }
+      ++row;
+    } else if (kind == OP_BOLUS) {
+      const int dest = (m.bolus_dest[io] >= 0) ? m.bolus_dest[io] : io;
+      const double amt = a * fa_of(m, th, io);
+#pragma unroll
+      for (int j = 0; j < NS; ++j) x[j] += (j == dest) ? amt : 0.0;
+    } else {
+#pragma unroll
+      for (int j = 0; j < NS; ++j) x[j] = io ? L.xinit[j] : 0.0;
+      if constexpr (LAG) {
+        const int64_t occ = static_cast<int64_t>(a);
+#pragma unroll
+        for (int k = 0; k < kMaxLagSlots; ++k) {
+          if (k < m.n_lag_slots) {
+            ls.cur[k] = static_cast<int32_t>(ops.lagb_off[occ * m.n_lag_slots + k]);
+            ls.end[k] = static_cast<int32_t>(ops.lagb_off[occ * m.n_lag_slots + k + 1]);
+          }
+        }
+        // boluses landing before the occasion's first remaining event open the occasion (zero rates there)
+        int which;
+        const double tau = lag_next(m, ops, ls, which);
+        const double t_first = ops.op_t0[o];
+        if (tau < t_first && t_first < inf) {
+#pragma unroll
+          for (int j = 0; j < NS; ++j) rs[j] = 0.0;
+          in_prop = true;
+          t_cur = tau;
+          t_stop = t_first;
+          continue;
+        }
+      }
     }
+    ++o;
   }
   if (ops.ll_obs != nullptr) {
     if (st == PMX_PAIR_OK && !isfinite(ll_acc)) st = PMX_PAIR_NONFINITE;
-    if (lane_ok) ops.ll_out[batch ? s : (s * ops.ll_ld + p)] = ll_acc;
+    if (lane_ok) ops.ll_out[batch ? s : (s * ops.ll_ld + p)] = (st == PMX_PAIR_OK || st == PMX_PAIR_NONFINITE) ? ll_acc : nanv;
   }
   if (status != nullptr && lane_ok && st != PMX_PAIR_OK) status[batch ? s : (s * P + p)] = st;  // pre-zeroed
 }
@@ -1076,23 +1238,28 @@ hipError_t launch_analytical(const LaunchArgs& a, const char** name) {
   return hipGetLastError();
 }
 
-template <int MODEL>
-hipError_t launch_ode(const LaunchArgs& a, const char** name) {
+template <int MODEL, bool LAG>
+hipError_t launch_ode_l(const LaunchArgs& a, const char** name) {
   hipStream_t st = static_cast<hipStream_t>(a.stream);
   if (a.mode == MODE_GRID) {
-    *name = "pmx_ode_rk4_grid";
+    *name = LAG ? "pmx_ode_rk4_grid<lag>" : "pmx_ode_rk4_grid";
     const int64_t n_chunks = (a.S + a.s_chunk - 1) / a.s_chunk;
     const int64_t blocks = n_chunks * a.n_ptiles;
-    hipLaunchKernelGGL((pmx_ode_rk4_grid<MODEL>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlock), 0, st, a.m, a.ops,
+    hipLaunchKernelGGL((pmx_ode_rk4_grid<MODEL, LAG>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlock), 0, st, a.m, a.ops,
                        a.theta, a.P, a.S, a.s_chunk, a.n_ptiles, a.pred, a.ld, a.status);
   } else {
-    *name = "pmx_ode_rk4_pair";
+    *name = LAG ? "pmx_ode_rk4_pair<lag>" : "pmx_ode_rk4_pair";
     const int64_t n_pairs = a.batch ? a.S : a.S * a.P;
     const int64_t blocks = (n_pairs + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL((pmx_ode_rk4_pair<MODEL>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlock), 0, st, a.m, a.ops,
+    hipLaunchKernelGGL((pmx_ode_rk4_pair<MODEL, LAG>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlock), 0, st, a.m, a.ops,
                        a.theta, a.P, a.S, a.batch, a.pred, a.ld, a.status);
   }
   return hipGetLastError();
+}
+
+template <int MODEL>
+hipError_t launch_ode(const LaunchArgs& a, const char** name) {
+  return a.m.n_lag_slots > 0 ? launch_ode_l<MODEL, true>(a, name) : launch_ode_l<MODEL, false>(a, name);
 }
 
 template <int KID>

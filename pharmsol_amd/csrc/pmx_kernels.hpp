@@ -27,6 +27,8 @@ struct DevModel {
   int32_t has_fa;
   int32_t lag_input[4];               // slot -> input
   int32_t lag_param[4];               // slot -> theta index of the lag time
+  int32_t lag_dest[4];                // slot -> state that receives the bolus
+  double rk4_h_max;                   // ODE + lag: pieces split on the device recompute n = ceil(dt / h_max)
 };
 constexpr int kMaxLagSlots = 4;
 

@@ -349,7 +349,8 @@ class ODE(Equation):
 
     @staticmethod
     def new(diffeq: str, out: Dict[int, Ratio], *, nparams: int, init: Optional[Dict[int, int]] = None,
-            h_max: float = 0.02) -> "ODE":
+            lag: Optional[Dict[int, int]] = None, fa: Optional[Dict[int, int]] = None, h_max: float = 0.02) -> "ODE":
+        """``ODE::new(diffeq, lag, fa, init, out)`` (ode/mod.rs:115-132) with a built-in ``diffeq`` body."""
         m = ODE()
         if diffeq not in _abi.ODE_MODELS:
             raise KeyError(f"unknown built-in diffeq '{diffeq}'")
@@ -357,6 +358,8 @@ class ODE(Equation):
         m.out = dict(out)
         m.nparams = int(nparams)
         m.init = dict(init or {})
+        m.lag = {str(k): v for k, v in (lag or {}).items()}
+        m.fa = {str(k): v for k, v in (fa or {}).items()}
         m.rk4_h_max = float(h_max)
         return m
 
@@ -416,14 +419,14 @@ def analytical(*, name: str, params: Sequence[str], structure: str, states: Sequ
 
 
 def ode(*, name: str, params: Sequence[str], diffeq: str, states: Sequence[str], outputs: Sequence[str],
-        routes: Sequence[Route], out: Dict[str, Ratio], derived=None, covariates=None, init=None,
+        routes: Sequence[Route], out: Dict[str, Ratio], derived=None, covariates=None, init=None, lag=None, fa=None,
         h_max: float = 0.02) -> ODE:
     """The ``ode!`` declaration with a built-in ``diffeq`` body (e.g. examples/ode_readme.rs:9-23)."""
     m = ODE()
     if diffeq not in _abi.ODE_MODELS:
         raise KeyError(f"unknown built-in diffeq '{diffeq}'")
     m.kernel_name = diffeq
-    _declare(m, name, params, derived, covariates, states, outputs, routes, out, init, None, None)
+    _declare(m, name, params, derived, covariates, states, outputs, routes, out, init, lag, fa)
     if len(m.states) != _abi.ODE_STATE_COUNT[diffeq]:
         raise ValueError(f"diffeq {diffeq} has {_abi.ODE_STATE_COUNT[diffeq]} states, {len(m.states)} declared")
     m.rk4_h_max = float(h_max)

@@ -288,6 +288,41 @@ def test_bioavailability_alone_and_on_ode():
     assert_parity(mo, mo.flatten(Data(subs)), th, TOL_ODE, expect_kernel="pmx_ode_rk4_grid")
 
 
+@pytest.mark.parametrize("n_support,batch", [(70, False), (3, False), (0, True)])
+def test_ode_lag_time_and_bioavailability(n_support, batch):
+    """The ODE back-end's lagged boluses (ode/mod.rs:609-823 over the re-sorted list, structs.rs:611-666): a landing
+    bolus splits the RK4 piece it falls in, and both halves re-derive their step count."""
+    from pharmsol_amd import ODE
+
+    rng = np.random.default_rng(91)
+    m = ODE.new("one_cmt_oral", {0: Ratio(1, 2)}, nparams=5, lag={0: 3}, fa={0: 4}, h_max=0.02).with_nstates(2).with_ndrugs(
+        1).with_nout(1)
+    # one_cmt_oral: infusions go to the central state, boluses to the depot (index = input)
+    subs = _lag_subjects(rng, 50)
+    flat = m.flatten(Data(subs))
+    n = len(subs) if batch else n_support
+    th = np.stack([rng.uniform(1.0, 2.0, n), rng.uniform(0.05, 0.3, n), rng.uniform(10, 50, n),
+                   np.round(rng.uniform(0, 3, n) * 2) / 2, rng.uniform(0.3, 1.0, n)], axis=1)
+    th[0, 3] = 0.0
+    kernel = "pmx_ode_rk4_pair<lag>" if (batch or n_support < 32) else "pmx_ode_rk4_grid<lag>"
+    assert_parity(m, flat, th, TOL_ODE, batch=batch, expect_kernel=kernel)
+
+
+def test_ode_two_lagged_inputs_and_negative_lag():
+    from pharmsol_amd import ODE
+
+    rng = np.random.default_rng(92)
+    m = ODE.new("two_cmt_iv", {0: Ratio(0, 3)}, nparams=6, lag={0: 4, 1: 5}, h_max=0.02).with_nstates(2).with_ndrugs(
+        2).with_nout(1)
+    flat = m.flatten(Data(_lag_subjects(rng, 30, two_inputs=True)))
+    th = np.concatenate([synth.theta_c3(64), rng.uniform(0, 2.5, (64, 2))], axis=1)
+    assert_parity(m, flat, th, TOL_ODE, expect_kernel="pmx_ode_rk4_grid<lag>")
+    th[5, 4] = -1.0
+    got, st = gpu_predict(m, flat, th)
+    assert (st[:, 5] == _abi.PMX_PAIR_BAD_LAG).all() and np.isnan(got[:, 5]).all()
+    assert (np.delete(st, 5, axis=1) == 0).all()
+
+
 def test_negative_lag_is_flagged():
     m = Analytical.new("one_compartment", {0: Ratio(0, 1)}, nparams=3, lag={0: 2}).with_nstates(1).with_ndrugs(1).with_nout(1)
     s = Subject.builder("neg").bolus(1.0, 10.0, 0).missing_observation(2.0, 0).build()

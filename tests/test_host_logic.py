@@ -202,7 +202,9 @@ def test_model_validation_errors():
     assert create(d) == _abi.PMX_ERR_UNSUPPORTED
     d = models.handwritten_ode("one_cmt_iv", 0, 2).desc()
     d.lag_param[0] = 1
-    assert create(d) == _abi.PMX_ERR_UNSUPPORTED
+    assert create(d) == _abi.PMX_OK  # ODE lag: RK4 pieces split per lane on the device
+    d.lag_param[0] = 2
+    assert create(d) == _abi.PMX_ERR_INVALID_ARGUMENT
     d = models.handwritten_ode("one_cmt_iv", 0, 2).desc()
     d.rk4_h_max = 0.0
     assert create(d) == _abi.PMX_ERR_INVALID_ARGUMENT
