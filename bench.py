@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--no-status", action="store_true", help="do not write the per-pair status bytes")
     ap.add_argument("--loglik", action="store_true",
                     help="time the fused log-likelihood entry (pmx_loglik_device) instead of predictions: output S x P")
+    ap.add_argument("--ld", type=int, default=0, help="leading dimension of the prediction rows (>= support points; 0 = dense)")
     ap.add_argument("--no-class", action="store_true",
                     help="A/B: disable the classed kernel (shared-design propagator reuse); every subject walks the generic kernel")
     args = ap.parse_args()
@@ -144,8 +145,12 @@ def main():
     pop = runtime.DevicePopulation(flat, device_index)
     d_theta = torch.as_tensor(np.ascontiguousarray(theta), device=dev)
     n_obs = pop.n_observations
-    pred = torch.empty((n_obs,) if batch else ((pop.n_subjects, P) if args.loglik else (n_obs, P)), dtype=torch.float64,
-                       device=dev)
+    ld = max(args.ld, P) if (args.ld and not batch and not args.loglik) else None
+    if ld is not None:  # rows padded to a leading dimension (ld_pred of pmx_predict_device); same bytes written
+        pred = torch.empty((n_obs, ld), dtype=torch.float64, device=dev)[:, :P]
+    else:
+        pred = torch.empty((n_obs,) if batch else ((pop.n_subjects, P) if args.loglik else (n_obs, P)),
+                           dtype=torch.float64, device=dev)
     em_c = em.to_c(model) if em is not None else None
     status = None if args.no_status else torch.zeros((pop.n_subjects,) if batch else (pop.n_subjects, P),
                                                      dtype=torch.uint8, device=dev)

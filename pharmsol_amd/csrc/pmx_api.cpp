@@ -281,6 +281,8 @@ pmx::CompileKey key_for(const pmx_model* m) {
       if (m->d.lag_param[i] >= 0) k.lag_mask |= (1u << i);
       if (m->d.fa_param[i] >= 0) has_fa = true;  // per-lane bolus amounts: the classed kernel's values are wave-uniform
     }
+    const char* nl = std::getenv("PMX_DISABLE_LADDER");  // fresh exp() on every step (A/B and parity checks)
+    k.ladder = !m->dyn && k.lag_mask == 0 && !(nl && nl[0] && nl[0] != '0');
     const char* off = std::getenv("PMX_DISABLE_CLASSING");
     const bool disabled = off && off[0] && off[0] != '0';
     if (!disabled && !m->dyn && !m->d.pmetrics_indexing && m->d.n_covariates == 0 && k.lag_mask == 0 && !has_fa) {
@@ -332,7 +334,7 @@ int32_t get_stream(pmx_population* pop, const pmx::CompileKey& key, DeviceStream
   ds->dev.n_rate = key.n_rate;
   if (key.class_g > 0) {
     pmx::ClassPlan cp;
-    pmx::build_class_plan(pop->hp, os, key.class_g, key.class_g / 2, &cp);
+    pmx::build_class_plan(pop->hp, os, key.class_g, key.class_g / 2, &cp, key.ladder);
     if (cp.n_chunks > 0) {
       if ((rc = upload(cp.prog_meta, &ds->cls.prog_meta, &ds->allocs)) != PMX_OK) return rc;
       if ((rc = upload(cp.prog_dt, &ds->cls.prog_dt, &ds->allocs)) != PMX_OK) return rc;

@@ -390,6 +390,11 @@ int32_t compile_ops(const HostPopulation& hp, const CompileKey& key, OpStream* o
       }
     }
     os->subj_op_off[s + 1] = static_cast<int64_t>(os->op_meta.size());
+    if (key.ladder && !ode) {  // exponential ladder along the subject's PROP ops (the lane's rate constants never change)
+      double prev = 0.0, span = 1.0;
+      for (int64_t o = os->subj_op_off[s]; o < os->subj_op_off[s + 1]; ++o)
+        if ((os->op_meta[o] & 0xffu) == OP_PROP) os->op_meta[o] |= ladder_code(os->op_a[o], &prev, &span) << 27;
+    }
   }
   if (cov_missing) {
     *err = "covariate interpolation failed (MissingSegments)";
@@ -432,7 +437,28 @@ inline uint64_t mix64(uint64_t h, uint64_t v) {
 }
 }  // namespace
 
-void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, int32_t min_class_size, ClassPlan* cp) {
+uint32_t ladder_code(double dt, double* prev, double* span) {
+  uint32_t code = 0;
+  if (*prev > 0.0 && dt > 0.0) {
+    for (uint32_t n = 1; n <= 4; ++n) {
+      if (std::fabs(dt - n * *prev) <= 8.0 * std::numeric_limits<double>::epsilon() * dt && *span * n <= 1024.0) {
+        code = n;
+        break;
+      }
+    }
+  }
+  if (code) {
+    *span *= code;
+    *prev = code * *prev;
+  } else {
+    *span = 1.0;
+    *prev = dt;
+  }
+  return code;
+}
+
+void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, int32_t min_class_size, ClassPlan* cp,
+                      bool ladder) {
   *cp = ClassPlan{};
   cp->G = G;
   const int64_t S = hp.n_subjects;
@@ -486,7 +512,7 @@ void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, i
     }
     const int64_t r0 = os.subj_op_off[cls_rep[c]], r1 = os.subj_op_off[cls_rep[c] + 1];
     // Program steps: every OBS op is FUSED into the step before it (bit 24 = "emit a row after this step",
-    // bits 25.. = its outeq), so a PROP+OBS pair costs one trip of the device loop.  A second observation
+    // bits 25-26 = its outeq), so a PROP+OBS pair costs one trip of the device loop.  A second observation
     // at the same instant gets a step of its own (kind OP_OBS = no state change).
     std::vector<int32_t> step_of_op(static_cast<size_t>(r1 - r0), -1);
     std::vector<uint32_t> step_meta;
@@ -496,9 +522,9 @@ void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, i
       const uint32_t io = (os.op_meta[o] >> 8) & 0xffffu;
       if (kind == OP_OBS) {
         if (!step_meta.empty() && ((step_meta.back() >> 24) & 1u) == 0u) {
-          step_meta.back() |= (1u << 24) | (io << 25);
+          step_meta.back() |= (1u << 24) | ((io & 3u) << 25);
         } else {
-          step_meta.push_back(make_meta(OP_OBS, 0) | (1u << 24) | (io << 25));
+          step_meta.push_back(make_meta(OP_OBS, 0) | (1u << 24) | ((io & 3u) << 25));
           step_dt.push_back(0.0);
         }
       } else {
@@ -508,6 +534,16 @@ void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, i
       }
     }
     const int64_t L = static_cast<int64_t>(step_meta.size());
+    if (ladder) {
+      // Exponential ladder (pmx_structures.hpp ladder_pow): bits 27-29 of a PROP step = n when its length is
+      // n x the previous PROP's (n = 1: same propagator again).  `span` = how many times the first rung's
+      // rounding error has been multiplied; past 1024 the next step starts a fresh ladder.
+      double prev = 0.0, span = 1.0;
+      for (int64_t i = 0; i < L; ++i) {
+        if ((step_meta[static_cast<size_t>(i)] & 0xffu) != OP_PROP) continue;
+        step_meta[static_cast<size_t>(i)] |= ladder_code(step_dt[static_cast<size_t>(i)], &prev, &span) << 27;
+      }
+    }
     for (int64_t i = 0; i < L; ++i) {
       cp->prog_meta.push_back(step_meta[static_cast<size_t>(i)]);
       cp->prog_dt.push_back(step_dt[static_cast<size_t>(i)]);

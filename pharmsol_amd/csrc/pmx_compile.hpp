@@ -65,9 +65,12 @@ struct CompileKey {
   int32_t class_g = 0;     // analytical GRID: members per chunk of the classed kernel (0 = no class plan)
   uint32_t lag_mask = 0;   // bit i: boluses on input i are delayed by a theta-dependent lag -> kept OUT of the
                            // op stream and merged per lane on the device (Occasion::add_lagtime, structs.rs:611-643)
+  bool ladder = false;     // analytical, theta-only coefficients, no lag: PROP ops carry the exponential-ladder code
+                           // (bits 27-29 of op_meta, pmx_structures.hpp ladder_pow)
   bool operator==(const CompileKey& o) const {
     return eq_kind == o.eq_kind && cov_time_mode == o.cov_time_mode && rk4_h_max == o.rk4_h_max &&
-           n_rate == o.n_rate && rate_input == o.rate_input && class_g == o.class_g && lag_mask == o.lag_mask;
+           n_rate == o.n_rate && rate_input == o.rate_input && class_g == o.class_g && lag_mask == o.lag_mask &&
+           ladder == o.ladder;
   }
 };
 
@@ -121,7 +124,13 @@ struct ClassPlan {
 
 // Group the subjects of an analytical op stream into classes; classes with fewer than
 // `min_class_size` members stay generic.
-void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, int32_t min_class_size, ClassPlan* out);
+// Exponential-ladder code of a PROP of length dt that follows a PROP whose exponentials are live:
+// n in 1..4 when dt == n * prev (within 8 ulp) and the accumulated error factor stays <= 1024, else 0 (fresh
+// exp()).  Updates prev/span to describe the exponentials after this step.
+uint32_t ladder_code(double dt, double* prev, double* span);
+
+void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, int32_t min_class_size, ClassPlan* out,
+                      bool ladder = true);
 
 // Validate + copy + sort (Occasion::sort, structs.rs:669-671) + build covariate segments.
 // Returns PMX_OK or an error with `err` filled.

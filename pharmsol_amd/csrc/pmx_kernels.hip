@@ -23,6 +23,8 @@
 // ode/mod.rs:609-823 (ODE event loop; diffsol replaced by fixed-step RK4).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include <cmath>
 #include <cstdint>
 
@@ -327,6 +329,9 @@ __global__ __launch_bounds__(kBlock) void pmx_analytical_grid(DevModel m, DevOps
   }
   const uint8_t st_lane = st_lane0;
   const double nanv = __longlong_as_double(0x7ff8000000000000LL);
+  double ex[LM::S::NE];  // the lane's exponentials of the last PROP (ladder)
+#pragma unroll
+  for (int i = 0; i < LM::S::NE; ++i) ex[i] = 0.0;
 
   // the op stream is read-only for the launch and indexed wave-uniformly: constant-address-space pointers
   // turn these into scalar (s_load) fetches
@@ -366,8 +371,19 @@ __global__ __launch_bounds__(kBlock) void pmx_analytical_grid(DevModel m, DevOps
         }
         if constexpr (LAG) {
           lag_prop<LM::ST, NS>(m, ops, ls, c_op_t0[o], c_op_t1[o], r, L.coef, th, x);
-        } else {
+        } else if constexpr (DYN) {
           advance<LM::ST>(L.coef, x, a, r);
+        } else {
+          // exponential ladder (pmx_compile.cpp ladder_code): bits 27-29 relate this PROP's length to the previous one's
+          const uint32_t rung = (meta >> 27) & 7u;
+          if (rung == 0u) {
+            LM::S::exps(L.coef, a, ex);
+          } else if (rung != 1u) {
+            ladder_pow<LM::S::NE>(ex, rung);
+          }
+          typename LM::S::Prop pr;
+          LM::S::from_exps(L.coef, ex, pr);
+          LM::S::apply(pr, x, r);
         }
         xpad = 0.0;  // pm_* wrappers re-pad slot 0 with 0 after every kernel call (analytical/mod.rs:70-75)
       } else if (kind == OP_OBS) {
@@ -444,7 +460,13 @@ __device__ __forceinline__ void classed_emit(const double (&x)[G][NS], double in
       v.y = __longlong_as_double(static_cast<int64_t>((static_cast<uint64_t>(r1[1]) << 32) | r0[1]));
       const bool row_live = (2 * h + 1 < n_live) || !upper;  // the last pair of a partial chunk has no member B
       double* dst = slot[h] + kld;
-      if (row_live && pair_full) *reinterpret_cast<double2*>(dst) = v;
+      if (row_live && pair_full) {
+        typedef double dbl2 __attribute__((ext_vector_type(2)));
+        dbl2 vv;
+        vv.x = v.x;
+        vv.y = v.y;
+        __builtin_nontemporal_store(vv, reinterpret_cast<dbl2*>(dst));
+      }
       if (any_half) {  // wave-uniform: only the wave holding the last slot of an odd-length row
         if (row_live && pair_half) *dst = v.x;
       }
@@ -554,14 +576,22 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
 #pragma unroll
       for (int i = 0; i < NS; ++i) x[j][i] = 0.0;
     uint32_t bad = 0;  // bit j: member j emitted a non-finite prediction
+    // the lane's exponentials outlive a step: bits 27-29 of a PROP step say how this step's length relates
+    // to the previous PROP's (0 = unrelated: exp(); 1 = equal; n = 2..4: n times as long: ladder_pow)
+    double ex[LM::S::NE];
     for (int64_t o = pb; o < pe; ++o, voff += G) {
       const uint32_t meta = prog_meta[o];
       const uint32_t kind = meta & 0xffu;
       const int io = static_cast<int>((meta >> 8) & 0xffffu);
       if (kind == OP_PROP) {
-        const double dt = prog_dt[o];
+        const uint32_t rung = (meta >> 27) & 7u;
+        if (rung == 0u) {
+          LM::S::exps(coef, prog_dt[o], ex);
+        } else if (rung != 1u) {
+          ladder_pow<LM::S::NE>(ex, rung);
+        }
         typename LM::S::Prop pr;
-        LM::S::make_prop(coef, dt, pr);
+        LM::S::from_exps(coef, ex, pr);
 #pragma unroll
         for (int j = 0; j < G; ++j) {
           LM::S::apply(pr, x[j], val[voff + j]);
@@ -586,7 +616,7 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
         }
       }  // (kind == OP_OBS: a second observation at the same instant, no state change)
       if ((meta >> 24) & 1u) {  // the observation fused into this step (pmx_compile.cpp build_class_plan)
-        const int oq = static_cast<int>(meta >> 25);
+        const int oq = static_cast<int>((meta >> 25) & 3u);
         int out_state = m.out[0].state;
         double inv_vol = inv_vol0;
         if (oq != 0) {  // outputs beyond the first: rare, re-derive the volume instead of keeping 4 live
@@ -1201,6 +1231,7 @@ hipError_t launch_analytical(const LaunchArgs& a, const char** name) {
         int64_t cpb = (a.cls.n_chunks * a.n_ptiles) / 8192;
         if (cpb < 1) cpb = 1;
         if (cpb > 8) cpb = 8;
+        if (const char* e = std::getenv("PMX_TUNE_CPB")) cpb = std::atoi(e) > 0 ? std::atoi(e) : cpb;  // tuning experiments
         const int64_t cblocks = ((a.cls.n_chunks + cpb - 1) / cpb + 7) / 8 * 8;  // whole XCD groups
         if (a.ops.ll_obs != nullptr) {
           *name = "pmx_analytical_classed<ll>";

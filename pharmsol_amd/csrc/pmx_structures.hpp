@@ -103,8 +103,10 @@ struct Structure<S_ONE> {
     c.inv_ke = 1.0 / kp[0];
     return true;
   }
-  __device__ __forceinline__ static void make_prop(const Coef& c, double dt, Prop& p) {
-    p.e = exp(-c.ke * dt);
+  static constexpr int NE = 1;
+  __device__ __forceinline__ static void exps(const Coef& c, double dt, double (&e)[NE]) { e[0] = exp(-c.ke * dt); }
+  __device__ __forceinline__ static void from_exps(const Coef& c, const double (&e)[NE], Prop& p) {
+    p.e = e[0];
     p.j = c.inv_ke * (1.0 - p.e);
   }
   __device__ __forceinline__ static void apply(const Prop& p, double (&x)[NS], double r) {
@@ -128,9 +130,14 @@ struct Structure<S_ONE_ABS> {
     c.ka_over = kp[0] / (kp[0] - kp[1]);
     return true;
   }
-  __device__ __forceinline__ static void make_prop(const Coef& c, double dt, Prop& p) {
-    p.ea = exp(-c.ka * dt);
-    p.ee = exp(-c.ke * dt);
+  static constexpr int NE = 2;
+  __device__ __forceinline__ static void exps(const Coef& c, double dt, double (&e)[NE]) {
+    e[0] = exp(-c.ka * dt);
+    e[1] = exp(-c.ke * dt);
+  }
+  __device__ __forceinline__ static void from_exps(const Coef& c, const double (&e)[NE], Prop& p) {
+    p.ea = e[0];
+    p.ee = e[1];
     p.j = c.inv_ke * (1.0 - p.ee);
     p.g = c.ka_over * (p.ee - p.ea);
   }
@@ -192,8 +199,13 @@ struct Structure<S_TWO> {
     TwoProp p;
   };
   __device__ __forceinline__ static bool prepare(const double* kp, Coef& c) { return c.t.prepare(kp[0], kp[1], kp[2]); }
-  __device__ __forceinline__ static void make_prop(const Coef& c, double dt, Prop& p) {
-    p.p.make(c.t, exp(-c.t.l1 * dt), exp(-c.t.l2 * dt));
+  static constexpr int NE = 2;
+  __device__ __forceinline__ static void exps(const Coef& c, double dt, double (&e)[NE]) {
+    e[0] = exp(-c.t.l1 * dt);
+    e[1] = exp(-c.t.l2 * dt);
+  }
+  __device__ __forceinline__ static void from_exps(const Coef& c, const double (&e)[NE], Prop& p) {
+    p.p.make(c.t, e[0], e[1]);
   }
   __device__ __forceinline__ static void apply(const Prop& q, double (&x)[NS], double r) {
     const TwoProp& p = q.p;
@@ -226,10 +238,16 @@ struct Structure<S_TWO_ABS> {
     c.a1b = c.t.kcp * r2;
     return ok;
   }
-  __device__ __forceinline__ static void make_prop(const Coef& c, double dt, Prop& p) {
-    const double e1 = exp(-c.t.l1 * dt);
-    const double e2 = exp(-c.t.l2 * dt);
-    p.ea = exp(-c.ka * dt);
+  static constexpr int NE = 3;
+  __device__ __forceinline__ static void exps(const Coef& c, double dt, double (&e)[NE]) {
+    e[0] = exp(-c.t.l1 * dt);
+    e[1] = exp(-c.t.l2 * dt);
+    e[2] = exp(-c.ka * dt);
+  }
+  __device__ __forceinline__ static void from_exps(const Coef& c, const double (&e)[NE], Prop& p) {
+    const double e1 = e[0];
+    const double e2 = e[1];
+    p.ea = e[2];
     p.p.make(c.t, e1, e2);
     const double h = c.ka * c.t.inv_d;  // ka * x[0] / (l1 - l2)  (:103)
     const double d1 = e1 - p.ea, d2 = e2 - p.ea;
@@ -319,12 +337,12 @@ struct Structure<S_THREE> {
   __device__ __forceinline__ static bool prepare(const double* kp, Coef& c) {
     return c.t.prepare(kp[0], kp[1], kp[2], kp[3], kp[4]);
   }
-  __device__ __forceinline__ static void make_prop(const Coef& c, double dt, Prop& p) {
-    double e[3];
+  static constexpr int NE = 3;
+  __device__ __forceinline__ static void exps(const Coef& c, double dt, double (&e)[NE]) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) e[i] = exp(-(c.t.l[i] * dt));
-    p.p.make(c.t, e);
   }
+  __device__ __forceinline__ static void from_exps(const Coef& c, const double (&e)[NE], Prop& p) { p.p.make(c.t, e); }
   __device__ __forceinline__ static void apply(const Prop& q, double (&x)[NS], double r) {
     const ThreeProp& p = q.p;
     const double y0 = p.m[0] * x[0] + p.m[1] * x[1] + p.m[2] * x[2] + p.j[0] * r;
@@ -360,11 +378,15 @@ struct Structure<S_THREE_ABS> {
     }
     return ok;
   }
-  __device__ __forceinline__ static void make_prop(const Coef& c, double dt, Prop& p) {
-    double e[3];
+  static constexpr int NE = 4;
+  __device__ __forceinline__ static void exps(const Coef& c, double dt, double (&e4)[NE]) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) e[i] = exp(-(c.t.l[i] * dt));
-    p.ea = exp(-c.ka * dt);
+    for (int i = 0; i < 3; ++i) e4[i] = exp(-(c.t.l[i] * dt));
+    e4[3] = exp(-c.ka * dt);
+  }
+  __device__ __forceinline__ static void from_exps(const Coef& c, const double (&e4)[NE], Prop& p) {
+    const double e[3] = {e4[0], e4[1], e4[2]};
+    p.ea = e4[3];
     p.p.make(c.t, e);
     const double d0 = e[0] - p.ea, d1 = e[1] - p.ea, d2 = e[2] - p.ea;
 #pragma unroll
@@ -383,12 +405,34 @@ struct Structure<S_THREE_ABS> {
   }
 };
 
+// make_prop = the exp() calls + the coefficient combination
+template <int ST>
+__device__ __forceinline__ void make_prop(const typename Structure<ST>::Coef& c, double dt, typename Structure<ST>::Prop& p) {
+  double e[Structure<ST>::NE];
+  Structure<ST>::exps(c, dt, e);
+  Structure<ST>::from_exps(c, e, p);
+}
+
+// The exponential ladder: when a step's length is n x the previous step's (n = 2, 3, 4; sampling designs on
+// 0.5/1/2/4/8/12/24 h grids are exactly that), exp(-lambda n dt) = exp(-lambda dt)^n costs n-1 multiplies instead of
+// an exp() call.  Each rung multiplies the relative error of the previous one by n; the host caps the
+// cumulative factor (pmx_compile.cpp ladder_codes), which keeps the deviation from a fresh exp() below 1e-12.
+template <int NE>
+__device__ __forceinline__ void ladder_pow(double (&e)[NE], uint32_t n) {
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const double b = e[i];
+    const double sq = b * b;
+    e[i] = (n == 2u) ? sq : ((n == 3u) ? sq * b : sq * sq);
+  }
+}
+
 // advance = make_prop + apply (one sub-segment of Analytical::solve, analytical/mod.rs:363-364)
 template <int ST>
 __device__ __forceinline__ void advance(const typename Structure<ST>::Coef& c, double (&x)[Structure<ST>::NS], double dt,
                                         double r) {
   typename Structure<ST>::Prop p;
-  Structure<ST>::make_prop(c, dt, p);
+  make_prop<ST>(c, dt, p);
   Structure<ST>::apply(p, x, r);
 }
 

@@ -333,6 +333,42 @@ def test_negative_lag_is_flagged():
     assert (np.delete(st, 7, axis=1) == 0).all() and np.isfinite(np.delete(got, 7, axis=1)).all()
 
 
+@pytest.mark.parametrize("structure,nparams,central", [("one_compartment", 2, 0), ("two_compartments", 4, 0),
+                                                       ("two_compartments_with_absorption", 5, 1),
+                                                       ("three_compartments", 6, 0)])
+def test_exponential_ladder_designs(structure, nparams, central):
+    """Steps whose length is 1x/2x/3x/4x the previous step's reuse its exponentials (exp(-l n dt) = exp(-l dt)^n,
+    pmx_structures.hpp ladder_pow).  Long doubling chains, equal steps, a 3x and a 4x rung, a chain long enough to hit
+    the restart cap: still ~1e-12 from the oracle, which calls exp() on every segment like the reference."""
+    rng = np.random.default_rng(5)
+    m = models.handwritten_analytical(structure, central, nparams)
+    times = [0.03125 * 2 ** k for k in range(14)]          # dt doubles 12 times: the cap (x1024) restarts the ladder
+    times += [times[-1] + 6.0 * (k + 1) for k in range(5)]  # equal steps
+    times += [times[-1] + 18.0, times[-1] + 18.0 + 24.0]    # x3, then 24 = 4/3 x 18: unrelated -> fresh exp
+    times += [times[-1] + 96.0]                             # x4
+    subs = []
+    for i in range(24):  # shared design -> classed kernel
+        b = Subject.builder(f"d{i}").bolus(0.0, float(rng.uniform(50, 500)), 0).infusion(0.0, float(rng.uniform(50, 500)), 0, 0.03125)
+        for t in times:
+            b = b.missing_observation(t, 0)
+        subs.append(b.build())
+    for i in range(5):  # ragged -> generic GRID kernel, same ladder along each subject's own PROP ops
+        b = Subject.builder(f"r{i}").bolus(0.0, 100.0, 0)
+        for t in times[: 9 + 3 * i]:
+            b = b.missing_observation(t, 0)
+        subs.append(b.build())
+    flat = m.flatten(Data(subs))
+    lo = np.array([0.02, 0.01, 0.01, 10, 1, 1])[:nparams]
+    hi = np.array([0.5, 0.5, 0.5, 100, 2, 2])[:nparams]
+    th = np.exp(rng.uniform(np.log(lo), np.log(hi), (64, nparams)))
+    if structure == "three_compartments":
+        th = synth.theta_c5(64)[:, 1:7]  # k10,k12,k13,k21,k31,v: draws with real eigenvalues
+    if structure == "two_compartments_with_absorption":
+        th = np.concatenate([synth.theta_c3(64)[:, :1], rng.uniform(0.8, 3.0, (64, 1)), synth.theta_c3(64)[:, 1:]], axis=1)
+    assert_parity(m, flat, th, 2e-11, expect_kernel="pmx_analytical_classed")  # (+ the generic kernel on the ragged five)
+    assert_parity(m, m.flatten(Data(subs[24:])), th, 2e-11, expect_kernel="pmx_analytical_grid")
+
+
 def test_pmetrics_one_based_wrappers():
     # pm_* kernels: state/rateiv slot 0 is a dead pad (analytical/mod.rs:62-90)
     m = Analytical.new("pm_two_compartments", {0: Ratio(1, 3)}, nparams=4).with_nstates(3).with_ndrugs(2).with_nout(1)

@@ -1,0 +1,232 @@
+// store_pattern_probe.hip — which geometry of the prediction write stream does MI355X like?
+// Stand-alone micro-benchmark (not part of the library): writes the C3 prediction matrix
+// (700 000 rows x 1000 doubles = 5.6 GB) with different wave->address maps and prints TB/s for each.
+//   build: hipcc --offload-arch=gfx950 -O3 -o gpurun_out/store_probe tools/store_pattern_probe.hip
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+#define CK(x)                                                                  \
+  do {                                                                         \
+    hipError_t e_ = (x);                                                       \
+    if (e_ != hipSuccess) {                                                    \
+      std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));             \
+      std::exit(1);                                                            \
+    }                                                                          \
+  } while (0)
+
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+
+constexpr int64_t S = 100000, O = 7, P = 1000, G = 8;
+constexpr int64_t ROWS = S * O;
+
+template <bool NT>
+__device__ __forceinline__ void st16(double* p, double a, double b) {
+  dbl2 v;
+  v.x = a;
+  v.y = b;
+  if (NT)
+    __builtin_nontemporal_store(v, reinterpret_cast<dbl2*>(p));
+  else
+    *reinterpret_cast<dbl2*>(p) = v;
+}
+
+// A: linear fill, 16 B per lane, grid-stride
+template <bool NT>
+__global__ __launch_bounds__(256) void k_linear(double* out, int64_t n2) {
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n2; i += gridDim.x * 256ll) st16<NT>(out + 2 * i, 1.0, 2.0);
+}
+
+// A2: one 16 B store per lane, no loop, huge grid
+template <bool NT>
+__global__ __launch_bounds__(256) void k_linear1(double* out, int64_t n2) {
+  const int64_t i = blockIdx.x * 256ll + threadIdx.x;
+  if (i < n2) st16<NT>(out + 2 * i, 1.0, 2.0);
+}
+// A3: 4 x 16 B per lane, each wave-store 1 KB contiguous, block writes 16 KB contiguous, no loop
+template <bool NT>
+__global__ __launch_bounds__(256) void k_linear4(double* out, int64_t n2) {
+  const int64_t base = blockIdx.x * 1024ll;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t i = base + j * 256 + threadIdx.x;
+    if (i < n2) st16<NT>(out + 2 * i, 1.0, 2.0);
+  }
+}
+// A4: 32 B per lane adjacent (two dwordx4 back to back per lane, the elementwise-kernel shape)
+template <bool NT>
+__global__ __launch_bounds__(256) void k_linear32(double* out, int64_t n2) {
+  const int64_t i = (blockIdx.x * 256ll + threadIdx.x) * 2;
+  if (i + 1 < n2) {
+    st16<NT>(out + 2 * i, 1.0, 2.0);
+    st16<NT>(out + 2 * i + 2, 1.0, 2.0);
+  }
+}
+
+// B: the classed kernel's map.  block -> (chunk-block, ptile of 256 p); per chunk: 7 obs x 4 member pairs;
+// lanes 0-31 write member 2h's row, lanes 32-63 member 2h+1's row, 16 B per lane (two adjacent p).
+// ROWMAJOR_SUBJ: row = subject*7 + obs (the ABI's order).  else obs-major: row = obs*S + subject.
+template <bool NT, bool OBS_MAJOR, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_classed(double* out, int64_t n_chunks, int cpb, int n_ptiles, int delay) {
+  const int64_t b = blockIdx.x;
+  const int64_t group = b / (8 * n_ptiles);
+  const int local = static_cast<int>(b % (8 * n_ptiles));
+  const int ptile = local / 8;
+  const int64_t cblock = group * 8 + (local % 8);
+  const unsigned lane = threadIdx.x & 63u;
+  const bool upper = lane >= 32u;
+  const int64_t p_even = static_cast<int64_t>(ptile) * BLOCK + (threadIdx.x & ~63u) + 2u * (lane & 31u);
+  const bool ok = p_even + 1 < P;
+  double acc = static_cast<double>(threadIdx.x);
+  for (int64_t c = cblock * cpb; c < (cblock + 1) * cpb && c < n_chunks; ++c) {
+    for (int k = 0; k < O; ++k) {
+      for (int d = 0; d < delay; ++d) acc = fma(acc, 1.0000001, 0.5);  // stand-in for the propagator math
+#pragma unroll
+      for (int h = 0; h < G / 2; ++h) {
+        const int64_t subj = c * G + 2 * h + (upper ? 1 : 0);
+        const int64_t row = OBS_MAJOR ? (k * S + subj) : (subj * O + k);
+        if (ok) st16<NT>(out + row * P + p_even, acc, acc);
+      }
+    }
+  }
+}
+
+// F/G: subject-major rows (the ABI's order) but KB rows of a member are written back to back
+// (KB = 2: pairs of observations; KB = 7: a member's whole block of rows) — what staging predictions of
+// several steps before storing them would produce.
+template <bool NT, int KB>
+__global__ __launch_bounds__(256) void k_classed_kb(double* out, int64_t n_chunks, int cpb, int n_ptiles) {
+  const int64_t b = blockIdx.x;
+  const int64_t group = b / (8 * n_ptiles);
+  const int local = static_cast<int>(b % (8 * n_ptiles));
+  const int ptile = local / 8;
+  const int64_t cblock = group * 8 + (local % 8);
+  const unsigned lane = threadIdx.x & 63u;
+  const bool upper = lane >= 32u;
+  const int64_t p_even = static_cast<int64_t>(ptile) * 256 + (threadIdx.x & ~63u) + 2u * (lane & 31u);
+  const bool ok = p_even + 1 < P;
+  for (int64_t c = cblock * cpb; c < (cblock + 1) * cpb && c < n_chunks; ++c) {
+    for (int k0 = 0; k0 < O; k0 += KB) {
+#pragma unroll
+      for (int h = 0; h < G / 2; ++h) {
+        const int64_t subj = c * G + 2 * h + (upper ? 1 : 0);
+        for (int k = k0; k < k0 + KB && k < O; ++k) {
+          const int64_t row = subj * O + k;
+          if (ok) st16<NT>(out + row * P + p_even, 1.0, 2.0);
+        }
+      }
+    }
+  }
+}
+
+// H: the classed map with chunk members far apart (subject = j * S/G + c) instead of consecutive
+template <bool NT>
+__global__ __launch_bounds__(256) void k_classed_spread(double* out, int64_t n_chunks, int cpb, int n_ptiles) {
+  const int64_t b = blockIdx.x;
+  const int64_t group = b / (8 * n_ptiles);
+  const int local = static_cast<int>(b % (8 * n_ptiles));
+  const int ptile = local / 8;
+  const int64_t cblock = group * 8 + (local % 8);
+  const unsigned lane = threadIdx.x & 63u;
+  const bool upper = lane >= 32u;
+  const int64_t p_even = static_cast<int64_t>(ptile) * 256 + (threadIdx.x & ~63u) + 2u * (lane & 31u);
+  const bool ok = p_even + 1 < P;
+  for (int64_t c = cblock * cpb; c < (cblock + 1) * cpb && c < n_chunks; ++c) {
+    for (int k = 0; k < O; ++k) {
+#pragma unroll
+      for (int h = 0; h < G / 2; ++h) {
+        const int64_t subj = (2 * h + (upper ? 1 : 0)) * (S / G) + c;
+        const int64_t row = subj * O + k;
+        if (ok) st16<NT>(out + row * P + p_even, 1.0, 2.0);
+      }
+    }
+  }
+}
+
+// E: one wave-store = 1 KB of ONE row (64 lanes x 16 B = 128 adjacent p): what an LDS transpose would allow.
+// block of 256 threads covers 512 p of a row -> 2 ptiles for P=1000; members are walked one row at a time.
+template <bool NT>
+__global__ __launch_bounds__(256) void k_rowwide(double* out, int64_t n_chunks, int cpb, int n_ptiles) {
+  const int64_t b = blockIdx.x;
+  const int64_t group = b / (8 * n_ptiles);
+  const int local = static_cast<int>(b % (8 * n_ptiles));
+  const int ptile = local / 8;
+  const int64_t cblock = group * 8 + (local % 8);
+  const int64_t p_even = static_cast<int64_t>(ptile) * 512 + 2 * threadIdx.x;
+  const bool ok = p_even + 1 < P;
+  for (int64_t c = cblock * cpb; c < (cblock + 1) * cpb && c < n_chunks; ++c) {
+    for (int k = 0; k < O; ++k) {
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const int64_t row = (c * G + j) * O + k;
+        if (ok) st16<NT>(out + row * P + p_even, 1.0, 2.0);
+      }
+    }
+  }
+}
+
+template <typename F>
+static void run(const char* name, F launch) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) launch();
+  CK(hipDeviceSynchronize());
+  const int reps = 10;
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < reps; ++i) launch();
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= reps;
+  std::printf("%-44s %7.4f ms  %6.3f TB/s\n", name, ms, ROWS * P * 8.0 / (ms * 1e-3) / 1e12);
+  std::fflush(stdout);
+}
+
+int main() {
+  double* out = nullptr;
+  CK(hipMalloc(&out, ROWS * P * 8));
+  CK(hipMemset(out, 0, ROWS * P * 8));
+  const int64_t n2 = ROWS * P / 2;
+  const int64_t n_chunks = S / G;
+  for (int rep = 0; rep < 2; ++rep) {
+    run("A linear fill", [&] { hipLaunchKernelGGL(k_linear<false>, dim3(256 * 16), dim3(256), 0, 0, out, n2); });
+    run("A linear fill nt", [&] { hipLaunchKernelGGL(k_linear<true>, dim3(256 * 16), dim3(256), 0, 0, out, n2); });
+    run("A linear fill grid 256*64", [&] { hipLaunchKernelGGL(k_linear<false>, dim3(256 * 64), dim3(256), 0, 0, out, n2); });
+    run("A2 one store per lane", [&] { hipLaunchKernelGGL(k_linear1<false>, dim3((n2 + 255) / 256), dim3(256), 0, 0, out, n2); });
+    run("A2 one store per lane nt", [&] { hipLaunchKernelGGL(k_linear1<true>, dim3((n2 + 255) / 256), dim3(256), 0, 0, out, n2); });
+    run("A3 4 stores per lane", [&] { hipLaunchKernelGGL(k_linear4<false>, dim3((n2 + 1023) / 1024), dim3(256), 0, 0, out, n2); });
+    run("A3 4 stores per lane nt", [&] { hipLaunchKernelGGL(k_linear4<true>, dim3((n2 + 1023) / 1024), dim3(256), 0, 0, out, n2); });
+    run("A4 32 B per lane", [&] { hipLaunchKernelGGL(k_linear32<false>, dim3((n2 / 2 + 255) / 256), dim3(256), 0, 0, out, n2); });
+    run("A5 hipMemsetAsync", [&] { CK(hipMemsetAsync(out, 0, ROWS * P * 8, 0)); });
+    for (int cpb : {1, 6}) {
+      const int64_t cb = ((n_chunks + cpb - 1) / cpb + 7) / 8 * 8;
+      char nm[96];
+      std::snprintf(nm, sizeof nm, "B classed map cpb=%d", cpb);
+      run(nm, [&] { hipLaunchKernelGGL((k_classed<false, false, 256>), dim3(cb * 4), dim3(256), 0, 0, out, n_chunks, cpb, 4, 0); });
+      std::snprintf(nm, sizeof nm, "B classed map nt cpb=%d", cpb);
+      run(nm, [&] { hipLaunchKernelGGL((k_classed<true, false, 256>), dim3(cb * 4), dim3(256), 0, 0, out, n_chunks, cpb, 4, 0); });
+      std::snprintf(nm, sizeof nm, "B classed map nt +delay64 cpb=%d", cpb);
+      run(nm, [&] { hipLaunchKernelGGL((k_classed<true, false, 256>), dim3(cb * 4), dim3(256), 0, 0, out, n_chunks, cpb, 4, 64); });
+      std::snprintf(nm, sizeof nm, "C full-row blocks (1024 thr) nt cpb=%d", cpb);
+      run(nm, [&] { hipLaunchKernelGGL((k_classed<true, false, 1024>), dim3(cb), dim3(1024), 0, 0, out, n_chunks, cpb, 1, 0); });
+      std::snprintf(nm, sizeof nm, "D obs-major rows nt cpb=%d", cpb);
+      run(nm, [&] { hipLaunchKernelGGL((k_classed<true, true, 256>), dim3(cb * 4), dim3(256), 0, 0, out, n_chunks, cpb, 4, 0); });
+      std::snprintf(nm, sizeof nm, "F 2 obs rows back to back nt cpb=%d", cpb);
+      run(nm, [&] { hipLaunchKernelGGL((k_classed_kb<true, 2>), dim3(cb * 4), dim3(256), 0, 0, out, n_chunks, cpb, 4); });
+      std::snprintf(nm, sizeof nm, "G 7 obs rows back to back nt cpb=%d", cpb);
+      run(nm, [&] { hipLaunchKernelGGL((k_classed_kb<true, 7>), dim3(cb * 4), dim3(256), 0, 0, out, n_chunks, cpb, 4); });
+      std::snprintf(nm, sizeof nm, "H members spread nt cpb=%d", cpb);
+      run(nm, [&] { hipLaunchKernelGGL((k_classed_spread<true>), dim3(cb * 4), dim3(256), 0, 0, out, n_chunks, cpb, 4); });
+      std::snprintf(nm, sizeof nm, "E 1KB-per-store rows nt cpb=%d", cpb);
+      run(nm, [&] { hipLaunchKernelGGL((k_rowwide<true>), dim3(cb * 2), dim3(256), 0, 0, out, n_chunks, cpb, 2); });
+      std::snprintf(nm, sizeof nm, "E 1KB-per-store rows cpb=%d", cpb);
+      run(nm, [&] { hipLaunchKernelGGL((k_rowwide<false>), dim3(cb * 2), dim3(256), 0, 0, out, n_chunks, cpb, 2); });
+    }
+  }
+  CK(hipFree(out));
+  return 0;
+}
