@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PMX_ABI_VERSION 1
+#define PMX_ABI_VERSION 2
 
 /* ---- limits (fixed-size descriptor arrays) ------------------------------- */
 #define PMX_MAX_STATES 8
@@ -94,7 +94,14 @@ typedef struct pmx_population_desc {
   const double* cov_knot_time;    /* covariate observations (src/data/covariate.rs:189-214) */
   const double* cov_knot_value;
   const uint8_t* cov_fixed;       /* [n_occasions*n_covariates] 1 = carry-forward only; NULL = all interpolated */
+  /* log-likelihood only (Observation::errorpoly / ::censoring, src/data/event.rs:575-582); both may be NULL */
+  const double* ev_errorpoly;     /* [n_events*4] the observation's own ErrorPoly c0..c3, overriding the error
+                                     model's (error_model.rs:1051-1054); c0 = NaN: none */
+  const int8_t* ev_censor;        /* [n_events] PMX_CENSOR_* (Censor, event.rs:557-567) */
 } pmx_population_desc;
+
+/* Censor: NONE -> lognormpdf, BLOQ -> log CDF, ALOQ -> log survival (prediction.rs:113-117) */
+enum { PMX_CENSOR_NONE = 0, PMX_CENSOR_BLOQ = 1, PMX_CENSOR_ALOQ = -1 };
 
 /* ---- models ---------------------------------------------------------------- */
 /* EqnKind, src/simulator/equation/mod.rs:580-586 */

@@ -59,6 +59,8 @@ def lib():
         L.pmx_oracle_sigma.argtypes = [C.POINTER(_abi.pmx_error_model), C.c_double, C.POINTER(C.c_double)]
         L.pmx_oracle_lognormpdf.restype = C.c_double
         L.pmx_oracle_lognormpdf.argtypes = [C.c_double, C.c_double, C.c_double]
+        L.pmx_oracle_lognormcdf.restype = C.c_int32
+        L.pmx_oracle_lognormcdf.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int32, C.POINTER(C.c_double)]
         L.pmx_oracle_last_error.restype = C.c_char_p
         L.pmx_oracle_max_threads.restype = C.c_int32
         L.pmx_oracle_sizeof_model_desc.restype = C.c_int64
@@ -172,3 +174,12 @@ def sigma(em, observation: float) -> float:
 
 def lognormpdf(obs: float, pred: float, sigma_: float) -> float:
     return float(lib().pmx_oracle_lognormpdf(float(obs), float(pred), float(sigma_)))
+
+
+def lognormcdf(obs: float, pred: float, sigma_: float, upper: bool = False) -> float:
+    """``lognormcdf`` / ``lognormccdf`` (upper=True); raises on the reference's Err branches."""
+    out = C.c_double()
+    rc = lib().pmx_oracle_lognormcdf(float(obs), float(pred), float(sigma_), 1 if upper else 0, C.byref(out))
+    if rc != 0:
+        raise _abi.PmxError(rc, "ErrorModelError::NegativeSigma")
+    return out.value

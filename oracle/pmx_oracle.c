@@ -1088,6 +1088,36 @@ int32_t pmx_oracle_sigma(const pmx_error_model* em, double y, double* sigma) {
   return PMX_OK;
 }
 
+/* lognormcdf (upper = 0) / lognormccdf (upper = 1), distributions.rs:52-103.  The normal CDF is statrs 0.19's
+ * (Cargo.toml; un-vendored): Normal::cdf(x) = 0.5 * erfc((mean - x) / (std_dev * SQRT_2)), Normal::new rejecting
+ * std_dev <= 0 or NaN.  Its erfc is a rational approximation good to ~1e-15; glibc's erfc stands in here. */
+int32_t pmx_oracle_lognormcdf(double obs, double pred, double sigma, int32_t upper, double* out) {
+  if (!(sigma > 0.0) || isnan(pred)) return PMX_ERR_ERROR_MODEL; /* Normal::new -> Err -> NegativeSigma */
+  double cdf = 0.5 * erfc((pred - obs) / (sigma * 1.4142135623730951));
+  double z = (obs - pred) / sigma;
+  if (!upper) {
+    if (cdf <= 0.0) {
+      if (z < -37.0) {
+        *out = pmx_oracle_lognormpdf(obs, pred, sigma) - log(fabs(z));
+        return PMX_OK;
+      }
+      return PMX_ERR_ERROR_MODEL;
+    }
+    *out = log(cdf);
+    return PMX_OK;
+  }
+  double sf = 1.0 - cdf;
+  if (sf <= 0.0) {
+    if (z > 37.0) {
+      *out = pmx_oracle_lognormpdf(obs, pred, sigma) - log(z);
+      return PMX_OK;
+    }
+    return PMX_ERR_ERROR_MODEL;
+  }
+  *out = log(sf);
+  return PMX_OK;
+}
+
 int32_t pmx_oracle_loglik(const pmx_model_desc* model, const pmx_population_desc* pop, const pmx_error_model* em,
                           const double* theta, int64_t n_support, double* ll, int64_t ld_ll, uint8_t* status,
                           int32_t nthreads) {
@@ -1100,6 +1130,7 @@ int32_t pmx_oracle_loglik(const pmx_model_desc* model, const pmx_population_desc
   /* observation values / outeqs in prediction order (occasions are sorted like simulate does) */
   double* yv = (double*)malloc(sizeof(double) * (size_t)(n_obs + 1));
   int* oq = (int*)malloc(sizeof(int) * (size_t)(n_obs + 1));
+  int64_t* osrc = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n_obs + 1)); /* row -> caller's event index */
   {
     scratch_t sc;
     scratch_init(&sc, pop);
@@ -1111,12 +1142,14 @@ int32_t pmx_oracle_loglik(const pmx_model_desc* model, const pmx_population_desc
         sc.ev[i].value = pop->ev_value[e0 + i];
         sc.ev[i].kind = pop->ev_kind[e0 + i];
         sc.ev[i].io = pop->ev_io[e0 + i];
+        sc.ev[i].src = e0 + i;
       }
       if (!pop->presorted) ev_sort(sc.ev, n);
       for (int64_t i = 0; i < n; i++)
         if (sc.ev[i].kind == PMX_EV_OBSERVATION) {
           yv[row] = sc.ev[i].value;
           oq[row] = sc.ev[i].io;
+          osrc[row] = sc.ev[i].src;
           row++;
         }
     }
@@ -1148,11 +1181,25 @@ int32_t pmx_oracle_loglik(const pmx_model_desc* model, const pmx_population_desc
           if (isnan(y)) continue; /* observation is None: contributes 0, prediction.rs:107-111 */
           int q = oq[off[s] + k];
           double sigma;
-          if (q >= model->nout || pmx_oracle_sigma(&em[q], y, &sigma) != PMX_OK) {
+          if (q >= model->nout) {
             r = PMX_ERR_ERROR_MODEL;
             break;
           }
-          total += pmx_oracle_lognormpdf(y, pr[k], sigma);
+          pmx_error_model e = em[q]; /* the observation's own ErrorPoly wins, error_model.rs:1051-1054 */
+          if (pop->ev_errorpoly && !isnan(pop->ev_errorpoly[osrc[off[s] + k] * 4]))
+            for (int c = 0; c < 4; c++) e.c[c] = pop->ev_errorpoly[osrc[off[s] + k] * 4 + c];
+          if (pmx_oracle_sigma(&e, y, &sigma) != PMX_OK) {
+            r = PMX_ERR_ERROR_MODEL;
+            break;
+          }
+          int cz = pop->ev_censor ? pop->ev_censor[osrc[off[s] + k]] : PMX_CENSOR_NONE;
+          double term; /* Prediction::log_likelihood, prediction.rs:113-117 */
+          if (cz == PMX_CENSOR_NONE) {
+            term = pmx_oracle_lognormpdf(y, pr[k], sigma);
+          } else if (pmx_oracle_lognormcdf(y, pr[k], sigma, cz == PMX_CENSOR_ALOQ, &term) != PMX_OK) {
+            term = NAN; /* Err(..) in the reference: the pair is flagged non-finite */
+          }
+          total += term;
         }
         if (st == PMX_PAIR_OK && !isfinite(total)) st = PMX_PAIR_NONFINITE; /* NonFiniteLikelihood, prediction.rs:119-124 */
         if (st == PMX_PAIR_COMPLEX_ROOTS) total = NAN;
@@ -1175,6 +1222,7 @@ int32_t pmx_oracle_loglik(const pmx_model_desc* model, const pmx_population_desc
   free(off);
   free(yv);
   free(oq);
+  free(osrc);
   if (failed != PMX_OK) FAIL(failed, "log-likelihood failed with status %d", failed);
   if (any_pair_failed) FAIL(PMX_ERR_PAIR_FAILED, "at least one (subject, support point) pair failed");
   return PMX_OK;

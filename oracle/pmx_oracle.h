@@ -52,6 +52,8 @@ int32_t pmx_oracle_loglik(const pmx_model_desc* model, const pmx_population_desc
 int32_t pmx_oracle_sigma(const pmx_error_model* em, double observation, double* sigma);
 /* lognormpdf (likelihood/distributions.rs:31-34) */
 double pmx_oracle_lognormpdf(double obs, double pred, double sigma);
+/* lognormcdf / lognormccdf (likelihood/distributions.rs:52-103); upper != 0 selects the survival function */
+int32_t pmx_oracle_lognormcdf(double obs, double pred, double sigma, int32_t upper, double* out);
 
 /* One call of a closed-form kernel: xout = kernel(x, p, t, rateiv)
  * (AnalyticalEq, src/simulator/mod.rs:54).  pm != 0 selects the pm_* wrapper

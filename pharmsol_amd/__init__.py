@@ -7,7 +7,7 @@ Host-side mirror of the reference interface for that path (``Subject`` builder,
 gfx950; there is no CPU fallback (the CPU oracle lives under ``oracle/`` and is
 test infrastructure only).
 """
-from .data import Bolus, Covariates, Data, Event, Infusion, Observation, Occasion, Subject, SubjectBuilder
+from .data import Bolus, Censor, Covariates, Data, Event, Infusion, Observation, Occasion, Subject, SubjectBuilder
 from .equation import (ODE, Analytical, Equation, LabelError, Lin, Pow, Ratio, Route, Scaled, analytical, bolus,
                        infusion, ode)
 from .error_model import AssayErrorModel, AssayErrorModels, ErrorPoly

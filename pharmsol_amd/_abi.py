@@ -8,7 +8,8 @@ from __future__ import annotations
 
 import ctypes as C
 
-PMX_ABI_VERSION = 1
+PMX_ABI_VERSION = 2
+PMX_CENSOR_NONE, PMX_CENSOR_BLOQ, PMX_CENSOR_ALOQ = 0, 1, -1
 
 PMX_MAX_STATES = 8
 PMX_MAX_INPUTS = 8
@@ -149,6 +150,8 @@ class pmx_population_desc(C.Structure):
         ("cov_knot_time", C.POINTER(C.c_double)),
         ("cov_knot_value", C.POINTER(C.c_double)),
         ("cov_fixed", C.POINTER(C.c_uint8)),
+        ("ev_errorpoly", C.POINTER(C.c_double)),
+        ("ev_censor", C.POINTER(C.c_int8)),
     ]
 
 

@@ -68,6 +68,7 @@ struct DeviceStream {
     const double* d_obs = nullptr;        // [n_obs][4]
     const double* d_cobs = nullptr;       // classed blocks
     const int64_t* d_chunk_obs_off = nullptr;
+    bool any_censored = false;
   };
   std::vector<LLCache> ll_cache;
   std::vector<void*> allocs;
@@ -380,13 +381,18 @@ int32_t get_ll_cache(const pmx_model* model, pmx_population* pop, DeviceStream* 
     }
   const auto& hp = pop->hp;
   std::vector<double> obs4(static_cast<size_t>(hp.n_obs) * 4, 0.0);
+  bool any_censored = false;
   for (int64_t r = 0; r < hp.n_obs; ++r) {
     const double y = hp.obs_value[static_cast<size_t>(r)];
     if (std::isnan(y)) continue;  // observation is None: weight 0
     const int q = hp.obs_outeq[static_cast<size_t>(r)];
     if (q >= nout) return fail(PMX_ERR_OUTEQ_OUT_OF_RANGE, "observation outeq >= nout");
     const pmx_error_model& e = em[q];
-    const double alpha = e.c[0] + e.c[1] * y + e.c[2] * (y * y) + e.c[3] * (y * y * y);
+    // the observation's own polynomial wins over the model's (error_model.rs:1051-1054)
+    const double* poly = e.c;
+    if (!hp.obs_errorpoly.empty() && !std::isnan(hp.obs_errorpoly[static_cast<size_t>(r) * 4]))
+      poly = &hp.obs_errorpoly[static_cast<size_t>(r) * 4];
+    const double alpha = poly[0] + poly[1] * y + poly[2] * (y * y) + poly[3] * (y * y * y);
     double sigma;
     if (e.kind == PMX_EM_ADDITIVE) sigma = std::sqrt(alpha * alpha + e.scalar * e.scalar);
     else if (e.kind == PMX_EM_PROPORTIONAL) sigma = e.scalar * alpha;
@@ -396,8 +402,17 @@ int32_t get_ll_cache(const pmx_model* model, pmx_population* pop, DeviceStream* 
     obs4[static_cast<size_t>(r) * 4 + 0] = y;
     obs4[static_cast<size_t>(r) * 4 + 1] = -0.5 * kLog2Pi - std::log(sigma);
     obs4[static_cast<size_t>(r) * 4 + 2] = 1.0 / (2.0 * sigma * sigma);
+    // censored rows: +-1/(sigma sqrt 2), the scale of statrs' Normal::cdf = 0.5 erfc((mean - x)/(sigma sqrt 2));
+    // sign = which tail (distributions.rs:52-103).  0 = uncensored.
+    const int8_t cz = hp.obs_censor.empty() ? int8_t(PMX_CENSOR_NONE) : hp.obs_censor[static_cast<size_t>(r)];
+    if (cz != PMX_CENSOR_NONE) {
+      if (!(sigma > 0.0)) return fail(PMX_ERR_ERROR_MODEL, "NegativeSigma: a censored observation needs sigma > 0 (Normal::new)");
+      obs4[static_cast<size_t>(r) * 4 + 3] = (cz == PMX_CENSOR_BLOQ ? 1.0 : -1.0) / (sigma * 1.4142135623730951);
+      any_censored = true;
+    }
   }
   DeviceStream::LLCache c;
+  c.any_censored = any_censored;
   c.em.assign(em, em + nout);
   int32_t rc;
   if ((rc = upload(obs4, &c.d_obs, &ds->allocs)) != PMX_OK) return rc;
@@ -507,6 +522,7 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
     a.ops.ll_ld = llreq->ld;
     a.cls.cobs = lc->d_cobs;
     a.cls.chunk_obs_off = lc->d_chunk_obs_off;
+    if (lc->any_censored) a.use_classes = 0;  // the classed blocks carry {value, const, weight} only: censored rows take the generic walk
   }
   if (!batch && P >= 32) {
     a.mode = pmx::MODE_GRID;

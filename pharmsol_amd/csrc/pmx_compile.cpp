@@ -87,6 +87,7 @@ int32_t build_host_population(const pmx_population_desc* d, HostPopulation* hp, 
   hp->ev_dur.resize(NE);
   hp->ev_kind.resize(NE);
   hp->ev_io.resize(NE);
+  std::vector<int64_t> ev_src(static_cast<size_t>(NE), 0);  // sorted position -> caller's event index
   std::vector<int64_t> order;
   for (int64_t o = 0; o < NO; ++o) {
     const int64_t e0 = hp->occ_ev_off[o], e1 = hp->occ_ev_off[o + 1];
@@ -109,6 +110,7 @@ int32_t build_host_population(const pmx_population_desc* d, HostPopulation* hp, 
       hp->ev_dur[dst] = d->ev_duration[src];
       hp->ev_kind[dst] = k;
       hp->ev_io[dst] = d->ev_io[src];
+      ev_src[dst] = src;
       if (k == PMX_EV_OBSERVATION)
         hp->max_outeq = std::max<int32_t>(hp->max_outeq, d->ev_io[src]);
     }
@@ -123,6 +125,14 @@ int32_t build_host_population(const pmx_population_desc* d, HostPopulation* hp, 
         hp->obs_value.push_back(hp->ev_value[e]);
         hp->obs_outeq.push_back(hp->ev_io[e]);
         hp->obs_subject.push_back(s);
+        if (d->ev_errorpoly)
+          for (int c = 0; c < 4; ++c) hp->obs_errorpoly.push_back(d->ev_errorpoly[ev_src[e] * 4 + c]);
+        if (d->ev_censor) {
+          const int8_t cz = d->ev_censor[ev_src[e]];
+          if (cz != PMX_CENSOR_NONE && cz != PMX_CENSOR_BLOQ && cz != PMX_CENSOR_ALOQ)
+            return fail(PMX_ERR_INVALID_ARGUMENT, "unknown censoring code");
+          hp->obs_censor.push_back(cz);
+        }
       }
     hp->subj_obs_off[s + 1] = static_cast<int64_t>(hp->obs_time.size());
   }

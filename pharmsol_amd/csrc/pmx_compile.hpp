@@ -43,6 +43,8 @@ struct HostPopulation {
   std::vector<double> obs_time;
   std::vector<double> obs_value;   // observed value (NaN = missing), for the log-likelihood
   std::vector<int32_t> obs_outeq;
+  std::vector<double> obs_errorpoly;  // [n_obs*4] the observation's own ErrorPoly (c0 = NaN: none); empty = none anywhere
+  std::vector<int8_t> obs_censor;     // [n_obs] PMX_CENSOR_*; empty = none anywhere
   std::vector<int64_t> obs_subject;
   int32_t max_outeq = -1;  // over all observations (range check vs model.nout)
   // covariates: per (occasion, covariate) segments as covariate.rs stores them

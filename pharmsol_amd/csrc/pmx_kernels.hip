@@ -287,12 +287,32 @@ __device__ __forceinline__ void lag_prop(const DevModel& m, const DevOps& ops, L
 
 // One observation in log-likelihood mode: acc += lognormpdf(obs, y, sigma) with the sigma-only parts
 // precomputed on the host (likelihood/distributions.rs:31-34; sigma from the observation,
-// error_model.rs:1045-1080).  `q` = {obs, -0.5 ln(2 pi) - ln sigma, 1/(2 sigma^2), -}.
+// error_model.rs:1045-1080).  `q` = {obs, -0.5 ln(2 pi) - ln sigma, 1/(2 sigma^2), censor scale}.
+// Censored rows (q[3] = +1/(sigma sqrt 2): BLOQ, -1/(sigma sqrt 2): ALOQ) take the log CDF / log survival
+// function of distributions.rs:52-103, with statrs' Normal::cdf = 0.5 erfc((mean - x)/(sigma sqrt 2)); a tail
+// that underflows falls back to the reference's asymptote (|z| > 37) or poisons the sum with NaN (its Err).
 __device__ __forceinline__ void ll_accumulate(const double* __restrict__ q, double y, double& acc) {
   const double w = q[2];
   if (w != 0.0) {  // weight 0 = missing observation: contributes 0 whatever the prediction (prediction.rs:107-111)
     const double d = q[0] - y;
-    acc += q[1] - (d * d) * w;
+    const double pdf = q[1] - (d * d) * w;
+    const double cs = q[3];
+    if (cs == 0.0) {  // wave-uniform
+      acc += pdf;
+    } else {
+      const double inv = fabs(cs);
+      const double cdf = 0.5 * erfc((y - q[0]) * inv);
+      const double z = d * (inv * 1.4142135623730951);  // (obs - pred) / sigma
+      const double nanv = __longlong_as_double(0x7ff8000000000000LL);
+      double ll;
+      if (cs > 0.0) {  // BLOQ: ln P(X <= obs)
+        ll = (cdf > 0.0) ? log(cdf) : ((z < -37.0) ? pdf - log(fabs(z)) : nanv);
+      } else {  // ALOQ: ln P(X > obs), computed as 1 - cdf like the reference
+        const double sf = 1.0 - cdf;
+        ll = (sf > 0.0) ? log(sf) : ((z > 37.0) ? pdf - log(z) : nanv);
+      }
+      acc += ll;
+    }
   }
 }
 
@@ -300,7 +320,7 @@ __device__ __forceinline__ void ll_accumulate(const double* __restrict__ q, doub
 // GRID kernel (analytical)
 // ------------------------------------------------------------------------------------
 template <int KID, bool DYN, bool LAG>
-__global__ __launch_bounds__(kBlock) void pmx_analytical_grid(DevModel m, DevOps ops, const double* __restrict__ theta,
+__global__ __launch_bounds__(kBlock, (!LAG && LaneModel<KID>::NS <= 2) ? 4 : 1) void pmx_analytical_grid(DevModel m, DevOps ops, const double* __restrict__ theta,
                                                               int64_t P, int64_t S, int32_t s_chunk, int32_t n_ptiles,
                                                               double* __restrict__ pred, int64_t ld,
                                                               uint8_t* __restrict__ status,

@@ -9,7 +9,8 @@ tests) read like pharmsol code:
 * sort order: time (total order) then Observation < Bolus < Infusion, stable — src/data/event.rs:292-304
 * ``Covariates``: named knot lists per occasion — src/data/covariate.rs:297-299
 
-Only what the prediction path consumes is kept (no error polynomials / censoring).
+Observations also carry what the likelihood consumes: an optional per-observation ``ErrorPoly`` and the
+``Censor`` state (src/data/event.rs:557-582).
 """
 from __future__ import annotations
 
@@ -18,7 +19,7 @@ import struct
 from dataclasses import dataclass, field
 from typing import Dict, Iterable, List, Optional, Sequence, Tuple, Union
 
-from ._abi import PMX_EV_BOLUS, PMX_EV_INFUSION, PMX_EV_OBSERVATION
+from ._abi import PMX_CENSOR_ALOQ, PMX_CENSOR_BLOQ, PMX_CENSOR_NONE, PMX_EV_BOLUS, PMX_EV_INFUSION, PMX_EV_OBSERVATION
 
 Label = Union[str, int]
 
@@ -52,14 +53,25 @@ class Infusion:
     kind = PMX_EV_INFUSION
 
 
+class Censor:
+    """``Censor`` (src/data/event.rs:557-567): how the likelihood reads the observed value."""
+
+    NONE = PMX_CENSOR_NONE  # lognormpdf
+    BLOQ = PMX_CENSOR_BLOQ  # below the limit of quantification: log CDF
+    ALOQ = PMX_CENSOR_ALOQ  # above it: log survival function
+
+
 @dataclass
 class Observation:
-    """Observation slot; ``value is None`` = prediction-only (src/data/event.rs:575-582)."""
+    """Observation slot; ``value is None`` = prediction-only (src/data/event.rs:575-582).  ``errorpoly`` =
+    (c0, c1, c2, c3) overriding the error model's polynomial for this observation."""
 
     time: float
     value: Optional[float]
     outeq: Label
     occasion: int = 0
+    errorpoly: Optional[Tuple[float, float, float, float]] = None
+    censoring: int = PMX_CENSOR_NONE
     kind = PMX_EV_OBSERVATION
 
 
@@ -79,7 +91,13 @@ class Covariates:
     fixed: Dict[str, bool] = field(default_factory=dict)
 
     def add_observation(self, name: str, time: float, value: float) -> None:
-        self.knots.setdefault(name, []).append((float(time), float(value)))
+        # Covariate::add_observation (covariate.rs:143-154): a value at an existing time replaces it
+        kn = self.knots.setdefault(name, [])
+        for i, (t, _) in enumerate(kn):
+            if t == float(time):
+                kn[i] = (t, float(value))
+                return
+        kn.append((float(time), float(value)))
 
     def set_fixed(self, name: str, fixed: bool = True) -> None:
         self.fixed[name] = fixed
@@ -152,6 +170,17 @@ class SubjectBuilder:
     def missing_observation(self, time: float, outeq: Label) -> "SubjectBuilder":
         return self.event(Observation(float(time), None, outeq, self._current.index))
 
+    def censored_observation(self, time: float, value: float, outeq: Label, censoring: int) -> "SubjectBuilder":
+        # builder.rs:161-178
+        return self.event(Observation(float(time), float(value), outeq, self._current.index, None, int(censoring)))
+
+    def observation_with_error(self, time: float, value: float, outeq: Label, errorpoly, censored: int = PMX_CENSOR_NONE
+                               ) -> "SubjectBuilder":
+        # builder.rs:211-229; errorpoly = ErrorPoly or (c0, c1, c2, c3)
+        poly = tuple(errorpoly) if not hasattr(errorpoly, "c0") else (errorpoly.c0, errorpoly.c1, errorpoly.c2, errorpoly.c3)
+        return self.event(Observation(float(time), float(value), outeq, self._current.index,
+                                      tuple(float(c) for c in poly), int(censored)))
+
     def repeat(self, n: int, delta: float) -> "SubjectBuilder":
         # builder.rs:251-313: clones of the LAST added event at time + delta*i
         last = self._last
@@ -163,10 +192,8 @@ class SubjectBuilder:
                 self.bolus(t, last.amount, last.input)
             elif isinstance(last, Infusion):
                 self.infusion(t, last.amount, last.input, last.duration)
-            elif last.value is not None:
-                self.observation(t, last.value, last.outeq)
-            else:
-                self.missing_observation(t, last.outeq)
+            else:  # value, censoring and error polynomial are kept (builder.rs:253-254)
+                self.event(Observation(t, last.value, last.outeq, self._current.index, last.errorpoly, last.censoring))
         return self
 
     def covariate(self, name: str, time: float, value: float) -> "SubjectBuilder":

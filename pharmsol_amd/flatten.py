@@ -23,7 +23,7 @@ class FlatPopulation:
 
     def __init__(self, *, subj_occ_off, occ_ev_off, occ_index, ev_time, ev_value, ev_duration, ev_kind, ev_io,
                  n_covariates=0, cov_knot_off=None, cov_knot_time=None, cov_knot_value=None, cov_fixed=None,
-                 presorted=False, subject_ids: Optional[List[str]] = None):
+                 presorted=False, subject_ids: Optional[List[str]] = None, ev_errorpoly=None, ev_censor=None):
         self.subj_occ_off = np.ascontiguousarray(subj_occ_off, dtype=np.int64)
         self.occ_ev_off = np.ascontiguousarray(occ_ev_off, dtype=np.int64)
         self.occ_index = np.ascontiguousarray(occ_index, dtype=np.int32)
@@ -46,6 +46,10 @@ class FlatPopulation:
         else:
             self.cov_knot_off = self.cov_knot_time = self.cov_knot_value = self.cov_fixed = None
         n_ev = self.ev_time.shape[0]
+        # likelihood-only attributes of observations (None = absent everywhere)
+        self.ev_errorpoly = None if ev_errorpoly is None else np.ascontiguousarray(ev_errorpoly, dtype=np.float64).reshape(n_ev, 4)
+        self.ev_censor = None if ev_censor is None else np.ascontiguousarray(ev_censor, dtype=np.int8)
+        assert self.ev_censor is None or self.ev_censor.shape[0] == n_ev
         for a in (self.ev_value, self.ev_duration, self.ev_kind, self.ev_io):
             assert a.shape[0] == n_ev
         assert self.occ_ev_off[-1] == n_ev and self.subj_occ_off[-1] == n_occ
@@ -102,6 +106,8 @@ class FlatPopulation:
         d.cov_knot_time = p(self.cov_knot_time, C.c_double)
         d.cov_knot_value = p(self.cov_knot_value, C.c_double)
         d.cov_fixed = p(self.cov_fixed, C.c_uint8)
+        d.ev_errorpoly = p(self.ev_errorpoly, C.c_double)
+        d.ev_censor = p(self.ev_censor, C.c_int8)
         return d
 
     # -- sharding (partition subjects, replicate theta) -----------
@@ -117,6 +123,8 @@ class FlatPopulation:
             ev_kind=self.ev_kind[e0:e1], ev_io=self.ev_io[e0:e1],
             n_covariates=self.n_covariates, presorted=self.presorted,
             subject_ids=None if self.subject_ids is None else self.subject_ids[s0:s1],
+            ev_errorpoly=None if self.ev_errorpoly is None else self.ev_errorpoly[e0:e1],
+            ev_censor=None if self.ev_censor is None else self.ev_censor[e0:e1],
         )
         if self.n_covariates > 0:
             nc = self.n_covariates
@@ -146,6 +154,10 @@ def flatten(model, data) -> FlatPopulation:
     dur: List[float] = []
     kind: List[int] = []
     io: List[int] = []
+    poly: List[tuple] = []
+    cens: List[int] = []
+    any_poly = any_cens = False
+    nanpoly = (float("nan"),) * 4
     knot_off = [0]
     knot_t: List[float] = []
     knot_v: List[float] = []
@@ -156,6 +168,14 @@ def flatten(model, data) -> FlatPopulation:
             for ev in occ.events:
                 t.append(ev.time)
                 kind.append(ev.kind)
+                if isinstance(ev, Observation) and ev.errorpoly is not None:
+                    poly.append(tuple(ev.errorpoly))
+                    any_poly = True
+                else:
+                    poly.append(nanpoly)
+                cz = ev.censoring if isinstance(ev, Observation) else 0
+                cens.append(cz)
+                any_cens = any_cens or cz != 0
                 if isinstance(ev, Bolus):
                     v.append(ev.amount)
                     dur.append(0.0)
@@ -185,4 +205,6 @@ def flatten(model, data) -> FlatPopulation:
         ev_duration=dur, ev_kind=kind, ev_io=io, n_covariates=nc,
         cov_knot_off=knot_off if nc else None, cov_knot_time=knot_t if nc else None,
         cov_knot_value=knot_v if nc else None, cov_fixed=fixed if nc else None,
-        presorted=False, subject_ids=[s.id for s in subjects])
+        presorted=False, subject_ids=[s.id for s in subjects],
+        ev_errorpoly=np.asarray(poly, dtype=np.float64).reshape(len(t), 4) if any_poly else None,
+        ev_censor=cens if any_cens else None)

@@ -143,3 +143,55 @@ def test_host_pointer_form_through_the_equation_api():
     ll, st = m.log_likelihood_matrix(flat, theta, EM_PROP)
     want, _ = oracle.loglik(m, flat, EM_PROP, theta)
     assert ll.shape == (40, 33) and np.abs(ll - want).max() / np.abs(want).max() < TOL_LL
+
+
+def _censor_some(flat, rng, frac_bloq=0.15, frac_aloq=0.1, frac_poly=0.2):
+    """Mark a share of the valued observations BLOQ / ALOQ and give some their own error polynomial."""
+    n = flat.n_events
+    is_obs = (flat.ev_kind == _abi.PMX_EV_OBSERVATION) & ~np.isnan(flat.ev_value)
+    u = rng.random(n)
+    cens = np.zeros(n, dtype=np.int8)
+    cens[is_obs & (u < frac_bloq)] = _abi.PMX_CENSOR_BLOQ
+    cens[is_obs & (u > 1.0 - frac_aloq)] = _abi.PMX_CENSOR_ALOQ
+    poly = np.full((n, 4), np.nan)
+    own = is_obs & (rng.random(n) < frac_poly)
+    poly[own] = np.stack([rng.uniform(0.05, 0.5, own.sum()), rng.uniform(0.0, 0.2, own.sum()), np.zeros(own.sum()),
+                          np.zeros(own.sum())], axis=1)
+    flat.ev_censor, flat.ev_errorpoly = cens, poly
+    return flat
+
+
+@pytest.mark.parametrize("n_support", [70, 5])
+def test_censored_observations_and_per_observation_error_polynomials(n_support):
+    """Censor::BLOQ / ALOQ rows take log CDF / log survival (distributions.rs:52-103), an observation's own ErrorPoly
+    replaces the model's (error_model.rs:1051-1054).  A shared design normally runs the classed kernel; censored
+    rows route it through the generic walk."""
+    rng = np.random.default_rng(11)
+    m, flat, theta = synth.config_c3(200, max(n_support, 8))
+    theta = theta[:n_support]
+    flat = _censor_some(with_observed_values(m, flat, theta[:1], rng), rng)
+    assert_ll_parity(m, flat, EM_ADD, theta,
+                     expect_kernel="pmx_analytical_grid" if n_support >= 32 else "pmx_analytical_pair")
+    # error polynomials alone keep the classed kernel
+    flat.ev_censor = None
+    assert_ll_parity(m, flat, EM_PROP, theta,
+                     expect_kernel="pmx_analytical_classed<ll>" if n_support >= 32 else "pmx_analytical_pair")
+
+
+def test_censored_tail_far_from_the_prediction():
+    """|z| > 37: the reference's asymptote; an upper tail that underflows before that is its Err -> flagged pair."""
+    from pharmsol_amd import Censor
+
+    m = models.handwritten_analytical("one_compartment", 0, 2).with_ndrugs(1)
+    subs = [Subject.builder("lo").bolus(0.0, 100.0, 0).censored_observation(1.0, 0.01, 0, Censor.BLOQ).build(),
+            Subject.builder("hi").bolus(0.0, 100.0, 0).censored_observation(1.0, 50.0, 0, Censor.ALOQ).build(),
+            Subject.builder("err").bolus(0.0, 100.0, 0).censored_observation(1.0, 9.5, 0, Censor.ALOQ).build()]
+    em = AssayErrorModels.empty().add(0, AssayErrorModel.additive(ErrorPoly(0.1, 0.0, 0.0, 0.0), 0.0))
+    th = np.array([[0.2, 10.0]] * 40)  # prediction 8.19, sigma 0.1: z = -82, +418, +13
+    flat = m.flatten(Data(subs))
+    got, st = gpu_loglik(m, flat, em, th)
+    want, wst = oracle.loglik(m, flat, em, th)
+    np.testing.assert_array_equal(st, wst)
+    assert (st[2] == _abi.PMX_PAIR_NONFINITE).all() and (st[:2] == 0).all()
+    np.testing.assert_allclose(got[:2], want[:2], rtol=1e-12)
+    assert np.isnan(got[2]).all()

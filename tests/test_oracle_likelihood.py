@@ -98,3 +98,69 @@ def test_non_finite_log_likelihood_is_flagged():  # prediction.rs:119-124
     em = AssayErrorModels.empty().add(0, AssayErrorModel.additive(ErrorPoly(1.0, 0.0, 0.0, 0.0), 0.0))
     ll, st = oracle.loglik(m, m.flatten(s), em, np.array([[0.1, 0.0], [0.1, 2.0]]))  # v = 0 -> pred = inf
     assert st[0, 0] == _abi.PMX_PAIR_NONFINITE and st[0, 1] == 0 and np.isfinite(ll[0, 1])
+
+
+# --------------------------------------------------------------------------- censoring (distributions.rs:52-103)
+def test_lognormcdf_and_ccdf_at_the_mean():  # distributions.rs:141-163
+    assert abs(oracle.lognormcdf(0.0, 0.0, 1.0) - math.log(0.5)) < 1e-10
+    assert abs(oracle.lognormcdf(0.0, 0.0, 1.0, upper=True) - math.log(0.5)) < 1e-10
+
+
+def test_lognormcdf_tails_stay_finite():  # distributions.rs:166-187: |z| = 40 takes the asymptote
+    lo = oracle.lognormcdf(-40.0, 0.0, 1.0)
+    hi = oracle.lognormcdf(40.0, 0.0, 1.0, upper=True)
+    assert math.isfinite(lo) and math.isfinite(hi)
+    # ln Phi(-40) ~ ln phi(40) - ln 40
+    want = -0.5 * 1.8378770664093453 - 800.0 - math.log(40.0)
+    assert abs(lo - want) < 1e-9 and abs(hi - want) < 1e-9
+    # the asymptote is written with lognormpdf(obs, pred, sigma), i.e. it carries a -ln(sigma) the true tail does not
+    # have (distributions.rs:64): restated as it is, not corrected
+    assert abs(oracle.lognormcdf(-20.0, 0.0, 0.5) - (-0.5 * 1.8378770664093453 - math.log(0.5) - 800.0 - math.log(40.0))) < 1e-9
+    # 1 - cdf loses the upper tail long before 37 sigma: the reference returns Err there (sf == 0, z <= 37)
+    with pytest.raises(_abi.PmxError):
+        oracle.lognormcdf(10.0, 0.0, 1.0, upper=True)
+    with pytest.raises(_abi.PmxError):
+        oracle.lognormcdf(0.0, 0.0, 0.0)  # Normal::new rejects sigma = 0
+
+
+def test_lognormcdf_against_scipy():
+    from scipy.stats import norm
+
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        obs, pred, s = rng.uniform(0, 10), rng.uniform(0, 10), rng.uniform(0.3, 3)  # |z| < 37: no asymptote branch
+        assert abs(oracle.lognormcdf(obs, pred, s) - norm.logcdf(obs, pred, s)) < 1e-11 * max(1.0, abs(norm.logcdf(obs, pred, s)))
+        z = (obs - pred) / s
+        if z < 5:  # (1 - cdf keeps ~1e-16 absolute: compare where the survival function is not tiny)
+            assert abs(oracle.lognormcdf(obs, pred, s, upper=True) - norm.logsf(obs, pred, s)) < 1e-8
+
+
+def test_censored_and_error_polynomial_observations_in_the_subject_sum():
+    """Prediction::log_likelihood (prediction.rs:105-125): BLOQ -> log CDF, ALOQ -> log survival; the observation's own
+    ErrorPoly replaces the model's (error_model.rs:1051-1054)."""
+    from pharmsol_amd import Censor
+
+    m = models.handwritten_analytical("one_compartment", 0, 2).with_ndrugs(1)
+    s = (Subject.builder("c").bolus(0.0, 100.0, 0)
+         .observation(1.0, 8.0, 0)
+         .censored_observation(2.0, 5.0, 0, Censor.BLOQ)
+         .censored_observation(3.0, 9.0, 0, Censor.ALOQ)
+         .observation_with_error(4.0, 6.0, 0, ErrorPoly(0.5, 0.0, 0.0, 0.0))
+         .observation_with_error(5.0, 4.0, 0, (0.3, 0.1, 0.0, 0.0), Censor.BLOQ)
+         .build())
+    em = AssayErrorModels.empty().add(0, AssayErrorModel.additive(ErrorPoly(0.1, 0.1, 0.0, 0.0), 0.2))
+    th = np.array([[0.2, 10.0]])
+    flat = m.flatten(s)
+    ll, st = oracle.loglik(m, flat, em, th)
+    pred, _ = oracle.predict(m, flat, th)
+    p = pred[:, 0]
+
+    def sig(c0, c1, y, lam=0.2):
+        return math.sqrt((c0 + c1 * y) ** 2 + lam ** 2)
+
+    want = (oracle.lognormpdf(8.0, p[0], sig(0.1, 0.1, 8.0))
+            + oracle.lognormcdf(5.0, p[1], sig(0.1, 0.1, 5.0))
+            + oracle.lognormcdf(9.0, p[2], sig(0.1, 0.1, 9.0), upper=True)
+            + oracle.lognormpdf(6.0, p[3], sig(0.5, 0.0, 6.0))
+            + oracle.lognormcdf(4.0, p[4], sig(0.3, 0.1, 4.0)))
+    assert st[0, 0] == 0 and abs(ll[0, 0] - want) < 1e-12 * abs(want)
