@@ -7,17 +7,19 @@ Host-side mirror of the reference interface for that path (``Subject`` builder,
 gfx950; there is no CPU fallback (the CPU oracle lives under ``oracle/`` and is
 test infrastructure only).
 """
-from .data import Bolus, Censor, Covariates, Data, Event, Infusion, Observation, Occasion, Subject, SubjectBuilder
+from .data import (Bolus, Censor, Covariates, Data, Event, Infusion, Observation, Occasion, Subject, SubjectBuilder,
+                   interpolate)
 from .equation import (ODE, Analytical, Equation, LabelError, Lin, Pow, Ratio, Route, Scaled, analytical, bolus,
                        infusion, ode)
 from .error_model import AssayErrorModel, AssayErrorModels, ErrorPoly
 from .flatten import FlatPopulation, flatten
 from .parameters import Parameters
+from .pmetrics import DataError, DataRow, build_data, read_pmetrics
 from .predictions import Prediction, SubjectPredictions
 from ._abi import PmxError
 
 __all__ = [
-    "Bolus", "Covariates", "Data", "Event", "Infusion", "Observation", "Occasion", "Subject", "SubjectBuilder",
+    "Bolus", "Censor", "Covariates", "Data", "DataError", "DataRow", "build_data", "read_pmetrics", "interpolate", "Event", "Infusion", "Observation", "Occasion", "Subject", "SubjectBuilder",
     "ODE", "Analytical", "Equation", "LabelError", "Lin", "Pow", "Ratio", "Route", "Scaled", "analytical", "bolus",
     "infusion", "ode", "AssayErrorModel", "AssayErrorModels", "ErrorPoly", "FlatPopulation", "flatten", "Parameters", "Prediction", "SubjectPredictions", "PmxError",
 ]

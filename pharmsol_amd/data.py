@@ -228,6 +228,13 @@ class Data:
     def __iter__(self):
         return iter(self.subjects)
 
+    @staticmethod
+    def from_pmetrics_csv_bytes(data: bytes) -> "Data":
+        """``Data::from_pmetrics_csv_bytes`` (src/data/parser/pmetrics/mod.rs:170-232)."""
+        from .pmetrics import from_pmetrics_csv_bytes
+
+        return from_pmetrics_csv_bytes(data)
+
 
 def interpolate(knots: Sequence[Tuple[float, float]], t: float, fixed: bool = False) -> float:
     """``Covariate::interpolate`` (src/data/covariate.rs:189-241) on the host.

@@ -454,3 +454,29 @@ def test_c4_full_size_against_closed_form():
     ma = Analytical.new("one_compartment", {0: Ratio(0, 1)}, nparams=2).with_nstates(1).with_ndrugs(1).with_nout(1)
     exact, _ = oracle.predict_batch(ma, flat, theta)
     assert rel_err(got, exact).max() <= TOL_ODE
+
+
+def test_pmetrics_csv_population_end_to_end():
+    """A Pmetrics file (ADDL/II expansion, an EVID=4 occasion, OUT=-99, a covariate column) read by
+    pharmsol_amd.pmetrics, resolved through a declared model and predicted on the device."""
+    from pharmsol_amd import Pow, Scaled, analytical, bolus, infusion
+    from pharmsol_amd.pmetrics import from_pmetrics_csv_bytes
+
+    eq = analytical(name="one_cmt_wt", params=["ke0", "v"], derived={"ke": Scaled("ke0", [Pow("wt", 70.0, 0.75)])},
+                    covariates=["wt"], structure="one_compartment", states=["central"], outputs=["1"],
+                    routes=[bolus("1", "central"), infusion("1", "central")], out={"1": Ratio("central", "v")})
+    rows = ["ID,EVID,TIME,DUR,DOSE,ADDL,II,INPUT,OUT,OUTEQ,WT"]
+    rng = np.random.default_rng(3)
+    for i in range(40):
+        wt = 50 + i
+        rows.append(f"s{i:02d},1,0,0,{300 + 5 * i},{3 + i % 3},12,1,.,.,{wt}")
+        for t in (1, 6, 13, 30, 47.5):
+            rows.append(f"s{i:02d},0,{t},.,.,.,.,.,{-99 if i % 4 == 0 else round(float(rng.uniform(1, 9)), 3)},1,{wt + 0.05 * t}")
+        if i % 2:
+            rows.append(f"s{i:02d},4,72,1.5,{200 + i},.,.,1,.,.,{wt + 4}")
+            rows.append(f"s{i:02d},0,75,.,.,.,.,.,2.5,1,{wt + 4.2}")
+    data = from_pmetrics_csv_bytes(("\n".join(rows) + "\n").encode())
+    flat = eq.flatten(data)
+    assert flat.n_subjects == 40 and flat.n_occasions == 60
+    th = np.stack([rng.uniform(0.05, 0.4, 48), rng.uniform(10, 60, 48)], axis=1)
+    assert_parity(eq, flat, th, TOL_ANALYTICAL, expect_kernel="pmx_analytical_grid<dyn>")
