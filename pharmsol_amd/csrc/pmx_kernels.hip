@@ -319,7 +319,7 @@ __device__ __forceinline__ void ll_accumulate(const double* __restrict__ q, doub
 // ------------------------------------------------------------------------------------
 // GRID kernel (analytical)
 // ------------------------------------------------------------------------------------
-template <int KID, bool DYN, bool LAG>
+template <int KID, bool DYN, bool LAG, bool LL>
 __global__ __launch_bounds__(kBlock, (!LAG && LaneModel<KID>::NS <= 2) ? 4 : 1) void pmx_analytical_grid(DevModel m, DevOps ops, const double* __restrict__ theta,
                                                               int64_t P, int64_t S, int32_t s_chunk, int32_t n_ptiles,
                                                               double* __restrict__ pred, int64_t ld,
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(kBlock, (!LAG && LaneModel<KID>::NS <= 2) ? 4 : 1) 
       } else if (kind == OP_OBS) {
         double y = lane_out<KID>(m, L, x, xpad, io, cov);
         if (st == PMX_PAIR_COMPLEX_ROOTS || st == PMX_PAIR_BAD_LAG) y = nanv;
-        if (ops.ll_obs != nullptr) {
+        if constexpr (LL) {
           ll_accumulate(ops.ll_obs + row * 4, y, ll_acc);
         } else {
           if (st == PMX_PAIR_OK && !isfinite(y)) st = PMX_PAIR_NONFINITE;
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(kBlock, (!LAG && LaneModel<KID>::NS <= 2) ? 4 : 1) 
           lag_open_occasion<LM::ST, NS>(m, ops, ls, static_cast<int64_t>(a), c_op_t0[o], L.coef, th, x);
       }
     }
-    if (ops.ll_obs != nullptr) {
+    if constexpr (LL) {
       if (st == PMX_PAIR_OK && !isfinite(ll_acc)) st = PMX_PAIR_NONFINITE;  // NonFiniteLikelihood (prediction.rs:119-124)
       if (lane_ok) ops.ll_out[s * ops.ll_ld + p] = (st == PMX_PAIR_OK || st == PMX_PAIR_NONFINITE) ? ll_acc : nanv;
     }
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
 // ------------------------------------------------------------------------------------
 // PAIR kernel (analytical): lane = (subject, support point), divergent schedules
 // ------------------------------------------------------------------------------------
-template <int KID, bool DYN, bool LAG>
+template <int KID, bool DYN, bool LAG, bool LL>
 __global__ __launch_bounds__(kBlock) void pmx_analytical_pair(DevModel m, DevOps ops, const double* __restrict__ theta,
                                                               int64_t P, int64_t S, int32_t batch,
                                                               double* __restrict__ pred, int64_t ld,
@@ -754,7 +754,7 @@ __global__ __launch_bounds__(kBlock) void pmx_analytical_pair(DevModel m, DevOps
     } else if (kind == OP_OBS) {
       double y = lane_out<KID>(m, L, x, xpad, io, cov);
       if (st == PMX_PAIR_COMPLEX_ROOTS || st == PMX_PAIR_BAD_LAG) y = nanv;
-      if (ops.ll_obs != nullptr) {
+      if constexpr (LL) {
         ll_accumulate(ops.ll_obs + row * 4, y, ll_acc);
       } else {
         if (st == PMX_PAIR_OK && !isfinite(y)) st = PMX_PAIR_NONFINITE;
@@ -775,7 +775,7 @@ __global__ __launch_bounds__(kBlock) void pmx_analytical_pair(DevModel m, DevOps
       if constexpr (LAG) lag_open_occasion<LM::ST, NS>(m, ops, ls, static_cast<int64_t>(a), ops.op_t0[o], L.coef, th, x);
     }
   }
-  if (ops.ll_obs != nullptr) {
+  if constexpr (LL) {
     if (st == PMX_PAIR_OK && !isfinite(ll_acc)) st = PMX_PAIR_NONFINITE;
     if (lane_ok) ops.ll_out[batch ? s : (s * ops.ll_ld + p)] = (st == PMX_PAIR_OK || st == PMX_PAIR_NONFINITE) ? ll_acc : nanv;
   }
@@ -1002,7 +1002,7 @@ __device__ __forceinline__ void ode_lag_prop(const DevModel& m, const DevOps& op
   ode_piece<MODEL>(m, kp, x, rs, t, t1);
 }
 
-template <int MODEL, bool LAG>
+template <int MODEL, bool LAG, bool LL>
 __global__ __launch_bounds__(kBlock) void pmx_ode_rk4_grid(DevModel m, DevOps ops, const double* __restrict__ theta,
                                                            int64_t P, int64_t S, int32_t s_chunk, int32_t n_ptiles,
                                                            double* __restrict__ pred, int64_t ld,
@@ -1061,7 +1061,7 @@ __global__ __launch_bounds__(kBlock) void pmx_ode_rk4_grid(DevModel m, DevOps op
       } else if (kind == OP_OBS) {
         double y = ode_out<MODEL>(m, L, x, io);
         if (LAG && st == PMX_PAIR_BAD_LAG) y = nanv;
-        if (ops.ll_obs != nullptr) {
+        if constexpr (LL) {
           ll_accumulate(ops.ll_obs + row * 4, y, ll_acc);
         } else {
           if (st == PMX_PAIR_OK && !isfinite(y)) st = PMX_PAIR_NONFINITE;
@@ -1080,7 +1080,7 @@ __global__ __launch_bounds__(kBlock) void pmx_ode_rk4_grid(DevModel m, DevOps op
           ode_lag_open_occasion<MODEL>(m, ops, ls, static_cast<int64_t>(a), uniformf64(ops.op_t0[o]), L.kp, th, x);
       }
     }
-    if (ops.ll_obs != nullptr) {
+    if constexpr (LL) {
       if (st == PMX_PAIR_OK && !isfinite(ll_acc)) st = PMX_PAIR_NONFINITE;
       if (lane_ok) ops.ll_out[s * ops.ll_ld + p] = (st == PMX_PAIR_OK || st == PMX_PAIR_NONFINITE) ? ll_acc : nanv;
     }
@@ -1091,7 +1091,7 @@ __global__ __launch_bounds__(kBlock) void pmx_ode_rk4_grid(DevModel m, DevOps op
 // PAIR: each lane is a small state machine {cursor o, remaining RK4 steps}; one trip of the
 // wave loop performs either one RK4 step or one op per lane, so lanes in different segments
 // of different subjects still step in lock-step (divergent timelines, C4).
-template <int MODEL, bool LAG>
+template <int MODEL, bool LAG, bool LL>
 __global__ __launch_bounds__(kBlock) void pmx_ode_rk4_pair(DevModel m, DevOps ops, const double* __restrict__ theta,
                                                            int64_t P, int64_t S, int32_t batch,
                                                            double* __restrict__ pred, int64_t ld,
@@ -1138,94 +1138,94 @@ __global__ __launch_bounds__(kBlock) void pmx_ode_rk4_pair(DevModel m, DevOps op
   // LAG: an open PROP (or occasion opening) [t_cur, t_stop) that lagged boluses may still split
   bool in_prop = false;
   double t_cur = 0.0, t_stop = 0.0;
+  // ONE action per lane per trip (an RK4 step, a lag sub-piece decision, or an op), written as a single if / else
+  // chain: with `continue`s the compiler rotates the stepping branch into an inner per-lane loop and lanes that
+  // need an op wait for the longest piece in the wave (measured: C4 2.4 -> 3.9 ms).
   while (rem > 0 || o < o1) {
     if (rem > 0) {
       rk4_step<MODEL>(L.kp, x, rs, h);
       --rem;
-      continue;
-    }
-    if constexpr (LAG) {
-      if (in_prop) {
-        int which;
-        const double tau = lag_next(m, ops, ls, which);
-        const bool bol = tau < t_stop;
-        const double stop = bol ? tau : t_stop;
-        if (stop > t_cur) {  // next sub-piece; n = ceil(dt / h_max) as ode_piece
-          const double dt = stop - t_cur;
-          double nf = ceil(dt / m.rk4_h_max);
-          if (!(nf >= 1.0)) nf = 1.0;
-          if (nf > 1.0e7) nf = 1.0e7;
-          rem = static_cast<int32_t>(nf);
-          h = dt / static_cast<double>(rem);
-          t_cur = stop;
-        } else if (bol) {
-          lag_apply_bolus<NS>(m, ops, ls, which, th, x);
-        } else {
-          in_prop = false;
-          ++o;
-        }
-        continue;
-      }
-    }
-    const uint32_t meta = ops.op_meta[o];
-    const uint32_t kind = meta & 0xffu;
-    const int io = static_cast<int>((meta >> 8) & 0xffffu);
-    const double a = ops.op_a[o];
-    if (kind == OP_PROP) {
-      ode_rates<MODEL>(m, ops.op_rate, o, ops.n_rate, rs);
-      if constexpr (LAG) {
-        in_prop = true;
-        t_cur = ops.op_t0[o];
-        t_stop = ops.op_t1[o];
-        continue;  // the open-PROP branch above walks it and advances o
+    } else if (LAG && in_prop) {
+      int which;
+      const double tau = lag_next(m, ops, ls, which);
+      const bool bol = tau < t_stop;
+      const double stop = bol ? tau : t_stop;
+      if (stop > t_cur) {  // next sub-piece; n = ceil(dt / h_max) as ode_piece
+        const double dt = stop - t_cur;
+        double nf = ceil(dt / m.rk4_h_max);
+        if (!(nf >= 1.0)) nf = 1.0;
+        if (nf > 1.0e7) nf = 1.0e7;
+        rem = static_cast<int32_t>(nf);
+        h = dt / static_cast<double>(rem);
+        t_cur = stop;
+      } else if (bol) {
+        lag_apply_bolus<NS>(m, ops, ls, which, th, x);
       } else {
-        h = ops.op_b[o];
-        rem = ops.op_n[o];
+        in_prop = false;
+        ++o;
       }
-    } else if (kind == OP_OBS) {
-      double y = ode_out<MODEL>(m, L, x, io);
-      if (LAG && st == PMX_PAIR_BAD_LAG) y = nanv;
-      if (ops.ll_obs != nullptr) {
-        ll_accumulate(ops.ll_obs + row * 4, y, ll_acc);
-      } else {
-        if (st == PMX_PAIR_OK && !isfinite(y)) st = PMX_PAIR_NONFINITE;
-        pred[row * ld + p] = y;
-      }
-      ++row;
-    } else if (kind == OP_BOLUS) {
-      const int dest = (m.bolus_dest[io] >= 0) ? m.bolus_dest[io] : io;
-      const double amt = a * fa_of(m, th, io);
-#pragma unroll
-      for (int j = 0; j < NS; ++j) x[j] += (j == dest) ? amt : 0.0;
     } else {
+      const uint32_t meta = ops.op_meta[o];
+      const uint32_t kind = meta & 0xffu;
+      const int io = static_cast<int>((meta >> 8) & 0xffffu);
+      const double a = ops.op_a[o];
+      bool next_op = true;  // LAG: a PROP / an occasion opening stays the current op until the branch above closes it
+      if (kind == OP_PROP) {
+        ode_rates<MODEL>(m, ops.op_rate, o, ops.n_rate, rs);
+        if constexpr (LAG) {
+          in_prop = true;
+          t_cur = ops.op_t0[o];
+          t_stop = ops.op_t1[o];
+          next_op = false;
+        } else {
+          h = ops.op_b[o];
+          rem = ops.op_n[o];
+        }
+      } else if (kind == OP_OBS) {
+        double y = ode_out<MODEL>(m, L, x, io);
+        if (LAG && st == PMX_PAIR_BAD_LAG) y = nanv;
+        if constexpr (LL) {
+          ll_accumulate(ops.ll_obs + row * 4, y, ll_acc);
+        } else {
+          if (st == PMX_PAIR_OK && !isfinite(y)) st = PMX_PAIR_NONFINITE;
+          pred[row * ld + p] = y;
+        }
+        ++row;
+      } else if (kind == OP_BOLUS) {
+        const int dest = (m.bolus_dest[io] >= 0) ? m.bolus_dest[io] : io;
+        const double amt = a * fa_of(m, th, io);
 #pragma unroll
-      for (int j = 0; j < NS; ++j) x[j] = io ? L.xinit[j] : 0.0;
-      if constexpr (LAG) {
-        const int64_t occ = static_cast<int64_t>(a);
+        for (int j = 0; j < NS; ++j) x[j] += (j == dest) ? amt : 0.0;
+      } else {
 #pragma unroll
-        for (int k = 0; k < kMaxLagSlots; ++k) {
-          if (k < m.n_lag_slots) {
-            ls.cur[k] = static_cast<int32_t>(ops.lagb_off[occ * m.n_lag_slots + k]);
-            ls.end[k] = static_cast<int32_t>(ops.lagb_off[occ * m.n_lag_slots + k + 1]);
+        for (int j = 0; j < NS; ++j) x[j] = io ? L.xinit[j] : 0.0;
+        if constexpr (LAG) {
+          const int64_t occ = static_cast<int64_t>(a);
+#pragma unroll
+          for (int k = 0; k < kMaxLagSlots; ++k) {
+            if (k < m.n_lag_slots) {
+              ls.cur[k] = static_cast<int32_t>(ops.lagb_off[occ * m.n_lag_slots + k]);
+              ls.end[k] = static_cast<int32_t>(ops.lagb_off[occ * m.n_lag_slots + k + 1]);
+            }
+          }
+          // boluses landing before the occasion's first remaining event open the occasion (zero rates there)
+          int which;
+          const double tau = lag_next(m, ops, ls, which);
+          const double t_first = ops.op_t0[o];
+          if (tau < t_first && t_first < inf) {
+#pragma unroll
+            for (int j = 0; j < NS; ++j) rs[j] = 0.0;
+            in_prop = true;
+            t_cur = tau;
+            t_stop = t_first;
+            next_op = false;
           }
         }
-        // boluses landing before the occasion's first remaining event open the occasion (zero rates there)
-        int which;
-        const double tau = lag_next(m, ops, ls, which);
-        const double t_first = ops.op_t0[o];
-        if (tau < t_first && t_first < inf) {
-#pragma unroll
-          for (int j = 0; j < NS; ++j) rs[j] = 0.0;
-          in_prop = true;
-          t_cur = tau;
-          t_stop = t_first;
-          continue;
-        }
       }
+      if (next_op) ++o;
     }
-    ++o;
   }
-  if (ops.ll_obs != nullptr) {
+  if constexpr (LL) {
     if (st == PMX_PAIR_OK && !isfinite(ll_acc)) st = PMX_PAIR_NONFINITE;
     if (lane_ok) ops.ll_out[batch ? s : (s * ops.ll_ld + p)] = (st == PMX_PAIR_OK || st == PMX_PAIR_NONFINITE) ? ll_acc : nanv;
   }
@@ -1277,14 +1277,22 @@ hipError_t launch_analytical(const LaunchArgs& a, const char** name) {
     }
     const int64_t n_chunks = (n_walk + s_chunk - 1) / s_chunk;
     const int64_t blocks = n_chunks * a.n_ptiles;
-    hipLaunchKernelGGL((pmx_analytical_grid<KID, DYN, LAG>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlock), 0, st, a.m,
-                       a.ops, a.theta, a.P, n_walk, s_chunk, a.n_ptiles, a.pred, a.ld, a.status, list);
+    if (a.ops.ll_obs != nullptr)
+      hipLaunchKernelGGL((pmx_analytical_grid<KID, DYN, LAG, true>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlock), 0, st,
+                         a.m, a.ops, a.theta, a.P, n_walk, s_chunk, a.n_ptiles, a.pred, a.ld, a.status, list);
+    else
+      hipLaunchKernelGGL((pmx_analytical_grid<KID, DYN, LAG, false>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlock), 0, st,
+                         a.m, a.ops, a.theta, a.P, n_walk, s_chunk, a.n_ptiles, a.pred, a.ld, a.status, list);
   } else {
     *name = kNamePair;
     const int64_t n_pairs = a.batch ? a.S : a.S * a.P;
     const int64_t blocks = (n_pairs + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL((pmx_analytical_pair<KID, DYN, LAG>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlock), 0, st, a.m,
-                       a.ops, a.theta, a.P, a.S, a.batch, a.pred, a.ld, a.status);
+    if (a.ops.ll_obs != nullptr)
+      hipLaunchKernelGGL((pmx_analytical_pair<KID, DYN, LAG, true>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlock), 0, st,
+                         a.m, a.ops, a.theta, a.P, a.S, a.batch, a.pred, a.ld, a.status);
+    else
+      hipLaunchKernelGGL((pmx_analytical_pair<KID, DYN, LAG, false>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlock), 0, st,
+                         a.m, a.ops, a.theta, a.P, a.S, a.batch, a.pred, a.ld, a.status);
   }
   return hipGetLastError();
 }
@@ -1296,14 +1304,22 @@ hipError_t launch_ode_l(const LaunchArgs& a, const char** name) {
     *name = LAG ? "pmx_ode_rk4_grid<lag>" : "pmx_ode_rk4_grid";
     const int64_t n_chunks = (a.S + a.s_chunk - 1) / a.s_chunk;
     const int64_t blocks = n_chunks * a.n_ptiles;
-    hipLaunchKernelGGL((pmx_ode_rk4_grid<MODEL, LAG>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlock), 0, st, a.m, a.ops,
-                       a.theta, a.P, a.S, a.s_chunk, a.n_ptiles, a.pred, a.ld, a.status);
+    if (a.ops.ll_obs != nullptr)
+      hipLaunchKernelGGL((pmx_ode_rk4_grid<MODEL, LAG, true>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlock), 0, st, a.m,
+                         a.ops, a.theta, a.P, a.S, a.s_chunk, a.n_ptiles, a.pred, a.ld, a.status);
+    else
+      hipLaunchKernelGGL((pmx_ode_rk4_grid<MODEL, LAG, false>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlock), 0, st, a.m,
+                         a.ops, a.theta, a.P, a.S, a.s_chunk, a.n_ptiles, a.pred, a.ld, a.status);
   } else {
     *name = LAG ? "pmx_ode_rk4_pair<lag>" : "pmx_ode_rk4_pair";
     const int64_t n_pairs = a.batch ? a.S : a.S * a.P;
     const int64_t blocks = (n_pairs + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL((pmx_ode_rk4_pair<MODEL, LAG>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlock), 0, st, a.m, a.ops,
-                       a.theta, a.P, a.S, a.batch, a.pred, a.ld, a.status);
+    if (a.ops.ll_obs != nullptr)
+      hipLaunchKernelGGL((pmx_ode_rk4_pair<MODEL, LAG, true>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlock), 0, st, a.m,
+                         a.ops, a.theta, a.P, a.S, a.batch, a.pred, a.ld, a.status);
+    else
+      hipLaunchKernelGGL((pmx_ode_rk4_pair<MODEL, LAG, false>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlock), 0, st, a.m,
+                         a.ops, a.theta, a.P, a.S, a.batch, a.pred, a.ld, a.status);
   }
   return hipGetLastError();
 }
