@@ -5,27 +5,36 @@ CSRC := pharmsol_amd/csrc
 LIB := pharmsol_amd/lib/libpmx_hip.so
 # -ffp-contract=off on the HOST side: the population compiler must evaluate covariate
 # lines (slope*t + intercept) exactly like the reference; device code keeps FMA contraction.
-HOSTFLAGS := -O2 -std=c++17 -fPIC -Wall -Wextra -ffp-contract=off
-DEVFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-parameter
-OBJ := $(CSRC)/build/pmx_compile.o $(CSRC)/build/pmx_api.o $(CSRC)/build/pmx_kernels.o
+HOSTFLAGS := -O2 -std=c++17 -fPIC -Wall -Wextra -ffp-contract=off -Iinclude
+DEVFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-parameter -Iinclude
+OBJ := $(CSRC)/build/pmx_compile.o $(CSRC)/build/pmx_api.o $(CSRC)/build/pmx_kernels.o $(CSRC)/build/pmx_jit.o
+DEVHDR := $(CSRC)/pmx_devtypes.hpp $(CSRC)/pmx_device.hpp $(CSRC)/pmx_ode.hpp include/pmx.h
 
 all: $(LIB) oracle
 
-$(CSRC)/build/pmx_compile.o: $(CSRC)/pmx_compile.cpp $(CSRC)/pmx_compile.hpp include/pmx.h
+$(CSRC)/build/pmx_compile.o: $(CSRC)/pmx_compile.cpp $(CSRC)/pmx_compile.hpp $(CSRC)/pmx_devtypes.hpp include/pmx.h
 	@mkdir -p $(CSRC)/build
 	g++ $(HOSTFLAGS) -c $< -o $@
 
-$(CSRC)/build/pmx_api.o: $(CSRC)/pmx_api.cpp $(CSRC)/pmx_compile.hpp $(CSRC)/pmx_kernels.hpp $(CSRC)/pmx_structures.hpp include/pmx.h
+$(CSRC)/build/pmx_api.o: $(CSRC)/pmx_api.cpp $(CSRC)/pmx_compile.hpp $(CSRC)/pmx_kernels.hpp $(CSRC)/pmx_structures.hpp $(CSRC)/pmx_jit.hpp $(DEVHDR)
 	@mkdir -p $(CSRC)/build
 	$(HIPCC) $(DEVFLAGS) -ffp-contract=off -x hip -c $< -o $@
 
-$(CSRC)/build/pmx_kernels.o: $(CSRC)/pmx_kernels.hip $(CSRC)/pmx_kernels.hpp $(CSRC)/pmx_structures.hpp $(CSRC)/pmx_compile.hpp include/pmx.h
+$(CSRC)/build/pmx_kernels.o: $(CSRC)/pmx_kernels.hip $(CSRC)/pmx_kernels.hpp $(CSRC)/pmx_structures.hpp $(CSRC)/pmx_compile.hpp $(DEVHDR)
 	@mkdir -p $(CSRC)/build
 	$(HIPCC) $(DEVFLAGS) -c $< -o $@
 
+# the device headers a run-time (hiprtc) compile of a user model includes, embedded as string literals
+$(CSRC)/build/pmx_jit_headers.inc: $(DEVHDR) tools/embed_headers.py
+	@mkdir -p $(CSRC)/build
+	python3 tools/embed_headers.py $@ include/pmx.h $(CSRC)/pmx_devtypes.hpp $(CSRC)/pmx_device.hpp $(CSRC)/pmx_ode.hpp
+
+$(CSRC)/build/pmx_jit.o: $(CSRC)/pmx_jit.cpp $(CSRC)/pmx_jit.hpp $(CSRC)/build/pmx_jit_headers.inc
+	$(HIPCC) $(DEVFLAGS) -I$(CSRC)/build -x hip -c $< -o $@
+
 $(LIB): $(OBJ)
 	@mkdir -p pharmsol_amd/lib
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJ)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJ) -L/opt/rocm/lib -lhiprtc
 
 oracle:
 	$(MAKE) -C oracle

@@ -20,8 +20,10 @@
 #ifndef PMX_H
 #define PMX_H
 
+#if !defined(__HIPCC_RTC__) /* hiprtc translation units bring their own fixed-width typedefs */
 #include <stddef.h>
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -136,7 +138,8 @@ enum {
   PMX_ODE_THREE_CMT_IV = 4,   /* three_compartment_models.rs test ODE      p=[k10,k12,k13,k21,k31,...] */
   PMX_ODE_THREE_CMT_ORAL = 5, /* p=[ka,k10,k12,k13,k21,k31,...] */
   PMX_ODE_ONE_CMT_MM = 6,     /* nonlinear: dx0 = -vmax*(x0/v)/(km + x0/v) + r0   p=[vmax,km,v] */
-  PMX_ODE_MODEL_COUNT = 7
+  PMX_ODE_MODEL_COUNT = 7,
+  PMX_ODE_CUSTOM = 100        /* user source compiled at run time: pmx_model_create_custom */
 };
 
 /* Where a value is read from. */
@@ -293,6 +296,31 @@ typedef struct pmx_error_model {
   double c[4];    /* ErrorPoly c0..c3 */
   double scalar;  /* lambda (additive) | gamma (proportional) */
 } pmx_error_model;
+
+/* ---- user ODE models compiled at run time (hiprtc) ---------------------------
+ * The reference takes `diffeq` / `out` / `init` as Rust closures (ODE::new, ode/mod.rs:115-132) or as DSL text it
+ * JIT-compiles for the CPU (src/dsl/jit.rs).  Here `source` is C/HIP text defining device functions with the
+ * reference's compiled-kernel argument order (src/dsl/native.rs:45-53: t, states, params, covariates, routes,
+ * derived, out):
+ *
+ *   PMX_DEVICE void pmx_dynamics(double t, const double* x, const double* p, const double* cov,
+ *                                const double* rateiv, const double* derived, double* dx);   // dx pre-zeroed
+ *   PMX_DEVICE void pmx_outputs (double t, const double* x, const double* p, const double* cov,
+ *                                const double* rateiv, const double* derived, double* y);    // y pre-zeroed
+ *   PMX_DEVICE void pmx_init    (double t, const double* x0, const double* p, const double* cov,
+ *                                const double* rateiv, const double* derived, double* x);    // iff has_init
+ *
+ * `rateiv[i]` is the active infusion rate of input i (the body adds it where the route goes, like a hand-written
+ * closure), `p` the support point in model order; `cov` and `derived` are NULL in this build (covariates are not
+ * available to custom bodies yet).  desc: eq_kind = PMX_EQ_ODE, kernel = PMX_ODE_CUSTOM, nstates/ndrugs/nout/
+ * nparams, rk4_h_max, lag_param/fa_param/bolus_dest as for built-in models; `out[]` is ignored.  The source is
+ * compiled for gfx950 at creation time (no device needed; PMX_ERR_INVALID_ARGUMENT + the compiler log in
+ * pmx_last_error() on a compile error) and runs through the same walkers, RK4 stepper, lag/fa handling and fused
+ * log-likelihood as the built-in bodies. */
+int32_t pmx_model_create_custom(const pmx_model_desc* desc, const char* source, int32_t has_init, pmx_model** out);
+/* The translation unit that was (or would be) handed to hiprtc for this source; free with pmx_free_text. */
+int32_t pmx_debug_jit_source(const pmx_model_desc* desc, const char* source, int32_t has_init, char** out_text);
+void pmx_free_text(char* text);
 
 /*   em   [model.nout] error model per output equation
  *   ll   [n_subjects x ld_ll], ll[s*ld_ll + p]  (the reference's Array2 (n_subjects, n_support); it stores

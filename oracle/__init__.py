@@ -71,6 +71,34 @@ def lib():
     return _lib
 
 
+def compile_custom(source: str, has_init: bool = False) -> None:
+    """Build the SAME user source the device compiles (``ODE.custom``) with gcc (``-ffp-contract=off``) and register
+    its bodies with the oracle.  The handles stay alive in this module (one custom model at a time: tests only)."""
+    import hashlib
+    import tempfile
+
+    global _custom_lib
+    h = hashlib.sha1(source.encode()).hexdigest()[:16]
+    d = os.path.join(tempfile.gettempdir(), "pmx_oracle_custom")
+    os.makedirs(d, exist_ok=True)
+    so = os.path.join(d, f"m{h}.so")
+    if not os.path.exists(so):
+        src = os.path.join(d, f"m{h}.cpp")
+        with open(src, "w") as f:
+            f.write('#include <cmath>\nusing namespace std;\n#define PMX_DEVICE extern "C"\n#line 1 "model"\n' + source)
+        subprocess.run(["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-o", so, src], check=True)
+    cl = C.CDLL(so)
+    fn = lambda n: C.cast(getattr(cl, n), C.c_void_p)  # noqa: E731
+    L = lib()
+    L.pmx_oracle_set_custom.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pmx_oracle_set_custom.restype = None
+    L.pmx_oracle_set_custom(fn("pmx_dynamics"), fn("pmx_outputs"), fn("pmx_init") if has_init else None)
+    _custom_lib = cl
+
+
+_custom_lib = None
+
+
 def max_threads() -> int:
     return int(lib().pmx_oracle_max_threads())
 

@@ -542,10 +542,26 @@ static void model_seq_eq(const ctx_t* c, double* pv, double t) {
   if (c->m->kernel == PMX_ORACLE_K_TEST_SEQ_ACCUM) pv[0] += 1.0; /* analytical/mod.rs:499-501 */
 }
 
+/* User bodies of a PMX_ODE_CUSTOM model (the closures of ODE::new, ode/mod.rs:115-132), argument order of the
+ * reference's compiled kernels (src/dsl/native.rs:45-53).  Registered by the test harness, which builds the very
+ * source text the device compiles with gcc (oracle/__init__.py compile_custom). */
+typedef void (*pmx_custom_fn)(double t, const double* x, const double* p, const double* cov, const double* rateiv,
+                              const double* derived, double* out);
+static pmx_custom_fn g_custom_dynamics = 0, g_custom_outputs = 0, g_custom_init = 0;
+void pmx_oracle_set_custom(void* dynamics, void* outputs, void* init) {
+  g_custom_dynamics = (pmx_custom_fn)dynamics;
+  g_custom_outputs = (pmx_custom_fn)outputs;
+  g_custom_init = (pmx_custom_fn)init;
+}
+
 /* `out`: y[o] = x[state] / vol, derive at the observation time
  * (expand/analytical.rs:320-326; e.g. examples/analytical_readme.rs:21-23) */
 static int model_out(const ctx_t* c, const double* x, const double* theta, double t_obs, double* y) {
   const pmx_model_desc* m = c->m;
+  if (m->eq_kind == PMX_EQ_ODE && m->kernel == PMX_ODE_CUSTOM) {
+    g_custom_outputs(t_obs, x, theta, 0, 0, 0, y); /* y zeroed by the caller */
+    return 0;
+  }
   double derived[PMX_MAX_DERIVED];
   int need = 0;
   for (int o = 0; o < m->nout; o++) need |= (m->out[o].vol_src == PMX_SRC_DERIVED);
@@ -679,7 +695,12 @@ static void ode_rhs(int model, const double* x, const double* p, double* dx) {
 
 /* PmRhs::call_inplace (closure.rs:344-357) + the ode! route injection
  * dx[dest] += rateiv[i] (expand/ode.rs:380-406). */
-static void ode_f(const pmx_model_desc* m, const double* x, const double* p, const double* rate, double* dx) {
+static void ode_f(const pmx_model_desc* m, double t, const double* x, const double* p, const double* rate, double* dx) {
+  if (m->kernel == PMX_ODE_CUSTOM) { /* the body adds rateiv itself, like a hand-written closure */
+    for (int i = 0; i < m->nstates; i++) dx[i] = 0.0;
+    g_custom_dynamics(t, x, p, 0, rate, 0, dx);
+    return;
+  }
   ode_rhs(m->kernel, x, p, dx);
   for (int i = 0; i < m->ndrugs; i++) {
     if (rate[i] != 0.0) {
@@ -700,13 +721,14 @@ static void rk4_piece(const pmx_model_desc* m, double* x, const double* p, const
   int ns = m->nstates;
   double k1[PMX_MAX_STATES], k2[PMX_MAX_STATES], k3[PMX_MAX_STATES], k4[PMX_MAX_STATES], xt[PMX_MAX_STATES];
   for (int64_t s = 0; s < n; s++) {
-    ode_f(m, x, p, rate, k1);
+    double t = t0 + (double)s * h; /* stage times t, t + h/2, t + h/2, t + h */
+    ode_f(m, t, x, p, rate, k1);
     for (int i = 0; i < ns; i++) xt[i] = x[i] + (0.5 * h) * k1[i];
-    ode_f(m, xt, p, rate, k2);
+    ode_f(m, t + 0.5 * h, xt, p, rate, k2);
     for (int i = 0; i < ns; i++) xt[i] = x[i] + (0.5 * h) * k2[i];
-    ode_f(m, xt, p, rate, k3);
+    ode_f(m, t + 0.5 * h, xt, p, rate, k3);
     for (int i = 0; i < ns; i++) xt[i] = x[i] + h * k3[i];
-    ode_f(m, xt, p, rate, k4);
+    ode_f(m, t + h, xt, p, rate, k4);
     for (int i = 0; i < ns; i++) x[i] = x[i] + (h / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
   }
 }
@@ -739,9 +761,11 @@ static int simulate_pair(const pmx_model_desc* m, const pmx_population_desc* pop
      * (analytical/mod.rs:409-426, ode/mod.rs:536-549) */
     double x[PMX_MAX_STATES + 1];
     for (int i = 0; i <= PMX_MAX_STATES; i++) x[i] = 0.0;
-    if (occ_index == 0)
+    if (occ_index == 0) {
       for (int i = 0; i < m->nstates; i++)
         if (m->init_param[i] >= 0) x[i] = theta[m->init_param[i]];
+      if (m->eq_kind == PMX_EQ_ODE && m->kernel == PMX_ODE_CUSTOM && g_custom_init) g_custom_init(0.0, x, theta, 0, 0, 0, x);
+    }
     /* resolve_occasion_events: clone + process_events (equation/mod.rs:247-273, structs.rs:681-690) */
     int64_t e0 = pop->occ_ev_off[oc], e1 = pop->occ_ev_off[oc + 1];
     int64_t n = e1 - e0;
@@ -904,8 +928,12 @@ static int validate(const pmx_model_desc* m, const pmx_population_desc* pop) {
         FAIL(PMX_ERR_INVALID_ARGUMENT, "kernel needs %d bindings, got %d", np, m->n_bind);
     }
   } else if (m->eq_kind == PMX_EQ_ODE) {
-    if (ode_nstates(m->kernel) < 0) FAIL(PMX_ERR_INVALID_ARGUMENT, "unknown ODE model %d", m->kernel);
-    if (m->nstates < ode_nstates(m->kernel)) FAIL(PMX_ERR_INVALID_ARGUMENT, "ODE model needs more states");
+    if (m->kernel == PMX_ODE_CUSTOM) {
+      if (!g_custom_dynamics || !g_custom_outputs) FAIL(PMX_ERR_INVALID_ARGUMENT, "custom ODE bodies not registered");
+    } else {
+      if (ode_nstates(m->kernel) < 0) FAIL(PMX_ERR_INVALID_ARGUMENT, "unknown ODE model %d", m->kernel);
+      if (m->nstates < ode_nstates(m->kernel)) FAIL(PMX_ERR_INVALID_ARGUMENT, "ODE model needs more states");
+    }
     if (!(m->rk4_h_max > 0.0)) FAIL(PMX_ERR_INVALID_ARGUMENT, "rk4_h_max must be > 0");
   } else
     FAIL(PMX_ERR_INVALID_ARGUMENT, "unknown eq_kind %d", m->eq_kind);

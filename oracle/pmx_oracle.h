@@ -50,6 +50,9 @@ int32_t pmx_oracle_loglik(const pmx_model_desc* model, const pmx_population_desc
                           int32_t nthreads);
 /* AssayErrorModel::sigma for an observed value (error_model.rs:1045-1080); returns PMX_OK or PMX_ERR_ERROR_MODEL. */
 int32_t pmx_oracle_sigma(const pmx_error_model* em, double observation, double* sigma);
+/* PMX_ODE_CUSTOM: the three user bodies (any may be NULL except dynamics/outputs), see oracle/__init__.py */
+void pmx_oracle_set_custom(void* dynamics, void* outputs, void* init);
+
 /* lognormpdf (likelihood/distributions.rs:31-34) */
 double pmx_oracle_lognormpdf(double obs, double pred, double sigma);
 /* lognormcdf / lognormccdf (likelihood/distributions.rs:52-103); upper != 0 selects the survival function */

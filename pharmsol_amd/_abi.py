@@ -101,6 +101,7 @@ ODE_MODELS = {
     "three_cmt_oral": 5,
     "one_cmt_mm": 6,
 }
+PMX_ODE_CUSTOM = 100
 ODE_STATE_COUNT = {"one_cmt_iv": 1, "one_cmt_oral": 2, "two_cmt_iv": 2, "two_cmt_oral": 3, "three_cmt_iv": 3,
                    "three_cmt_oral": 4, "one_cmt_mm": 1}
 ODE_PARAM_COUNT = {"one_cmt_iv": 1, "one_cmt_oral": 2, "two_cmt_iv": 3, "two_cmt_oral": 4, "three_cmt_iv": 5,

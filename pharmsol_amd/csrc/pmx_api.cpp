@@ -8,12 +8,14 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../include/pmx.h"
 #include "pmx_compile.hpp"
+#include "pmx_jit.hpp"
 #include "pmx_kernels.hpp"
 #include "pmx_structures.hpp"  // kernel_nparams()
 
@@ -113,6 +115,14 @@ struct pmx_model {
   pmx_model_desc d;
   bool dyn = false;  // kernel parameters depend on covariates
   bool has_init = false;
+  // custom (hiprtc) models: the code object and its per-device modules
+  bool custom = false;
+  std::vector<char> jit_code;
+  mutable std::mutex jit_mu;
+  mutable std::map<int, pmx::JitModule> jit_modules;
+  ~pmx_model() {
+    for (auto& kv : jit_modules) pmx::jit_unload(&kv.second);
+  }
 };
 
 extern "C" {
@@ -180,6 +190,8 @@ int32_t pmx_model_create(const pmx_model_desc* d, pmx_model** out) {
   g_err.clear();
   if (!d || !out) return fail(PMX_ERR_INVALID_ARGUMENT, "null argument");
   *out = nullptr;
+  if (d->eq_kind == PMX_EQ_ODE && d->kernel == PMX_ODE_CUSTOM)
+    return fail(PMX_ERR_INVALID_ARGUMENT, "PMX_ODE_CUSTOM models are created with pmx_model_create_custom");
   if (d->nstates < 1 || d->nstates > PMX_MAX_STATES) return fail(PMX_ERR_INVALID_ARGUMENT, "nstates out of range");
   if (d->ndrugs < 0 || d->ndrugs > PMX_MAX_INPUTS) return fail(PMX_ERR_INVALID_ARGUMENT, "ndrugs out of range");
   if (d->nout < 1 || d->nout > PMX_MAX_OUT) return fail(PMX_ERR_INVALID_ARGUMENT, "nout out of range");
@@ -262,6 +274,77 @@ int32_t pmx_model_create(const pmx_model_desc* d, pmx_model** out) {
   return PMX_OK;
 }
 
+}  // extern "C"
+
+namespace {
+int32_t check_custom_desc(const pmx_model_desc* d, const char* source) {
+  if (!d || !source) return fail(PMX_ERR_INVALID_ARGUMENT, "null argument");
+  if (d->eq_kind != PMX_EQ_ODE || d->kernel != PMX_ODE_CUSTOM)
+    return fail(PMX_ERR_INVALID_ARGUMENT, "custom models need eq_kind = PMX_EQ_ODE and kernel = PMX_ODE_CUSTOM");
+  if (d->nstates < 1 || d->nstates > PMX_MAX_STATES) return fail(PMX_ERR_INVALID_ARGUMENT, "nstates out of range");
+  if (d->ndrugs < 0 || d->ndrugs > PMX_MAX_INPUTS) return fail(PMX_ERR_INVALID_ARGUMENT, "ndrugs out of range");
+  if (d->nout < 1 || d->nout > PMX_MAX_OUT) return fail(PMX_ERR_INVALID_ARGUMENT, "nout out of range");
+  if (d->nparams < 1 || d->nparams > PMX_MAX_PARAMS) return fail(PMX_ERR_INVALID_ARGUMENT, "nparams out of range");
+  if (!(d->rk4_h_max > 0.0)) return fail(PMX_ERR_INVALID_ARGUMENT, "rk4_h_max must be > 0");
+  if (d->n_covariates != 0 || d->n_derived != 0 || d->n_bind != 0 || d->pmetrics_indexing)
+    return fail(PMX_ERR_UNSUPPORTED, "covariates / derived parameters / pm indexing are not available to custom ODE bodies yet");
+  int n_lag = 0;
+  for (int i = 0; i < PMX_MAX_INPUTS; ++i) {
+    if (d->lag_param[i] >= d->nparams || d->fa_param[i] >= d->nparams)
+      return fail(PMX_ERR_INVALID_ARGUMENT, "lag_param / fa_param out of range");
+    if (d->bolus_dest[i] >= d->nstates) return fail(PMX_ERR_INVALID_ARGUMENT, "route destination out of range");
+    n_lag += d->lag_param[i] >= 0;
+  }
+  if (n_lag > pmx::kMaxLagSlots) return fail(PMX_ERR_UNSUPPORTED, "more than 4 lagged inputs are not supported on the device path");
+  return PMX_OK;
+}
+pmx::JitSpec spec_of(const pmx_model_desc* d, const char* source, int32_t has_init) {
+  pmx::JitSpec sp;
+  sp.nstates = d->nstates;
+  sp.nparams = d->nparams;
+  sp.nout = d->nout;
+  sp.ninputs = d->ndrugs > 0 ? d->ndrugs : 1;
+  sp.has_init = has_init != 0;
+  sp.source = source;
+  return sp;
+}
+}  // namespace
+
+extern "C" {
+
+int32_t pmx_model_create_custom(const pmx_model_desc* d, const char* source, int32_t has_init, pmx_model** out) {
+  g_err.clear();
+  if (!out) return fail(PMX_ERR_INVALID_ARGUMENT, "out is null");
+  *out = nullptr;
+  const int32_t rc = check_custom_desc(d, source);
+  if (rc != PMX_OK) return rc;
+  auto m = std::make_unique<pmx_model>();
+  m->d = *d;
+  m->custom = true;
+  m->has_init = has_init != 0;
+  std::string log;
+  if (!pmx::jit_compile(spec_of(d, source, has_init), &m->jit_code, &log))
+    return fail(PMX_ERR_INVALID_ARGUMENT, "hiprtc could not compile the model source:\n" + log);
+  *out = m.release();
+  return PMX_OK;
+}
+
+int32_t pmx_debug_jit_source(const pmx_model_desc* d, const char* source, int32_t has_init, char** out_text) {
+  g_err.clear();
+  if (!out_text) return fail(PMX_ERR_INVALID_ARGUMENT, "out_text is null");
+  *out_text = nullptr;
+  const int32_t rc = check_custom_desc(d, source);
+  if (rc != PMX_OK) return rc;
+  const std::string tu = pmx::jit_translation_unit(spec_of(d, source, has_init));
+  char* buf = static_cast<char*>(std::malloc(tu.size() + 1));
+  if (!buf) return fail(PMX_ERR_OUT_OF_MEMORY, "malloc");
+  std::memcpy(buf, tu.c_str(), tu.size() + 1);
+  *out_text = buf;
+  return PMX_OK;
+}
+
+void pmx_free_text(char* text) { std::free(text); }
+
 void pmx_model_destroy(pmx_model* m) { delete m; }
 
 }  // extern "C"
@@ -297,6 +380,7 @@ pmx::CompileKey key_for(const pmx_model* m) {
     k.rate_input = 0;
     for (int i = 0; i < PMX_MAX_INPUTS; ++i)
       if (m->d.lag_param[i] >= 0) k.lag_mask |= (1u << i);
+    k.want_times = m->custom;  // a user body may be non-autonomous
   }
   return k;
 }
@@ -548,7 +632,42 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
     if (me != hipSuccess) return fail(PMX_ERR_HIP, std::string("hipMemsetAsync(status): ") + hipGetErrorString(me));
   }
   const char* name = "";
-  hipError_t e = pmx::launch_predict(a, &name);
+  hipError_t e;
+  if (model->custom) {
+    // hiprtc-compiled model: resolve (once per device) and launch the matching entry point of its module
+    const pmx::JitModule* jm = nullptr;
+    {
+      std::lock_guard<std::mutex> lock(model->jit_mu);
+      auto it = model->jit_modules.find(pop->device);
+      if (it == model->jit_modules.end()) {
+        pmx::JitModule mod;
+        const hipError_t le = pmx::jit_load(model->jit_code, &mod);
+        if (le != hipSuccess) return fail(PMX_ERR_HIP, std::string("loading the compiled model: ") + hipGetErrorString(le));
+        it = model->jit_modules.emplace(pop->device, mod).first;
+      }
+      jm = &it->second;
+    }
+    const int lag = a.m.n_lag_slots > 0 ? 1 : 0, ll = a.ops.ll_obs != nullptr ? 1 : 0;
+    const int mode = a.mode == pmx::MODE_GRID ? 0 : 1;
+    static const char* const kNames[2][2] = {{"pmx_jit_ode_rk4_grid", "pmx_jit_ode_rk4_grid<lag>"},
+                                             {"pmx_jit_ode_rk4_pair", "pmx_jit_ode_rk4_pair<lag>"}};
+    name = kNames[mode][lag];
+    if (a.S <= 0 || (a.P <= 0 && !a.batch)) {
+      e = hipSuccess;
+    } else if (mode == 0) {
+      const int64_t n_chunks = (a.S + a.s_chunk - 1) / a.s_chunk;
+      void* args[] = {&a.m, &a.ops, &a.theta, &a.P, &a.S, &a.s_chunk, &a.n_ptiles, &a.pred, &a.ld, &a.status};
+      e = hipModuleLaunchKernel(jm->fn[0][lag][ll], static_cast<uint32_t>(n_chunks * a.n_ptiles), 1, 1, 256, 1, 1, 0,
+                                static_cast<hipStream_t>(stream), args, nullptr);
+    } else {
+      const int64_t n_pairs = a.batch ? a.S : a.S * a.P;
+      void* args[] = {&a.m, &a.ops, &a.theta, &a.P, &a.S, &a.batch, &a.pred, &a.ld, &a.status};
+      e = hipModuleLaunchKernel(jm->fn[1][lag][ll], static_cast<uint32_t>((n_pairs + 255) / 256), 1, 1, 256, 1, 1, 0,
+                                static_cast<hipStream_t>(stream), args, nullptr);
+    }
+  } else {
+    e = pmx::launch_predict(a, &name);
+  }
   g_kernel_name = name;
   if (e != hipSuccess) return fail(PMX_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
   return PMX_OK;

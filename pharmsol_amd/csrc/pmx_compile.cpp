@@ -207,6 +207,7 @@ int32_t compile_ops(const HostPopulation& hp, const CompileKey& key, OpStream* o
   os->n_lag_slots = n_slots;
   std::vector<std::vector<std::pair<double, double>>> lagb(n_slots > 0 ? n_slots : 1);  // per slot, this occasion
   if (n_slots > 0) os->lagb_off.push_back(0);
+  const bool times = n_slots > 0 || key.want_times;  // PROP ops carry their absolute [t0, t1)
 
   std::vector<double> covv(nc > 0 ? nc : 1, 0.0);
   std::vector<double> rate(n_rate > 0 ? n_rate : 1, 0.0);
@@ -217,7 +218,7 @@ int32_t compile_ops(const HostPopulation& hp, const CompileKey& key, OpStream* o
     os->op_meta.push_back(make_meta(kind, io));
     os->op_a.push_back(a);
     os->op_b.push_back(b);
-    if (n_slots > 0) {
+    if (times) {
       os->op_t0.push_back(0.0);
       os->op_t1.push_back(0.0);
     }
@@ -319,7 +320,7 @@ int32_t compile_ops(const HostPopulation& hp, const CompileKey& key, OpStream* o
               const double dt = nxt - cur;
               const double t_cov = key.cov_time_mode == PMX_COV_TIME_SEGMENT_END_ABS ? nxt : dt;
               push(OP_PROP, 0, dt, r0, 0, nullptr, oc, t_cov, true);
-              if (n_slots > 0) {
+              if (times) {
                 os->op_t0.back() = cur;
                 os->op_t1.back() = nxt;
               }
@@ -387,7 +388,7 @@ int32_t compile_ops(const HostPopulation& hp, const CompileKey& key, OpStream* o
                 }
                 const int32_t n = static_cast<int32_t>(nf);
                 push(OP_PROP, 0, dt, dt / static_cast<double>(n), n, rate.data(), oc, t, true);
-                if (n_slots > 0) {
+                if (times) {
                   os->op_t0.back() = t;
                   os->op_t1.back() = stop;
                 }

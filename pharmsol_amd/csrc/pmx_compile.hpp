@@ -20,11 +20,11 @@
 #include <string>
 #include <vector>
 
-#include "../../include/pmx.h"
+#include "pmx_devtypes.hpp"
 
 namespace pmx {
 
-enum OpKind : uint32_t { OP_RESET = 0, OP_BOLUS = 1, OP_OBS = 2, OP_PROP = 3 };
+// enum OpKind { OP_RESET, OP_BOLUS, OP_OBS, OP_PROP }: pmx_devtypes.hpp
 
 // op_meta layout: bits 0..7 kind, 8..23 io (input / outeq / reset: 1 = run init), 24..31 unused
 inline uint32_t make_meta(uint32_t kind, uint32_t io) { return kind | (io << 8); }
@@ -67,12 +67,13 @@ struct CompileKey {
   int32_t class_g = 0;     // analytical GRID: members per chunk of the classed kernel (0 = no class plan)
   uint32_t lag_mask = 0;   // bit i: boluses on input i are delayed by a theta-dependent lag -> kept OUT of the
                            // op stream and merged per lane on the device (Occasion::add_lagtime, structs.rs:611-643)
+  bool want_times = false; // PROP ops carry absolute [t0, t1) even without lag (custom ODE bodies may read the time)
   bool ladder = false;     // analytical, theta-only coefficients, no lag: PROP ops carry the exponential-ladder code
                            // (bits 27-29 of op_meta, pmx_structures.hpp ladder_pow)
   bool operator==(const CompileKey& o) const {
     return eq_kind == o.eq_kind && cov_time_mode == o.cov_time_mode && rk4_h_max == o.rk4_h_max &&
            n_rate == o.n_rate && rate_input == o.rate_input && class_g == o.class_g && lag_mask == o.lag_mask &&
-           ladder == o.ladder;
+           ladder == o.ladder && want_times == o.want_times;
   }
 };
 

@@ -1,0 +1,148 @@
+// pmx_device.hpp — device helpers shared by every kernel family (and by hiprtc-compiled user models).
+#pragma once
+
+#if !defined(__HIPCC_RTC__)
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#endif
+
+#include "pmx_devtypes.hpp"
+
+namespace pmx {
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ int64_t uniform64(int64_t v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
+  const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(static_cast<uint64_t>(v) >> 32));
+  return static_cast<int64_t>((static_cast<uint64_t>(hi) << 32) | lo);
+}
+__device__ __forceinline__ uint32_t uniform32(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// Read-only-for-the-launch data addressed with wave-uniform indices: a constant-address-space
+// pointer lets the backend use the scalar unit (s_load_*) instead of 64 identical vector loads.
+template <class T>
+using cptr = const __attribute__((address_space(4))) T*;
+template <class T>
+__device__ __forceinline__ cptr<T> as_const(const T* p) {
+  return (cptr<T>)(p);
+}
+__device__ __forceinline__ double uniformf64(double v) {
+  return __longlong_as_double(uniform64(__double_as_longlong(v)));
+}
+
+// derive: derived[d] = ((theta[src] * f0) * f1), covariates as seen by the op
+
+template <int N>
+__device__ __forceinline__ double select_state(const double (&x)[N], int idx) {
+  // The empty asm pins each element in a VGPR pair: without it LLVM rewrites the select chain into
+  // ONE load from a selected address, which forces the whole state array out of registers (it was
+  // promoted to LDS/scratch for every 3- and 4-state structure).
+  double v = x[0];
+#pragma unroll
+  for (int i = 1; i < N; ++i) {
+    double xi = x[i];
+    asm volatile("" : "+v"(xi));
+    v = (idx == i) ? xi : v;
+  }
+  return v;
+}
+
+// ------------------------------------------------------------------------------------
+// theta-dependent event rewrite on the device: lag time and bioavailability
+// (Occasion::add_lagtime / add_bioavailability, src/data/structs.rs:611-666).
+// Lagged boluses are NOT in the op stream; each lane merges them at t + lag(theta): a bolus that lands
+// inside a PROP [t0, t1) splits it exactly where the reference's re-sorted event list would
+// (solve(prev, tau), bolus, solve(tau, next)), a bolus that lands before the occasion's first remaining
+// event opens the occasion.  At equal times an observation precedes the bolus (event.rs:292-304): a
+// bolus landing exactly on an event time is applied at the START of the next PROP.
+// ------------------------------------------------------------------------------------
+struct LagState {
+  double lag[kMaxLagSlots];
+  int32_t cur[kMaxLagSlots];
+  int32_t end[kMaxLagSlots];
+};
+
+__device__ __forceinline__ double fa_of(const DevModel& m, const double* __restrict__ th, int input) {
+  double f = 1.0;
+  if (m.has_fa) {  // wave-uniform; models without bioavailability never enter
+    int fp = -1;
+#pragma unroll
+    for (int i = 0; i < PMX_MAX_INPUTS; ++i) fp = (i == input) ? m.fa_param[i] : fp;
+    if (fp >= 0) f = th[fp];
+  }
+  return f;
+}
+
+// earliest pending lagged bolus: returns its landing time (inf if none) and slot
+__device__ __forceinline__ double lag_next(const DevModel& m, const DevOps& ops, const LagState& ls, int& which) {
+  double tau = __longlong_as_double(0x7ff0000000000000LL);
+  which = -1;
+#pragma unroll
+  for (int k = 0; k < kMaxLagSlots; ++k) {
+    if (k < m.n_lag_slots && ls.cur[k] < ls.end[k]) {
+      const double tk = ops.lagb_time[ls.cur[k]] + ls.lag[k];
+      if (tk < tau) {
+        tau = tk;
+        which = k;
+      }
+    }
+  }
+  return tau;
+}
+
+template <int NS>
+__device__ __forceinline__ void lag_apply_bolus(const DevModel& m, const DevOps& ops, LagState& ls, int which,
+                                                const double* __restrict__ th, double (&x)[NS]) {
+  int32_t idx = 0;
+  int input = 0, dest = 0;
+#pragma unroll
+  for (int k = 0; k < kMaxLagSlots; ++k) {
+    if (k == which) {
+      idx = ls.cur[k];
+      input = m.lag_input[k];
+      dest = m.lag_dest[k];
+      ls.cur[k] += 1;
+    }
+  }
+  const double amt = ops.lagb_amount[idx] * fa_of(m, th, input);
+#pragma unroll
+  for (int i = 0; i < NS; ++i) x[i] += (i == dest) ? amt : 0.0;
+}
+
+// One observation in log-likelihood mode: acc += lognormpdf(obs, y, sigma) with the sigma-only parts
+// precomputed on the host (likelihood/distributions.rs:31-34; sigma from the observation,
+// error_model.rs:1045-1080).  `q` = {obs, -0.5 ln(2 pi) - ln sigma, 1/(2 sigma^2), censor scale}.
+// Censored rows (q[3] = +1/(sigma sqrt 2): BLOQ, -1/(sigma sqrt 2): ALOQ) take the log CDF / log survival
+// function of distributions.rs:52-103, with statrs' Normal::cdf = 0.5 erfc((mean - x)/(sigma sqrt 2)); a tail
+// that underflows falls back to the reference's asymptote (|z| > 37) or poisons the sum with NaN (its Err).
+__device__ __forceinline__ void ll_accumulate(const double* __restrict__ q, double y, double& acc) {
+  const double w = q[2];
+  if (w != 0.0) {  // weight 0 = missing observation: contributes 0 whatever the prediction (prediction.rs:107-111)
+    const double d = q[0] - y;
+    const double pdf = q[1] - (d * d) * w;
+    const double cs = q[3];
+    if (cs == 0.0) {  // wave-uniform
+      acc += pdf;
+    } else {
+      const double inv = fabs(cs);
+      const double cdf = 0.5 * erfc((y - q[0]) * inv);
+      const double z = d * (inv * 1.4142135623730951);  // (obs - pred) / sigma
+      const double nanv = __longlong_as_double(0x7ff8000000000000LL);
+      double ll;
+      if (cs > 0.0) {  // BLOQ: ln P(X <= obs)
+        ll = (cdf > 0.0) ? log(cdf) : ((z < -37.0) ? pdf - log(fabs(z)) : nanv);
+      } else {  // ALOQ: ln P(X > obs), computed as 1 - cdf like the reference
+        const double sf = 1.0 - cdf;
+        ll = (sf > 0.0) ? log(sf) : ((z > 37.0) ? pdf - log(z) : nanv);
+      }
+      acc += ll;
+    }
+  }
+}
+
+}  // namespace
+}  // namespace pmx

@@ -1,0 +1,64 @@
+// pmx_devtypes.hpp — the structs the kernels receive by value (kernarg segment).  Shared by the library's own
+// translation unit and by the sources hiprtc compiles at run time for user models (pmx_jit.cpp), so it must
+// stay free of host-only headers.
+#pragma once
+
+#if !defined(__HIPCC_RTC__)
+#include <cstdint>
+#endif
+
+#include "pmx.h"
+
+namespace pmx {
+
+// op kinds of the flattened per-subject stream (pmx_compile.hpp OpStream)
+enum OpKind : uint32_t { OP_RESET = 0, OP_BOLUS = 1, OP_OBS = 2, OP_PROP = 3 };
+
+// Model description as the kernels see it (passed by value in the kernarg segment).
+struct DevModel {
+  int32_t eq_kind, kernel;
+  int32_t nparams, n_cov, n_derived, n_bind, nout, pm;
+  int32_t has_init;
+  int32_t pad_;
+  pmx_derived derived[PMX_MAX_DERIVED];
+  pmx_bind bind[PMX_MAX_KPARAMS];
+  pmx_out out[PMX_MAX_OUT];
+  int32_t init_param[PMX_MAX_STATES];
+  int32_t bolus_dest[PMX_MAX_INPUTS];
+  int32_t infusion_dest[PMX_MAX_INPUTS];
+  int32_t fa_param[PMX_MAX_INPUTS];   // bioavailability: amount *= theta[fa_param[input]]  (structs.rs:645-666)
+  int32_t n_lag_slots;                // lagged inputs (<= kMaxLagSlots)
+  int32_t has_fa;
+  int32_t lag_input[4];               // slot -> input
+  int32_t lag_param[4];               // slot -> theta index of the lag time
+  int32_t lag_dest[4];                // slot -> state that receives the bolus
+  double rk4_h_max;                   // ODE + lag: pieces split on the device recompute n = ceil(dt / h_max)
+};
+constexpr int kMaxLagSlots = 4;
+
+// Device mirror of an OpStream (all pointers are device pointers).
+struct DevOps {
+  const int64_t* subj_op_off;   // [S+1]
+  const int64_t* subj_obs_off;  // [S+1]
+  const int32_t* subj_order;    // [S]
+  const uint32_t* op_meta;      // [n_ops]
+  const double* op_a;           // [n_ops]
+  const double* op_b;           // [n_ops]
+  const int32_t* op_n;          // [n_ops] (ODE)
+  const double* op_rate;        // [n_ops*n_rate] (ODE)
+  const double* op_cov;         // [n_ops*n_cov]
+  const double* op_t0;          // lag models: absolute start of each PROP / first event time of a RESET's occasion
+  const double* op_t1;          // lag models: absolute end of each PROP
+  const int64_t* lagb_off;      // [(n_occasions*n_lag_slots)+1]
+  const double* lagb_time;
+  const double* lagb_amount;
+  // fused log-likelihood (pmx_loglik): nullptr = prediction mode
+  const double* ll_obs;         // [n_observations][4] = {observed value, -0.5 ln(2pi) - ln(sigma), 1/(2 sigma^2), 0};
+                                //   weight 0 marks a missing observation (contributes nothing)
+  double* ll_out;               // [n_subjects x ll_ld]
+  int64_t ll_ld;
+  int32_t n_rate;
+  int32_t pad_;
+};
+
+}  // namespace pmx

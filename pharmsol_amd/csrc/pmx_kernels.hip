@@ -30,31 +30,12 @@
 
 #include "pmx_kernels.hpp"
 #include "pmx_structures.hpp"
+#include "pmx_device.hpp"
+#include "pmx_ode.hpp"
 
 namespace pmx {
 
 namespace {
-
-constexpr int kBlock = 256;
-
-__device__ __forceinline__ int64_t uniform64(int64_t v) {
-  const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
-  const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(static_cast<uint64_t>(v) >> 32));
-  return static_cast<int64_t>((static_cast<uint64_t>(hi) << 32) | lo);
-}
-__device__ __forceinline__ uint32_t uniform32(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-
-// Read-only-for-the-launch data addressed with wave-uniform indices: a constant-address-space
-// pointer lets the backend use the scalar unit (s_load_*) instead of 64 identical vector loads.
-template <class T>
-using cptr = const __attribute__((address_space(4))) T*;
-template <class T>
-__device__ __forceinline__ cptr<T> as_const(const T* p) {
-  return (cptr<T>)(p);
-}
-__device__ __forceinline__ double uniformf64(double v) {
-  return __longlong_as_double(uniform64(__double_as_longlong(v)));
-}
 
 // derive: derived[d] = ((theta[src] * f0) * f1), covariates as seen by the op
 // (expand/analytical.rs:254,286; bindings.rs:98-117).  `base` = theta[src_param].
@@ -68,21 +49,6 @@ __device__ __forceinline__ double apply_factors(const pmx_derived& dd, double ba
       const double fac = (f.op == PMX_F_POW) ? pow(cv / f.ref, f.coef) : (1.0 + f.coef * (cv - f.ref));
       v = v * fac;
     }
-  }
-  return v;
-}
-
-template <int N>
-__device__ __forceinline__ double select_state(const double (&x)[N], int idx) {
-  // The empty asm pins each element in a VGPR pair: without it LLVM rewrites the select chain into
-  // ONE load from a selected address, which forces the whole state array out of registers (it was
-  // promoted to LDS/scratch for every 3- and 4-state structure).
-  double v = x[0];
-#pragma unroll
-  for (int i = 1; i < N; ++i) {
-    double xi = x[i];
-    asm volatile("" : "+v"(xi));
-    v = (idx == i) ? xi : v;
   }
   return v;
 }
@@ -174,67 +140,7 @@ __device__ __forceinline__ double lane_out(const DevModel& m, const LaneModel<KI
 }
 
 
-// ------------------------------------------------------------------------------------
-// theta-dependent event rewrite on the device: lag time and bioavailability
-// (Occasion::add_lagtime / add_bioavailability, src/data/structs.rs:611-666).
-// Lagged boluses are NOT in the op stream; each lane merges them at t + lag(theta): a bolus that lands
-// inside a PROP [t0, t1) splits it exactly where the reference's re-sorted event list would
-// (solve(prev, tau), bolus, solve(tau, next)), a bolus that lands before the occasion's first remaining
-// event opens the occasion.  At equal times an observation precedes the bolus (event.rs:292-304): a
-// bolus landing exactly on an event time is applied at the START of the next PROP.
-// ------------------------------------------------------------------------------------
-struct LagState {
-  double lag[kMaxLagSlots];
-  int32_t cur[kMaxLagSlots];
-  int32_t end[kMaxLagSlots];
-};
-
-__device__ __forceinline__ double fa_of(const DevModel& m, const double* __restrict__ th, int input) {
-  double f = 1.0;
-  if (m.has_fa) {  // wave-uniform; models without bioavailability never enter
-    int fp = -1;
-#pragma unroll
-    for (int i = 0; i < PMX_MAX_INPUTS; ++i) fp = (i == input) ? m.fa_param[i] : fp;
-    if (fp >= 0) f = th[fp];
-  }
-  return f;
-}
-
-// earliest pending lagged bolus: returns its landing time (inf if none) and slot
-__device__ __forceinline__ double lag_next(const DevModel& m, const DevOps& ops, const LagState& ls, int& which) {
-  double tau = __longlong_as_double(0x7ff0000000000000LL);
-  which = -1;
-#pragma unroll
-  for (int k = 0; k < kMaxLagSlots; ++k) {
-    if (k < m.n_lag_slots && ls.cur[k] < ls.end[k]) {
-      const double tk = ops.lagb_time[ls.cur[k]] + ls.lag[k];
-      if (tk < tau) {
-        tau = tk;
-        which = k;
-      }
-    }
-  }
-  return tau;
-}
-
-template <int NS>
-__device__ __forceinline__ void lag_apply_bolus(const DevModel& m, const DevOps& ops, LagState& ls, int which,
-                                                const double* __restrict__ th, double (&x)[NS]) {
-  int32_t idx = 0;
-  int input = 0, dest = 0;
-#pragma unroll
-  for (int k = 0; k < kMaxLagSlots; ++k) {
-    if (k == which) {
-      idx = ls.cur[k];
-      input = m.lag_input[k];
-      dest = m.lag_dest[k];
-      ls.cur[k] += 1;
-    }
-  }
-  const double amt = ops.lagb_amount[idx] * fa_of(m, th, input);
-#pragma unroll
-  for (int i = 0; i < NS; ++i) x[i] += (i == dest) ? amt : 0.0;
-}
+// (lag / bioavailability helpers shared with the ODE back-end: pmx_device.hpp)
 
 // RESET of a lag model: point the cursors at this occasion's lists and run the boluses that land before the
 // occasion's first remaining event (they become the first events of the re-sorted list).
@@ -284,37 +190,6 @@ __device__ __forceinline__ void lag_prop(const DevModel& m, const DevOps& ops, L
   if (t1 > t) advance<ST>(coef, x, t1 - t, r);
 }
 
-
-// One observation in log-likelihood mode: acc += lognormpdf(obs, y, sigma) with the sigma-only parts
-// precomputed on the host (likelihood/distributions.rs:31-34; sigma from the observation,
-// error_model.rs:1045-1080).  `q` = {obs, -0.5 ln(2 pi) - ln sigma, 1/(2 sigma^2), censor scale}.
-// Censored rows (q[3] = +1/(sigma sqrt 2): BLOQ, -1/(sigma sqrt 2): ALOQ) take the log CDF / log survival
-// function of distributions.rs:52-103, with statrs' Normal::cdf = 0.5 erfc((mean - x)/(sigma sqrt 2)); a tail
-// that underflows falls back to the reference's asymptote (|z| > 37) or poisons the sum with NaN (its Err).
-__device__ __forceinline__ void ll_accumulate(const double* __restrict__ q, double y, double& acc) {
-  const double w = q[2];
-  if (w != 0.0) {  // weight 0 = missing observation: contributes 0 whatever the prediction (prediction.rs:107-111)
-    const double d = q[0] - y;
-    const double pdf = q[1] - (d * d) * w;
-    const double cs = q[3];
-    if (cs == 0.0) {  // wave-uniform
-      acc += pdf;
-    } else {
-      const double inv = fabs(cs);
-      const double cdf = 0.5 * erfc((y - q[0]) * inv);
-      const double z = d * (inv * 1.4142135623730951);  // (obs - pred) / sigma
-      const double nanv = __longlong_as_double(0x7ff8000000000000LL);
-      double ll;
-      if (cs > 0.0) {  // BLOQ: ln P(X <= obs)
-        ll = (cdf > 0.0) ? log(cdf) : ((z < -37.0) ? pdf - log(fabs(z)) : nanv);
-      } else {  // ALOQ: ln P(X > obs), computed as 1 - cdf like the reference
-        const double sf = 1.0 - cdf;
-        ll = (sf > 0.0) ? log(sf) : ((z > 37.0) ? pdf - log(z) : nanv);
-      }
-      acc += ll;
-    }
-  }
-}
 
 // ------------------------------------------------------------------------------------
 // GRID kernel (analytical)
@@ -783,21 +658,25 @@ __global__ __launch_bounds__(kBlock) void pmx_analytical_pair(DevModel m, DevOps
 }
 
 // ------------------------------------------------------------------------------------
-// ODE: built-in diffeq bodies + classic RK4 (fixed step per constant-rate piece)
+// ODE: built-in diffeq bodies (the walkers and the RK4 stepper are in pmx_ode.hpp)
 // ------------------------------------------------------------------------------------
 template <int MODEL>
 struct OdeModel;
 
 template <>
 struct OdeModel<PMX_ODE_ONE_CMT_IV> {  // examples/ode_readme.rs:17-19
+  static constexpr bool CUSTOM = false;
   static constexpr int NS = 1, NP = 1, CENTRAL = 0;
+  static constexpr int NR = 1;
   __device__ __forceinline__ static void rhs(const double* p, const double (&x)[NS], double (&dx)[NS]) {
     dx[0] = -p[0] * x[0];
   }
 };
 template <>
 struct OdeModel<PMX_ODE_ONE_CMT_ORAL> {
+  static constexpr bool CUSTOM = false;
   static constexpr int NS = 2, NP = 2, CENTRAL = 1;
+  static constexpr int NR = 2;
   __device__ __forceinline__ static void rhs(const double* p, const double (&x)[NS], double (&dx)[NS]) {
     dx[0] = -p[0] * x[0];
     dx[1] = p[0] * x[0] - p[1] * x[1];
@@ -805,7 +684,9 @@ struct OdeModel<PMX_ODE_ONE_CMT_ORAL> {
 };
 template <>
 struct OdeModel<PMX_ODE_TWO_CMT_IV> {  // two_compartment_models.rs:131-136
+  static constexpr bool CUSTOM = false;
   static constexpr int NS = 2, NP = 3, CENTRAL = 0;
+  static constexpr int NR = 2;
   __device__ __forceinline__ static void rhs(const double* p, const double (&x)[NS], double (&dx)[NS]) {
     dx[0] = -p[0] * x[0] - p[1] * x[0] + p[2] * x[1];
     dx[1] = p[1] * x[0] - p[2] * x[1];
@@ -813,7 +694,9 @@ struct OdeModel<PMX_ODE_TWO_CMT_IV> {  // two_compartment_models.rs:131-136
 };
 template <>
 struct OdeModel<PMX_ODE_TWO_CMT_ORAL> {  // two_compartment_models.rs:188-194, p=[ke,ka,kcp,kpc]
+  static constexpr bool CUSTOM = false;
   static constexpr int NS = 3, NP = 4, CENTRAL = 1;
+  static constexpr int NR = 3;
   __device__ __forceinline__ static void rhs(const double* p, const double (&x)[NS], double (&dx)[NS]) {
     dx[0] = -p[1] * x[0];
     dx[1] = -p[0] * x[1] + p[1] * x[0] - p[2] * x[1] + p[3] * x[2];
@@ -822,7 +705,9 @@ struct OdeModel<PMX_ODE_TWO_CMT_ORAL> {  // two_compartment_models.rs:188-194, p
 };
 template <>
 struct OdeModel<PMX_ODE_THREE_CMT_IV> {
+  static constexpr bool CUSTOM = false;
   static constexpr int NS = 3, NP = 5, CENTRAL = 0;
+  static constexpr int NR = 3;
   __device__ __forceinline__ static void rhs(const double* p, const double (&x)[NS], double (&dx)[NS]) {
     dx[0] = -(p[0] + p[1] + p[2]) * x[0] + p[3] * x[1] + p[4] * x[2];
     dx[1] = p[1] * x[0] - p[3] * x[1];
@@ -831,7 +716,9 @@ struct OdeModel<PMX_ODE_THREE_CMT_IV> {
 };
 template <>
 struct OdeModel<PMX_ODE_THREE_CMT_ORAL> {
+  static constexpr bool CUSTOM = false;
   static constexpr int NS = 4, NP = 6, CENTRAL = 1;
+  static constexpr int NR = 4;
   __device__ __forceinline__ static void rhs(const double* p, const double (&x)[NS], double (&dx)[NS]) {
     dx[0] = -p[0] * x[0];
     dx[1] = p[0] * x[0] - (p[1] + p[2] + p[3]) * x[1] + p[4] * x[2] + p[5] * x[3];
@@ -841,395 +728,30 @@ struct OdeModel<PMX_ODE_THREE_CMT_ORAL> {
 };
 template <>
 struct OdeModel<PMX_ODE_ONE_CMT_MM> {  // p=[vmax,km,v]
+  static constexpr bool CUSTOM = false;
   static constexpr int NS = 1, NP = 3, CENTRAL = 0;
+  static constexpr int NR = 1;
   __device__ __forceinline__ static void rhs(const double* p, const double (&x)[NS], double (&dx)[NS]) {
     const double cc = x[0] / p[2];
     dx[0] = -p[0] * cc / (p[1] + cc);
   }
 };
 
-// one classic RK4 step of dx = rhs(x) + rs   (rs = per-state infusion rates, constant over the piece)
-template <int MODEL>
-__device__ __forceinline__ void rk4_step(const double* kp, double (&x)[OdeModel<MODEL>::NS],
-                                         const double (&rs)[OdeModel<MODEL>::NS], double h) {
-  using M = OdeModel<MODEL>;
-  constexpr int NS = M::NS;
-  double k1[NS], k2[NS], k3[NS], k4[NS], xt[NS];
-  M::rhs(kp, x, k1);
-#pragma unroll
-  for (int i = 0; i < NS; ++i) {
-    k1[i] += rs[i];
-    xt[i] = x[i] + (0.5 * h) * k1[i];
-  }
-  M::rhs(kp, xt, k2);
-#pragma unroll
-  for (int i = 0; i < NS; ++i) {
-    k2[i] += rs[i];
-    xt[i] = x[i] + (0.5 * h) * k2[i];
-  }
-  M::rhs(kp, xt, k3);
-#pragma unroll
-  for (int i = 0; i < NS; ++i) {
-    k3[i] += rs[i];
-    xt[i] = x[i] + h * k3[i];
-  }
-  M::rhs(kp, xt, k4);
-#pragma unroll
-  for (int i = 0; i < NS; ++i) {
-    k4[i] += rs[i];
-    x[i] = x[i] + (h / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
-  }
-}
-
-template <int MODEL>
-struct OdeLane {
-  using M = OdeModel<MODEL>;
-  double kp[M::NP];
-  double inv_vol[PMX_MAX_OUT];
-  double xinit[M::NS];
-};
-
-template <int MODEL>
-__device__ __forceinline__ void ode_lane_setup(const DevModel& m, const double* __restrict__ th, OdeLane<MODEL>& L) {
-  using M = OdeModel<MODEL>;
-#pragma unroll
-  for (int j = 0; j < M::NP; ++j) L.kp[j] = th[j];
-#pragma unroll
-  for (int o = 0; o < PMX_MAX_OUT; ++o) {
-    double v = 1.0;
-    if (o < m.nout && m.out[o].vol_src == PMX_SRC_PRIMARY) v = th[m.out[o].vol_index];
-    L.inv_vol[o] = 1.0 / v;
-  }
-#pragma unroll
-  for (int i = 0; i < M::NS; ++i) L.xinit[i] = (m.has_init && m.init_param[i] >= 0) ? th[m.init_param[i]] : 0.0;
-}
-
-template <int MODEL>
-__device__ __forceinline__ double ode_out(const DevModel& m, const OdeLane<MODEL>& L,
-                                          const double (&x)[OdeModel<MODEL>::NS], int outeq) {
-  int state = 0;
-  double inv = 1.0;
-#pragma unroll
-  for (int o = 0; o < PMX_MAX_OUT; ++o) {
-    if (o == outeq) {
-      state = m.out[o].state;
-      inv = L.inv_vol[o];
-    }
-  }
-  return select_state<OdeModel<MODEL>::NS>(x, state) * inv;
-}
-
-// per-state rate vector of a PROP op: dx[dest(input)] += rateiv[input]  (expand/ode.rs:380-406)
-template <int MODEL>
-__device__ __forceinline__ void ode_rates(const DevModel& m, const double* __restrict__ op_rate, int64_t o, int n_rate,
-                                          double (&rs)[OdeModel<MODEL>::NS]) {
-  using M = OdeModel<MODEL>;
-#pragma unroll
-  for (int i = 0; i < M::NS; ++i) rs[i] = 0.0;
-  for (int k = 0; k < n_rate; ++k) {
-    const double r = op_rate[o * n_rate + k];
-    const int dest = (m.infusion_dest[k] >= 0) ? m.infusion_dest[k] : M::CENTRAL;
-#pragma unroll
-    for (int i = 0; i < M::NS; ++i) rs[i] += (i == dest) ? r : 0.0;
-  }
-}
-
-// One constant-rate piece [t0, t1] whose length is only known on the device (a lagged bolus split it):
-// n = ceil(dt / h_max) classic RK4 steps, the host compiler's rule (pmx_compile.cpp, ODE PROP ops).
-template <int MODEL>
-__device__ __forceinline__ void ode_piece(const DevModel& m, const double* kp, double (&x)[OdeModel<MODEL>::NS],
-                                          const double (&rs)[OdeModel<MODEL>::NS], double t0, double t1) {
-  const double dt = t1 - t0;
-  if (!(dt > 0.0)) return;
-  double nf = ceil(dt / m.rk4_h_max);
-  if (!(nf >= 1.0)) nf = 1.0;
-  if (nf > 1.0e7) nf = 1.0e7;  // a lane with an absurd lag must still terminate
-  const int32_t n = static_cast<int32_t>(nf);
-  const double h = dt / static_cast<double>(n);
-  for (int32_t k = 0; k < n; ++k) rk4_step<MODEL>(kp, x, rs, h);
-}
-
-// lag_open_occasion / lag_prop of the ODE back-end: same merge rule, RK4 pieces instead of closed forms.
-// Between an early lagged bolus and the occasion's first remaining event no infusion can be active
-// (infusions are events of the occasion), so those pieces run with zero rates.
-template <int MODEL>
-__device__ __forceinline__ void ode_lag_open_occasion(const DevModel& m, const DevOps& ops, LagState& ls, int64_t occ,
-                                                      double t_first, const double* kp, const double* __restrict__ th,
-                                                      double (&x)[OdeModel<MODEL>::NS]) {
-  constexpr int NS = OdeModel<MODEL>::NS;
-#pragma unroll
-  for (int k = 0; k < kMaxLagSlots; ++k) {
-    if (k < m.n_lag_slots) {
-      ls.cur[k] = static_cast<int32_t>(ops.lagb_off[occ * m.n_lag_slots + k]);
-      ls.end[k] = static_cast<int32_t>(ops.lagb_off[occ * m.n_lag_slots + k + 1]);
-    } else {
-      ls.cur[k] = ls.end[k] = 0;
-    }
-  }
-  double zero[NS];
-#pragma unroll
-  for (int i = 0; i < NS; ++i) zero[i] = 0.0;
-  bool started = false;
-  double t = 0.0;
-  for (;;) {
-    int which;
-    const double tau = lag_next(m, ops, ls, which);
-    if (!(tau < t_first)) break;
-    if (started) ode_piece<MODEL>(m, kp, x, zero, t, tau);
-    t = tau;
-    started = true;
-    lag_apply_bolus<NS>(m, ops, ls, which, th, x);
-  }
-  if (started && t_first < __longlong_as_double(0x7ff0000000000000LL)) ode_piece<MODEL>(m, kp, x, zero, t, t_first);
-}
-
-template <int MODEL>
-__device__ __forceinline__ void ode_lag_prop(const DevModel& m, const DevOps& ops, LagState& ls, double t0, double t1,
-                                             const double* kp, const double (&rs)[OdeModel<MODEL>::NS],
-                                             const double* __restrict__ th, double (&x)[OdeModel<MODEL>::NS]) {
-  constexpr int NS = OdeModel<MODEL>::NS;
-  double t = t0;
-  for (;;) {
-    int which;
-    const double tau = lag_next(m, ops, ls, which);
-    if (!(tau < t1)) break;
-    if (tau > t) {
-      ode_piece<MODEL>(m, kp, x, rs, t, tau);
-      t = tau;
-    }
-    lag_apply_bolus<NS>(m, ops, ls, which, th, x);
-  }
-  ode_piece<MODEL>(m, kp, x, rs, t, t1);
-}
 
 template <int MODEL, bool LAG, bool LL>
 __global__ __launch_bounds__(kBlock) void pmx_ode_rk4_grid(DevModel m, DevOps ops, const double* __restrict__ theta,
                                                            int64_t P, int64_t S, int32_t s_chunk, int32_t n_ptiles,
                                                            double* __restrict__ pred, int64_t ld,
                                                            uint8_t* __restrict__ status) {
-  using M = OdeModel<MODEL>;
-  constexpr int NS = M::NS;
-  const int64_t b = blockIdx.x;
-  const int32_t ptile = static_cast<int32_t>(b % n_ptiles);
-  const int64_t chunk = b / n_ptiles;
-  const int64_t p = static_cast<int64_t>(ptile) * kBlock + threadIdx.x;
-  const bool lane_ok = p < P;
-  const int64_t pc = lane_ok ? p : (P - 1);
-  const double* __restrict__ th = theta + pc * m.nparams;
-  OdeLane<MODEL> L;
-  ode_lane_setup<MODEL>(m, th, L);
-  uint8_t st_lane = PMX_PAIR_OK;
-  LagState ls;
-  if constexpr (LAG) {
-#pragma unroll
-    for (int k = 0; k < kMaxLagSlots; ++k) {
-      ls.lag[k] = (k < m.n_lag_slots) ? th[m.lag_param[k]] : 0.0;
-      ls.cur[k] = ls.end[k] = 0;
-      if (k < m.n_lag_slots && !(ls.lag[k] >= 0.0)) {
-        st_lane = PMX_PAIR_BAD_LAG;
-        ls.lag[k] = 0.0;  // keep the walk finite; every output of this lane is NaN anyway
-      }
-    }
-  }
-  const double nanv = __longlong_as_double(0x7ff8000000000000LL);
-  const int64_t s_begin = chunk * s_chunk;
-  const int64_t s_end = (s_begin + s_chunk < S) ? (s_begin + s_chunk) : S;
-  for (int64_t s = s_begin; s < s_end; ++s) {
-    const int64_t o0 = uniform64(ops.subj_op_off[s]);
-    const int64_t o1 = uniform64(ops.subj_op_off[s + 1]);
-    int64_t row = uniform64(ops.subj_obs_off[s]);
-    double x[NS];
-#pragma unroll
-    for (int i = 0; i < NS; ++i) x[i] = 0.0;
-    uint8_t st = st_lane;
-    double ll_acc = 0.0;
-    for (int64_t o = o0; o < o1; ++o) {
-      const uint32_t meta = uniform32(ops.op_meta[o]);
-      const uint32_t kind = meta & 0xffu;
-      const int io = static_cast<int>((meta >> 8) & 0xffffu);
-      const double a = uniformf64(ops.op_a[o]);
-      if (kind == OP_PROP) {
-        double rs[NS];
-        ode_rates<MODEL>(m, ops.op_rate, o, ops.n_rate, rs);
-        if constexpr (LAG) {
-          ode_lag_prop<MODEL>(m, ops, ls, uniformf64(ops.op_t0[o]), uniformf64(ops.op_t1[o]), L.kp, rs, th, x);
-        } else {
-          const double h = uniformf64(ops.op_b[o]);
-          const int32_t n = static_cast<int32_t>(uniform32(static_cast<uint32_t>(ops.op_n[o])));
-          for (int32_t k = 0; k < n; ++k) rk4_step<MODEL>(L.kp, x, rs, h);
-        }
-      } else if (kind == OP_OBS) {
-        double y = ode_out<MODEL>(m, L, x, io);
-        if (LAG && st == PMX_PAIR_BAD_LAG) y = nanv;
-        if constexpr (LL) {
-          ll_accumulate(ops.ll_obs + row * 4, y, ll_acc);
-        } else {
-          if (st == PMX_PAIR_OK && !isfinite(y)) st = PMX_PAIR_NONFINITE;
-          if (lane_ok) pred[row * ld + p] = y;
-        }
-        ++row;
-      } else if (kind == OP_BOLUS) {
-        const int dest = (m.bolus_dest[io] >= 0) ? m.bolus_dest[io] : io;
-        const double amt = a * fa_of(m, th, io);
-#pragma unroll
-        for (int i = 0; i < NS; ++i) x[i] += (i == dest) ? amt : 0.0;
-      } else {
-#pragma unroll
-        for (int i = 0; i < NS; ++i) x[i] = io ? L.xinit[i] : 0.0;
-        if constexpr (LAG)
-          ode_lag_open_occasion<MODEL>(m, ops, ls, static_cast<int64_t>(a), uniformf64(ops.op_t0[o]), L.kp, th, x);
-      }
-    }
-    if constexpr (LL) {
-      if (st == PMX_PAIR_OK && !isfinite(ll_acc)) st = PMX_PAIR_NONFINITE;
-      if (lane_ok) ops.ll_out[s * ops.ll_ld + p] = (st == PMX_PAIR_OK || st == PMX_PAIR_NONFINITE) ? ll_acc : nanv;
-    }
-    if (status != nullptr && lane_ok && st != PMX_PAIR_OK) status[s * P + p] = st;  // array pre-zeroed by the library
-  }
+  ode_grid_body<OdeModel<MODEL>, LAG, LL>(m, ops, theta, P, S, s_chunk, n_ptiles, pred, ld, status);
 }
 
-// PAIR: each lane is a small state machine {cursor o, remaining RK4 steps}; one trip of the
-// wave loop performs either one RK4 step or one op per lane, so lanes in different segments
-// of different subjects still step in lock-step (divergent timelines, C4).
 template <int MODEL, bool LAG, bool LL>
 __global__ __launch_bounds__(kBlock) void pmx_ode_rk4_pair(DevModel m, DevOps ops, const double* __restrict__ theta,
                                                            int64_t P, int64_t S, int32_t batch,
                                                            double* __restrict__ pred, int64_t ld,
                                                            uint8_t* __restrict__ status) {
-  using M = OdeModel<MODEL>;
-  constexpr int NS = M::NS;
-  const int64_t n_pairs = batch ? S : S * P;
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  const bool lane_ok = i < n_pairs;
-  const int64_t ic = lane_ok ? i : (n_pairs - 1);
-  const int64_t s = ops.subj_order[batch ? ic : (ic / P)];
-  const int64_t p = batch ? 0 : (ic % P);
-  const double* __restrict__ th = theta + (batch ? s : p) * m.nparams;
-  OdeLane<MODEL> L;
-  ode_lane_setup<MODEL>(m, th, L);
-  uint8_t st = PMX_PAIR_OK;
-  LagState ls;
-  if constexpr (LAG) {
-#pragma unroll
-    for (int k = 0; k < kMaxLagSlots; ++k) {
-      ls.lag[k] = (k < m.n_lag_slots) ? th[m.lag_param[k]] : 0.0;
-      ls.cur[k] = ls.end[k] = 0;
-      if (k < m.n_lag_slots && !(ls.lag[k] >= 0.0)) {
-        st = PMX_PAIR_BAD_LAG;
-        ls.lag[k] = 0.0;
-      }
-    }
-  }
-  const double nanv = __longlong_as_double(0x7ff8000000000000LL);
-  const double inf = __longlong_as_double(0x7ff0000000000000LL);
-
-  int64_t o = ops.subj_op_off[s];
-  const int64_t o1 = lane_ok ? ops.subj_op_off[s + 1] : o;
-  int64_t row = ops.subj_obs_off[s];
-  double x[NS], rs[NS];
-#pragma unroll
-  for (int k = 0; k < NS; ++k) {
-    x[k] = 0.0;
-    rs[k] = 0.0;
-  }
-  int32_t rem = 0;
-  double h = 0.0;
-  double ll_acc = 0.0;
-  // LAG: an open PROP (or occasion opening) [t_cur, t_stop) that lagged boluses may still split
-  bool in_prop = false;
-  double t_cur = 0.0, t_stop = 0.0;
-  // ONE action per lane per trip (an RK4 step, a lag sub-piece decision, or an op), written as a single if / else
-  // chain: with `continue`s the compiler rotates the stepping branch into an inner per-lane loop and lanes that
-  // need an op wait for the longest piece in the wave (measured: C4 2.4 -> 3.9 ms).
-  while (rem > 0 || o < o1) {
-    if (rem > 0) {
-      rk4_step<MODEL>(L.kp, x, rs, h);
-      --rem;
-    } else if (LAG && in_prop) {
-      int which;
-      const double tau = lag_next(m, ops, ls, which);
-      const bool bol = tau < t_stop;
-      const double stop = bol ? tau : t_stop;
-      if (stop > t_cur) {  // next sub-piece; n = ceil(dt / h_max) as ode_piece
-        const double dt = stop - t_cur;
-        double nf = ceil(dt / m.rk4_h_max);
-        if (!(nf >= 1.0)) nf = 1.0;
-        if (nf > 1.0e7) nf = 1.0e7;
-        rem = static_cast<int32_t>(nf);
-        h = dt / static_cast<double>(rem);
-        t_cur = stop;
-      } else if (bol) {
-        lag_apply_bolus<NS>(m, ops, ls, which, th, x);
-      } else {
-        in_prop = false;
-        ++o;
-      }
-    } else {
-      const uint32_t meta = ops.op_meta[o];
-      const uint32_t kind = meta & 0xffu;
-      const int io = static_cast<int>((meta >> 8) & 0xffffu);
-      const double a = ops.op_a[o];
-      bool next_op = true;  // LAG: a PROP / an occasion opening stays the current op until the branch above closes it
-      if (kind == OP_PROP) {
-        ode_rates<MODEL>(m, ops.op_rate, o, ops.n_rate, rs);
-        if constexpr (LAG) {
-          in_prop = true;
-          t_cur = ops.op_t0[o];
-          t_stop = ops.op_t1[o];
-          next_op = false;
-        } else {
-          h = ops.op_b[o];
-          rem = ops.op_n[o];
-        }
-      } else if (kind == OP_OBS) {
-        double y = ode_out<MODEL>(m, L, x, io);
-        if (LAG && st == PMX_PAIR_BAD_LAG) y = nanv;
-        if constexpr (LL) {
-          ll_accumulate(ops.ll_obs + row * 4, y, ll_acc);
-        } else {
-          if (st == PMX_PAIR_OK && !isfinite(y)) st = PMX_PAIR_NONFINITE;
-          pred[row * ld + p] = y;
-        }
-        ++row;
-      } else if (kind == OP_BOLUS) {
-        const int dest = (m.bolus_dest[io] >= 0) ? m.bolus_dest[io] : io;
-        const double amt = a * fa_of(m, th, io);
-#pragma unroll
-        for (int j = 0; j < NS; ++j) x[j] += (j == dest) ? amt : 0.0;
-      } else {
-#pragma unroll
-        for (int j = 0; j < NS; ++j) x[j] = io ? L.xinit[j] : 0.0;
-        if constexpr (LAG) {
-          const int64_t occ = static_cast<int64_t>(a);
-#pragma unroll
-          for (int k = 0; k < kMaxLagSlots; ++k) {
-            if (k < m.n_lag_slots) {
-              ls.cur[k] = static_cast<int32_t>(ops.lagb_off[occ * m.n_lag_slots + k]);
-              ls.end[k] = static_cast<int32_t>(ops.lagb_off[occ * m.n_lag_slots + k + 1]);
-            }
-          }
-          // boluses landing before the occasion's first remaining event open the occasion (zero rates there)
-          int which;
-          const double tau = lag_next(m, ops, ls, which);
-          const double t_first = ops.op_t0[o];
-          if (tau < t_first && t_first < inf) {
-#pragma unroll
-            for (int j = 0; j < NS; ++j) rs[j] = 0.0;
-            in_prop = true;
-            t_cur = tau;
-            t_stop = t_first;
-            next_op = false;
-          }
-        }
-      }
-      if (next_op) ++o;
-    }
-  }
-  if constexpr (LL) {
-    if (st == PMX_PAIR_OK && !isfinite(ll_acc)) st = PMX_PAIR_NONFINITE;
-    if (lane_ok) ops.ll_out[batch ? s : (s * ops.ll_ld + p)] = (st == PMX_PAIR_OK || st == PMX_PAIR_NONFINITE) ? ll_acc : nanv;
-  }
-  if (status != nullptr && lane_ok && st != PMX_PAIR_OK) status[batch ? s : (s * P + p)] = st;  // pre-zeroed
+  ode_pair_body<OdeModel<MODEL>, LAG, LL>(m, ops, theta, P, S, batch, pred, ld, status);
 }
 
 // ------------------------------------------------------------------------------------

@@ -1,0 +1,431 @@
+// pmx_ode.hpp — the ODE back-end's device code, generic over a model policy: fixed-step classic RK4 per constant-
+// rate piece, the GRID and PAIR walkers (ode/mod.rs:609-823 semantics).  Included by
+// pmx_kernels.hip with the built-in diffeq bodies and by the source hiprtc compiles for a user model (pmx_jit.cpp).
+#pragma once
+
+#include "pmx_device.hpp"
+
+namespace pmx {
+namespace {
+
+// ------------------------------------------------------------------------------------
+// ODE: built-in diffeq bodies + classic RK4 (fixed step per constant-rate piece)
+// ------------------------------------------------------------------------------------
+// Model policy M (a built-in diffeq body below, or the wrapper pmx_jit.cpp generates around a user's source):
+//   NS, NP, CENTRAL, CUSTOM, NR (length of the rate vector: NS per-state rates for built-ins, the model's inputs
+//   for custom bodies, which add rateiv themselves like a hand-written ODE::new closure)
+//   built-in:  rhs(p, x, dx)                       autonomous; the walker adds the per-state rates
+//   custom:    rhs(t, p, x, rateiv, dx), out(t, p, x, y), init(p, x); NOUT, HAS_INIT
+template <class M>
+__device__ __forceinline__ void ode_eval(double t, const double* kp, const double (&x)[M::NS], const double (&rs)[M::NR],
+                                         double (&dx)[M::NS]) {
+  if constexpr (M::CUSTOM) {
+    M::rhs(t, kp, x, rs, dx);
+  } else {
+    M::rhs(kp, x, dx);
+#pragma unroll
+    for (int i = 0; i < M::NS; ++i) dx[i] += rs[i];
+  }
+}
+
+// one classic RK4 step from t to t + h (rs constant over the piece)
+template <class M>
+__device__ __forceinline__ void rk4_step(const double* kp, double (&x)[M::NS], const double (&rs)[M::NR], double t,
+                                         double h) {
+  constexpr int NS = M::NS;
+  double k1[NS], k2[NS], k3[NS], k4[NS], xt[NS];
+  ode_eval<M>(t, kp, x, rs, k1);
+#pragma unroll
+  for (int i = 0; i < NS; ++i) xt[i] = x[i] + (0.5 * h) * k1[i];
+  ode_eval<M>(t + 0.5 * h, kp, xt, rs, k2);
+#pragma unroll
+  for (int i = 0; i < NS; ++i) xt[i] = x[i] + (0.5 * h) * k2[i];
+  ode_eval<M>(t + 0.5 * h, kp, xt, rs, k3);
+#pragma unroll
+  for (int i = 0; i < NS; ++i) xt[i] = x[i] + h * k3[i];
+  ode_eval<M>(t + h, kp, xt, rs, k4);
+#pragma unroll
+  for (int i = 0; i < NS; ++i) x[i] = x[i] + (h / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+}
+
+template <class M>
+struct OdeLane {
+  double kp[M::NP];
+  double inv_vol[PMX_MAX_OUT];
+  double xinit[M::NS];
+};
+
+template <class M>
+__device__ __forceinline__ void ode_lane_setup(const DevModel& m, const double* __restrict__ th, OdeLane<M>& L) {
+#pragma unroll
+  for (int j = 0; j < M::NP; ++j) L.kp[j] = th[j];
+  if constexpr (M::CUSTOM) {
+#pragma unroll
+    for (int o = 0; o < PMX_MAX_OUT; ++o) L.inv_vol[o] = 1.0;
+#pragma unroll
+    for (int i = 0; i < M::NS; ++i) L.xinit[i] = 0.0;
+    if constexpr (M::HAS_INIT) M::init(L.kp, L.xinit);
+    return;
+  }
+#pragma unroll
+  for (int o = 0; o < PMX_MAX_OUT; ++o) {
+    double v = 1.0;
+    if (o < m.nout && m.out[o].vol_src == PMX_SRC_PRIMARY) v = th[m.out[o].vol_index];
+    L.inv_vol[o] = 1.0 / v;
+  }
+#pragma unroll
+  for (int i = 0; i < M::NS; ++i) L.xinit[i] = (m.has_init && m.init_param[i] >= 0) ? th[m.init_param[i]] : 0.0;
+}
+
+template <class M>
+__device__ __forceinline__ double ode_out(const DevModel& m, const OdeLane<M>& L,
+                                          const double (&x)[M::NS], int outeq, double t) {
+  if constexpr (M::CUSTOM) {
+    double y[M::NOUT];
+#pragma unroll
+    for (int o = 0; o < M::NOUT; ++o) y[o] = 0.0;
+    M::out(t, L.kp, x, y);
+    double v = y[0];
+#pragma unroll
+    for (int o = 1; o < M::NOUT; ++o) v = (o == outeq) ? y[o] : v;
+    return v;
+  }
+  int state = 0;
+  double inv = 1.0;
+#pragma unroll
+  for (int o = 0; o < PMX_MAX_OUT; ++o) {
+    if (o == outeq) {
+      state = m.out[o].state;
+      inv = L.inv_vol[o];
+    }
+  }
+  return select_state<M::NS>(x, state) * inv;
+}
+
+// per-state rate vector of a PROP op: dx[dest(input)] += rateiv[input]  (expand/ode.rs:380-406)
+template <class M>
+__device__ __forceinline__ void ode_rates(const DevModel& m, const double* __restrict__ op_rate, int64_t o, int n_rate,
+                                          double (&rs)[M::NR]) {
+  if constexpr (M::CUSTOM) {  // rateiv[input], handed to the user's body as it is
+#pragma unroll
+    for (int k = 0; k < M::NR; ++k) rs[k] = (k < n_rate) ? op_rate[o * n_rate + k] : 0.0;
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < M::NS; ++i) rs[i] = 0.0;
+  for (int k = 0; k < n_rate; ++k) {
+    const double r = op_rate[o * n_rate + k];
+    const int dest = (m.infusion_dest[k] >= 0) ? m.infusion_dest[k] : M::CENTRAL;
+#pragma unroll
+    for (int i = 0; i < M::NS; ++i) rs[i] += (i == dest) ? r : 0.0;
+  }
+}
+
+// One constant-rate piece [t0, t1] whose length is only known on the device (a lagged bolus split it):
+// n = ceil(dt / h_max) classic RK4 steps, the host compiler's rule (pmx_compile.cpp, ODE PROP ops).
+template <class M>
+__device__ __forceinline__ void ode_piece(const DevModel& m, const double* kp, double (&x)[M::NS],
+                                          const double (&rs)[M::NR], double t0, double t1) {
+  const double dt = t1 - t0;
+  if (!(dt > 0.0)) return;
+  double nf = ceil(dt / m.rk4_h_max);
+  if (!(nf >= 1.0)) nf = 1.0;
+  if (nf > 1.0e7) nf = 1.0e7;  // a lane with an absurd lag must still terminate
+  const int32_t n = static_cast<int32_t>(nf);
+  const double h = dt / static_cast<double>(n);
+  for (int32_t k = 0; k < n; ++k) rk4_step<M>(kp, x, rs, t0 + static_cast<double>(k) * h, h);
+}
+
+// lag_open_occasion / lag_prop of the ODE back-end: same merge rule, RK4 pieces instead of closed forms.
+// Between an early lagged bolus and the occasion's first remaining event no infusion can be active
+// (infusions are events of the occasion), so those pieces run with zero rates.
+template <class M>
+__device__ __forceinline__ void ode_lag_open_occasion(const DevModel& m, const DevOps& ops, LagState& ls, int64_t occ,
+                                                      double t_first, const double* kp, const double* __restrict__ th,
+                                                      double (&x)[M::NS]) {
+  constexpr int NS = M::NS;
+#pragma unroll
+  for (int k = 0; k < kMaxLagSlots; ++k) {
+    if (k < m.n_lag_slots) {
+      ls.cur[k] = static_cast<int32_t>(ops.lagb_off[occ * m.n_lag_slots + k]);
+      ls.end[k] = static_cast<int32_t>(ops.lagb_off[occ * m.n_lag_slots + k + 1]);
+    } else {
+      ls.cur[k] = ls.end[k] = 0;
+    }
+  }
+  double zero[M::NR];
+#pragma unroll
+  for (int i = 0; i < M::NR; ++i) zero[i] = 0.0;
+  bool started = false;
+  double t = 0.0;
+  for (;;) {
+    int which;
+    const double tau = lag_next(m, ops, ls, which);
+    if (!(tau < t_first)) break;
+    if (started) ode_piece<M>(m, kp, x, zero, t, tau);
+    t = tau;
+    started = true;
+    lag_apply_bolus<NS>(m, ops, ls, which, th, x);
+  }
+  if (started && t_first < __longlong_as_double(0x7ff0000000000000LL)) ode_piece<M>(m, kp, x, zero, t, t_first);
+}
+
+template <class M>
+__device__ __forceinline__ void ode_lag_prop(const DevModel& m, const DevOps& ops, LagState& ls, double t0, double t1,
+                                             const double* kp, const double (&rs)[M::NR],
+                                             const double* __restrict__ th, double (&x)[M::NS]) {
+  constexpr int NS = M::NS;
+  double t = t0;
+  for (;;) {
+    int which;
+    const double tau = lag_next(m, ops, ls, which);
+    if (!(tau < t1)) break;
+    if (tau > t) {
+      ode_piece<M>(m, kp, x, rs, t, tau);
+      t = tau;
+    }
+    lag_apply_bolus<NS>(m, ops, ls, which, th, x);
+  }
+  ode_piece<M>(m, kp, x, rs, t, t1);
+}
+
+template <class M, bool LAG, bool LL>
+__device__ __forceinline__ void ode_grid_body(const DevModel& m, const DevOps& ops, const double* __restrict__ theta,
+                                              int64_t P, int64_t S, int32_t s_chunk, int32_t n_ptiles,
+                                              double* __restrict__ pred, int64_t ld, uint8_t* __restrict__ status) {
+  constexpr int NS = M::NS;
+  const int64_t b = blockIdx.x;
+  const int32_t ptile = static_cast<int32_t>(b % n_ptiles);
+  const int64_t chunk = b / n_ptiles;
+  const int64_t p = static_cast<int64_t>(ptile) * kBlock + threadIdx.x;
+  const bool lane_ok = p < P;
+  const int64_t pc = lane_ok ? p : (P - 1);
+  const double* __restrict__ th = theta + pc * m.nparams;
+  OdeLane<M> L;
+  ode_lane_setup<M>(m, th, L);
+  uint8_t st_lane = PMX_PAIR_OK;
+  LagState ls;
+  if constexpr (LAG) {
+#pragma unroll
+    for (int k = 0; k < kMaxLagSlots; ++k) {
+      ls.lag[k] = (k < m.n_lag_slots) ? th[m.lag_param[k]] : 0.0;
+      ls.cur[k] = ls.end[k] = 0;
+      if (k < m.n_lag_slots && !(ls.lag[k] >= 0.0)) {
+        st_lane = PMX_PAIR_BAD_LAG;
+        ls.lag[k] = 0.0;  // keep the walk finite; every output of this lane is NaN anyway
+      }
+    }
+  }
+  const double nanv = __longlong_as_double(0x7ff8000000000000LL);
+  const int64_t s_begin = chunk * s_chunk;
+  const int64_t s_end = (s_begin + s_chunk < S) ? (s_begin + s_chunk) : S;
+  for (int64_t s = s_begin; s < s_end; ++s) {
+    const int64_t o0 = uniform64(ops.subj_op_off[s]);
+    const int64_t o1 = uniform64(ops.subj_op_off[s + 1]);
+    int64_t row = uniform64(ops.subj_obs_off[s]);
+    double x[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) x[i] = 0.0;
+    uint8_t st = st_lane;
+    double ll_acc = 0.0;
+    for (int64_t o = o0; o < o1; ++o) {
+      const uint32_t meta = uniform32(ops.op_meta[o]);
+      const uint32_t kind = meta & 0xffu;
+      const int io = static_cast<int>((meta >> 8) & 0xffffu);
+      const double a = uniformf64(ops.op_a[o]);
+      if (kind == OP_PROP) {
+        double rs[M::NR];
+        ode_rates<M>(m, ops.op_rate, o, ops.n_rate, rs);
+        if constexpr (LAG) {
+          ode_lag_prop<M>(m, ops, ls, uniformf64(ops.op_t0[o]), uniformf64(ops.op_t1[o]), L.kp, rs, th, x);
+        } else {
+          const double h = uniformf64(ops.op_b[o]);
+          const int32_t n = static_cast<int32_t>(uniform32(static_cast<uint32_t>(ops.op_n[o])));
+          double t0 = 0.0;  // only a custom (possibly non-autonomous) body reads the time
+          if constexpr (M::CUSTOM) t0 = uniformf64(ops.op_t0[o]);
+          for (int32_t k = 0; k < n; ++k) rk4_step<M>(L.kp, x, rs, t0 + static_cast<double>(k) * h, h);
+        }
+      } else if (kind == OP_OBS) {
+        double y = ode_out<M>(m, L, x, io, a);
+        if (LAG && st == PMX_PAIR_BAD_LAG) y = nanv;
+        if constexpr (LL) {
+          ll_accumulate(ops.ll_obs + row * 4, y, ll_acc);
+        } else {
+          if (st == PMX_PAIR_OK && !isfinite(y)) st = PMX_PAIR_NONFINITE;
+          if (lane_ok) pred[row * ld + p] = y;
+        }
+        ++row;
+      } else if (kind == OP_BOLUS) {
+        const int dest = (m.bolus_dest[io] >= 0) ? m.bolus_dest[io] : io;
+        const double amt = a * fa_of(m, th, io);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) x[i] += (i == dest) ? amt : 0.0;
+      } else {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) x[i] = io ? L.xinit[i] : 0.0;
+        if constexpr (LAG)
+          ode_lag_open_occasion<M>(m, ops, ls, static_cast<int64_t>(a), uniformf64(ops.op_t0[o]), L.kp, th, x);
+      }
+    }
+    if constexpr (LL) {
+      if (st == PMX_PAIR_OK && !isfinite(ll_acc)) st = PMX_PAIR_NONFINITE;
+      if (lane_ok) ops.ll_out[s * ops.ll_ld + p] = (st == PMX_PAIR_OK || st == PMX_PAIR_NONFINITE) ? ll_acc : nanv;
+    }
+    if (status != nullptr && lane_ok && st != PMX_PAIR_OK) status[s * P + p] = st;  // array pre-zeroed by the library
+  }
+}
+
+// PAIR: each lane is a small state machine {cursor o, remaining RK4 steps}; one trip of the
+// wave loop performs either one RK4 step or one op per lane, so lanes in different segments
+// of different subjects still step in lock-step (divergent timelines, C4).
+template <class M, bool LAG, bool LL>
+__device__ __forceinline__ void ode_pair_body(const DevModel& m, const DevOps& ops, const double* __restrict__ theta,
+                                              int64_t P, int64_t S, int32_t batch, double* __restrict__ pred,
+                                              int64_t ld, uint8_t* __restrict__ status) {
+  constexpr int NS = M::NS;
+  const int64_t n_pairs = batch ? S : S * P;
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const bool lane_ok = i < n_pairs;
+  const int64_t ic = lane_ok ? i : (n_pairs - 1);
+  const int64_t s = ops.subj_order[batch ? ic : (ic / P)];
+  const int64_t p = batch ? 0 : (ic % P);
+  const double* __restrict__ th = theta + (batch ? s : p) * m.nparams;
+  OdeLane<M> L;
+  ode_lane_setup<M>(m, th, L);
+  uint8_t st = PMX_PAIR_OK;
+  LagState ls;
+  if constexpr (LAG) {
+#pragma unroll
+    for (int k = 0; k < kMaxLagSlots; ++k) {
+      ls.lag[k] = (k < m.n_lag_slots) ? th[m.lag_param[k]] : 0.0;
+      ls.cur[k] = ls.end[k] = 0;
+      if (k < m.n_lag_slots && !(ls.lag[k] >= 0.0)) {
+        st = PMX_PAIR_BAD_LAG;
+        ls.lag[k] = 0.0;
+      }
+    }
+  }
+  const double nanv = __longlong_as_double(0x7ff8000000000000LL);
+  const double inf = __longlong_as_double(0x7ff0000000000000LL);
+
+  int64_t o = ops.subj_op_off[s];
+  const int64_t o1 = lane_ok ? ops.subj_op_off[s + 1] : o;
+  int64_t row = ops.subj_obs_off[s];
+  double x[NS], rs[M::NR];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) x[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < M::NR; ++k) rs[k] = 0.0;
+  int32_t rem = 0;
+  double h = 0.0;
+  // custom bodies may read the time: the open piece's start and step count (stage time = t_piece + k h)
+  double t_piece = 0.0;
+  int32_t n_piece = 0;
+  double ll_acc = 0.0;
+  // LAG: an open PROP (or occasion opening) [t_cur, t_stop) that lagged boluses may still split
+  bool in_prop = false;
+  double t_cur = 0.0, t_stop = 0.0;
+  // ONE action per lane per trip (an RK4 step, a lag sub-piece decision, or an op), written as a single if / else
+  // chain: with `continue`s the compiler rotates the stepping branch into an inner per-lane loop and lanes that
+  // need an op wait for the longest piece in the wave (measured: C4 2.4 -> 3.9 ms).
+  while (rem > 0 || o < o1) {
+    if (rem > 0) {
+      double t = 0.0;
+      if constexpr (M::CUSTOM) t = t_piece + static_cast<double>(n_piece - rem) * h;
+      rk4_step<M>(L.kp, x, rs, t, h);
+      --rem;
+    } else if (LAG && in_prop) {
+      int which;
+      const double tau = lag_next(m, ops, ls, which);
+      const bool bol = tau < t_stop;
+      const double stop = bol ? tau : t_stop;
+      if (stop > t_cur) {  // next sub-piece; n = ceil(dt / h_max) as ode_piece
+        const double dt = stop - t_cur;
+        double nf = ceil(dt / m.rk4_h_max);
+        if (!(nf >= 1.0)) nf = 1.0;
+        if (nf > 1.0e7) nf = 1.0e7;
+        rem = static_cast<int32_t>(nf);
+        h = dt / static_cast<double>(rem);
+        t_piece = t_cur;
+        n_piece = rem;
+        t_cur = stop;
+      } else if (bol) {
+        lag_apply_bolus<NS>(m, ops, ls, which, th, x);
+      } else {
+        in_prop = false;
+        ++o;
+      }
+    } else {
+      const uint32_t meta = ops.op_meta[o];
+      const uint32_t kind = meta & 0xffu;
+      const int io = static_cast<int>((meta >> 8) & 0xffffu);
+      const double a = ops.op_a[o];
+      bool next_op = true;  // LAG: a PROP / an occasion opening stays the current op until the branch above closes it
+      if (kind == OP_PROP) {
+        ode_rates<M>(m, ops.op_rate, o, ops.n_rate, rs);
+        if constexpr (LAG) {
+          in_prop = true;
+          t_cur = ops.op_t0[o];
+          t_stop = ops.op_t1[o];
+          next_op = false;
+        } else {
+          h = ops.op_b[o];
+          rem = ops.op_n[o];
+          if constexpr (M::CUSTOM) {
+            t_piece = ops.op_t0[o];
+            n_piece = rem;
+          }
+        }
+      } else if (kind == OP_OBS) {
+        double y = ode_out<M>(m, L, x, io, a);
+        if (LAG && st == PMX_PAIR_BAD_LAG) y = nanv;
+        if constexpr (LL) {
+          ll_accumulate(ops.ll_obs + row * 4, y, ll_acc);
+        } else {
+          if (st == PMX_PAIR_OK && !isfinite(y)) st = PMX_PAIR_NONFINITE;
+          pred[row * ld + p] = y;
+        }
+        ++row;
+      } else if (kind == OP_BOLUS) {
+        const int dest = (m.bolus_dest[io] >= 0) ? m.bolus_dest[io] : io;
+        const double amt = a * fa_of(m, th, io);
+#pragma unroll
+        for (int j = 0; j < NS; ++j) x[j] += (j == dest) ? amt : 0.0;
+      } else {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) x[j] = io ? L.xinit[j] : 0.0;
+        if constexpr (LAG) {
+          const int64_t occ = static_cast<int64_t>(a);
+#pragma unroll
+          for (int k = 0; k < kMaxLagSlots; ++k) {
+            if (k < m.n_lag_slots) {
+              ls.cur[k] = static_cast<int32_t>(ops.lagb_off[occ * m.n_lag_slots + k]);
+              ls.end[k] = static_cast<int32_t>(ops.lagb_off[occ * m.n_lag_slots + k + 1]);
+            }
+          }
+          // boluses landing before the occasion's first remaining event open the occasion (zero rates there)
+          int which;
+          const double tau = lag_next(m, ops, ls, which);
+          const double t_first = ops.op_t0[o];
+          if (tau < t_first && t_first < inf) {
+#pragma unroll
+            for (int j = 0; j < M::NR; ++j) rs[j] = 0.0;
+            in_prop = true;
+            t_cur = tau;
+            t_stop = t_first;
+            next_op = false;
+          }
+        }
+      }
+      if (next_op) ++o;
+    }
+  }
+  if constexpr (LL) {
+    if (st == PMX_PAIR_OK && !isfinite(ll_acc)) st = PMX_PAIR_NONFINITE;
+    if (lane_ok) ops.ll_out[batch ? s : (s * ops.ll_ld + p)] = (st == PMX_PAIR_OK || st == PMX_PAIR_NONFINITE) ? ll_acc : nanv;
+  }
+  if (status != nullptr && lane_ok && st != PMX_PAIR_OK) status[batch ? s : (s * P + p)] = st;  // pre-zeroed
+}
+
+}  // namespace
+}  // namespace pmx

@@ -363,13 +363,35 @@ class ODE(Equation):
         m.rk4_h_max = float(h_max)
         return m
 
+    @staticmethod
+    def custom(source: str, *, nstates: int, nparams: int, ndrugs: int = 1, nout: int = 1, has_init: bool = False,
+               lag: Optional[Dict[int, int]] = None, fa: Optional[Dict[int, int]] = None, h_max: float = 0.02) -> "ODE":
+        """``ODE::new(diffeq, lag, fa, init, out)`` with USER bodies (ode/mod.rs:115-132): ``source`` is C/HIP text
+        defining ``pmx_dynamics`` / ``pmx_outputs`` (/ ``pmx_init``) as described in include/pmx.h; the library
+        compiles it for gfx950 with hiprtc.  Index-based like ``ODE::new``: data labels are dense numeric indices,
+        a bolus on input i goes to state i."""
+        m = ODE()
+        m.kernel_name = "custom"
+        m.source = str(source)
+        m.has_init = bool(has_init)
+        m.out = {}
+        m.nparams = int(nparams)
+        m.init = {}
+        m.lag = {str(k): v for k, v in (lag or {}).items()}
+        m.fa = {str(k): v for k, v in (fa or {}).items()}
+        m.rk4_h_max = float(h_max)
+        return m.with_nstates(nstates).with_ndrugs(ndrugs).with_nout(nout)
+
     def with_step(self, h_max: float) -> "ODE":
         self.rk4_h_max = float(h_max)
         self._handle = None
         return self
 
+    source: Optional[str] = None  # custom bodies (ODE.custom)
+    has_init = False
+
     def _kernel_id(self) -> int:
-        return _abi.ODE_MODELS[self.kernel_name]
+        return _abi.PMX_ODE_CUSTOM if self.source is not None else _abi.ODE_MODELS[self.kernel_name]
 
     def _required_names(self) -> List[str]:
         return []

@@ -25,7 +25,12 @@ class DeviceModel:
         self.model = model
         self.desc = model.desc() if not isinstance(model, _abi.pmx_model_desc) else model
         h = C.c_void_p()
-        _ffi.check(_ffi.lib().pmx_model_create(C.byref(self.desc), C.byref(h)))
+        src = getattr(model, "source", None)
+        if src is not None:  # user ODE body: compiled for gfx950 with hiprtc inside the library
+            _ffi.check(_ffi.lib().pmx_model_create_custom(C.byref(self.desc), src.encode(), 1 if model.has_init else 0,
+                                                          C.byref(h)))
+        else:
+            _ffi.check(_ffi.lib().pmx_model_create(C.byref(self.desc), C.byref(h)))
         self.handle = h
 
     def __del__(self):
@@ -65,6 +70,18 @@ class DevicePopulation:
         if h and _ffi is not None and _ffi._lib is not None:
             _ffi._lib.pmx_population_destroy(h)
             self.handle = None
+
+
+def jit_translation_unit(model) -> str:
+    """The source text the library hands to hiprtc for a custom ODE model (``pmx_debug_jit_source``)."""
+    L = _ffi.lib()
+    d = model.desc()
+    out = C.c_void_p()
+    _ffi.check(L.pmx_debug_jit_source(C.byref(d), model.source.encode(), 1 if model.has_init else 0, C.byref(out)))
+    try:
+        return C.cast(out, C.c_char_p).value.decode()
+    finally:
+        L.pmx_free_text(out)
 
 
 def _as_model(model) -> DeviceModel:

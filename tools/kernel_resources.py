@@ -4,7 +4,7 @@ usage: tools/kernel_resources.py [substring-filter]"""
 import re, subprocess, sys
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
 src = "pharmsol_amd/csrc/pmx_kernels.hip"
-out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-parameter",
+out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-parameter", "-Iinclude",
                       "-c", src, "-o", "/tmp/_kr.o", "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True).stderr
 rows, cur = [], None
 pats = (("vgpr", r" VGPRs: (\d+)"), ("sgpr", r"TotalSGPRs: (\d+)"), ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"),
