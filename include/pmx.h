@@ -63,7 +63,8 @@ enum {
   PMX_PAIR_OK = 0,
   PMX_PAIR_COMPLEX_ROOTS = 1, /* reference panics: two_compartment_models.rs:20-22, three_compartment_models.rs:32-34 */
   PMX_PAIR_NONFINITE = 2,     /* a prediction is NaN/inf (PharmsolError::NonFiniteLikelihood-style guard) */
-  PMX_PAIR_BAD_LAG = 3        /* the support point gives a negative or NaN lag time: its predictions are NaN */
+  PMX_PAIR_BAD_LAG = 3,       /* the support point gives a negative or NaN lag time: its predictions are NaN */
+  PMX_PAIR_SOLVER_FAIL = 4    /* adaptive ODE solver: step size underflow (PharmsolError::DiffsolError, error/mod.rs:25) */
 };
 
 /* ---- events ---------------------------------------------------------------- */
@@ -213,8 +214,16 @@ typedef struct pmx_model_desc {
    * only (equation/mod.rs:328; one_compartment_models.rs:16). */
   int32_t bolus_dest[PMX_MAX_INPUTS];
   int32_t infusion_dest[PMX_MAX_INPUTS];
-  double rk4_h_max;     /* ODE: fixed-step RK4, h = dt/ceil(dt/h_max) per constant-rate piece */
+  double rk4_h_max;     /* ODE: fixed-step RK4, h = dt/ceil(dt/h_max) per constant-rate piece; adaptive: largest step */
+  /* ODE solver (`ODE::with_solver` / `with_tolerances`, ode/mod.rs:134-166; the reference's diffsol solvers are
+   * replaced: SURVEY.md §8 a23).  PMX_SOLVER_RK4 = the fixed-step default.  PMX_SOLVER_DOPRI5 = embedded
+   * Dormand-Prince 5(4) with step-size control per lane: err = rms(e_i / (atol + rtol max(|x_i|, |x'_i|))) <= 1. */
+  int32_t ode_solver;
+  int32_t reserved_;
+  double ode_rtol, ode_atol;
 } pmx_model_desc;
+
+enum { PMX_SOLVER_RK4 = 0, PMX_SOLVER_DOPRI5 = 1 };
 
 typedef struct pmx_population pmx_population; /* opaque */
 typedef struct pmx_model pmx_model;           /* opaque */

@@ -733,6 +733,80 @@ static void rk4_piece(const pmx_model_desc* m, double* x, const double* p, const
   }
 }
 
+/* ---- PMX_SOLVER_DOPRI5: Dormand-Prince 5(4) with step-size control (the build's stand-in for the reference's
+ * adaptive diffsol solvers; same rule set as pmx_ode.hpp dopri5_try / dopri5_advance). ---------------------- */
+static double dopri5_try(const pmx_model_desc* m, const double* x, const double* p, const double* rate, double t, double h,
+                         double* xn) {
+  int ns = m->nstates;
+  double k1[PMX_MAX_STATES], k2[PMX_MAX_STATES], k3[PMX_MAX_STATES], k4[PMX_MAX_STATES], k5[PMX_MAX_STATES],
+      k6[PMX_MAX_STATES], k7[PMX_MAX_STATES], xt[PMX_MAX_STATES];
+  ode_f(m, t, x, p, rate, k1);
+  for (int i = 0; i < ns; i++) xt[i] = x[i] + h * (0.2 * k1[i]);
+  ode_f(m, t + 0.2 * h, xt, p, rate, k2);
+  for (int i = 0; i < ns; i++) xt[i] = x[i] + h * ((3.0 / 40.0) * k1[i] + (9.0 / 40.0) * k2[i]);
+  ode_f(m, t + 0.3 * h, xt, p, rate, k3);
+  for (int i = 0; i < ns; i++) xt[i] = x[i] + h * ((44.0 / 45.0) * k1[i] - (56.0 / 15.0) * k2[i] + (32.0 / 9.0) * k3[i]);
+  ode_f(m, t + 0.8 * h, xt, p, rate, k4);
+  for (int i = 0; i < ns; i++)
+    xt[i] = x[i] + h * ((19372.0 / 6561.0) * k1[i] - (25360.0 / 2187.0) * k2[i] + (64448.0 / 6561.0) * k3[i] -
+                        (212.0 / 729.0) * k4[i]);
+  ode_f(m, t + (8.0 / 9.0) * h, xt, p, rate, k5);
+  for (int i = 0; i < ns; i++)
+    xt[i] = x[i] + h * ((9017.0 / 3168.0) * k1[i] - (355.0 / 33.0) * k2[i] + (46732.0 / 5247.0) * k3[i] +
+                        (49.0 / 176.0) * k4[i] - (5103.0 / 18656.0) * k5[i]);
+  ode_f(m, t + h, xt, p, rate, k6);
+  for (int i = 0; i < ns; i++)
+    xn[i] = x[i] + h * ((35.0 / 384.0) * k1[i] + (500.0 / 1113.0) * k3[i] + (125.0 / 192.0) * k4[i] -
+                        (2187.0 / 6784.0) * k5[i] + (11.0 / 84.0) * k6[i]);
+  ode_f(m, t + h, xn, p, rate, k7);
+  double acc = 0.0;
+  for (int i = 0; i < ns; i++) {
+    double e = h * ((71.0 / 57600.0) * k1[i] - (71.0 / 16695.0) * k3[i] + (71.0 / 1920.0) * k4[i] -
+                    (17253.0 / 339200.0) * k5[i] + (22.0 / 525.0) * k6[i] - (1.0 / 40.0) * k7[i]);
+    double sc = m->ode_atol + m->ode_rtol * fmax(fabs(x[i]), fabs(xn[i]));
+    double q = e / sc;
+    acc += q * q;
+  }
+  return sqrt(acc / (double)ns);
+}
+
+typedef struct {
+  double h;
+  int failed;
+} adapt_t;
+
+static void dopri5_piece(const pmx_model_desc* m, double* x, const double* p, const double* rate, double t0, double t1,
+                         adapt_t* as) {
+  double t = t0;
+  for (int64_t guard = 0; guard < 10000000; guard++) {
+    double left = t1 - t;
+    if (!(left > 0.0)) return;
+    double h = fmin(as->h, m->rk4_h_max);
+    int clipped = h >= left;
+    if (clipped) h = left;
+    double xn[PMX_MAX_STATES];
+    double err = dopri5_try(m, x, p, rate, t, h, xn);
+    int ok = err <= 1.0;
+    double fac = (err > 0.0) ? 0.9 * pow(err, -0.2) : 5.0;
+    if (!(fac >= 0.2)) fac = 0.2;
+    if (fac > 5.0) fac = 5.0;
+    if (!ok && fac > 1.0) fac = 1.0;
+    double h_next = h * fac;
+    if (ok) {
+      for (int i = 0; i < m->nstates; i++) x[i] = xn[i];
+      t = clipped ? t1 : (t + h);
+      as->h = clipped ? fmax(as->h, h_next) : h_next;
+      if (clipped) return;
+      continue;
+    }
+    as->h = h_next;
+    if (!(h_next > 1.0e-13 * fmax(1.0, fabs(t)))) {
+      as->failed = 1;
+      return;
+    }
+  }
+}
+
 /* ------------------------------------------------------------------------- */
 /* One (subject, support point): Equation::simulate_subject_dense             */
 /* equation/mod.rs:480-516 (analytical) / ode/mod.rs:306-461 (ODE)            */
@@ -752,6 +826,7 @@ static int simulate_pair(const pmx_model_desc* m, const pmx_population_desc* pop
   int ncov = pop->n_covariates;
   int64_t row = 0; /* prediction row within the subject */
   uint8_t st = PMX_PAIR_OK;
+  adapt_t adapt = {m->rk4_h_max, 0}; /* adaptive solver: the proposal restarts with every subject */
   ctx_t ctx;
   ctx.m = m;
   for (int64_t oc = occ0; oc < occ1; oc++) { /* for occasion in subject.occasions() :494 */
@@ -876,6 +951,10 @@ static int simulate_pair(const pmx_model_desc* m, const pmx_population_desc* pop
           if ((int)e->io >= m->nout) return PMX_ERR_OUTEQ_OUT_OF_RANGE;
           if (model_out(&ctx, x, theta, e->time, y)) return PMX_ERR_INVALID_ARGUMENT;
           double pr = y[e->io];
+          if (adapt.failed) { /* step-size underflow before this row */
+            if (st == PMX_PAIR_OK) st = PMX_PAIR_SOLVER_FAIL;
+            pr = NAN;
+          }
           if (st == PMX_PAIR_OK && !isfinite(pr)) st = PMX_PAIR_NONFINITE;
           pred[row * pred_stride] = pr;
           row++;
@@ -894,7 +973,10 @@ static int simulate_pair(const pmx_model_desc* m, const pmx_population_desc* pop
               double s = sc->inf[k].time, en = s + sc->inf[k].duration;
               if (s <= t && t < en) rate[sc->inf[k].input] += sc->inf[k].amount / sc->inf[k].duration;
             }
-            rk4_piece(m, x, theta, rate, t, stop);
+            if (m->ode_solver == PMX_SOLVER_DOPRI5)
+              dopri5_piece(m, x, theta, rate, t, stop, &adapt);
+            else
+              rk4_piece(m, x, theta, rate, t, stop);
             t = stop;
           }
         }

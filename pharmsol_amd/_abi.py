@@ -102,6 +102,8 @@ ODE_MODELS = {
     "one_cmt_mm": 6,
 }
 PMX_ODE_CUSTOM = 100
+PMX_SOLVER_RK4, PMX_SOLVER_DOPRI5 = 0, 1
+PMX_PAIR_SOLVER_FAIL = 4
 ODE_STATE_COUNT = {"one_cmt_iv": 1, "one_cmt_oral": 2, "two_cmt_iv": 2, "two_cmt_oral": 3, "three_cmt_iv": 3,
                    "three_cmt_oral": 4, "one_cmt_mm": 1}
 ODE_PARAM_COUNT = {"one_cmt_iv": 1, "one_cmt_oral": 2, "two_cmt_iv": 3, "two_cmt_oral": 4, "three_cmt_iv": 5,
@@ -194,6 +196,10 @@ class pmx_model_desc(C.Structure):
         ("bolus_dest", C.c_int32 * PMX_MAX_INPUTS),
         ("infusion_dest", C.c_int32 * PMX_MAX_INPUTS),
         ("rk4_h_max", C.c_double),
+        ("ode_solver", C.c_int32),
+        ("reserved_", C.c_int32),
+        ("ode_rtol", C.c_double),
+        ("ode_atol", C.c_double),
     ]
 
 

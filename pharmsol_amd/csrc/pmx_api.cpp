@@ -243,6 +243,10 @@ int32_t pmx_model_create(const pmx_model_desc* d, pmx_model** out) {
     if (d->nstates < ode_nstates(d->kernel)) return fail(PMX_ERR_INVALID_ARGUMENT, "model has fewer states than its diffeq");
     if (d->nparams < ode_nparams(d->kernel)) return fail(PMX_ERR_INVALID_ARGUMENT, "too few parameters for the diffeq");
     if (!(d->rk4_h_max > 0.0)) return fail(PMX_ERR_INVALID_ARGUMENT, "rk4_h_max must be > 0");
+    if (d->ode_solver != PMX_SOLVER_RK4 && d->ode_solver != PMX_SOLVER_DOPRI5)
+      return fail(PMX_ERR_INVALID_ARGUMENT, "unknown ode_solver");
+    if (d->ode_solver == PMX_SOLVER_DOPRI5 && !(d->ode_rtol > 0.0 && d->ode_atol > 0.0))
+      return fail(PMX_ERR_INVALID_ARGUMENT, "the adaptive solver needs ode_rtol > 0 and ode_atol > 0");
     if (d->n_derived > 0 || d->n_bind > 0 || pm)
       return fail(PMX_ERR_UNSUPPORTED, "derived parameters / pm indexing are not supported for ODE models yet");
     {
@@ -286,6 +290,10 @@ int32_t check_custom_desc(const pmx_model_desc* d, const char* source) {
   if (d->nout < 1 || d->nout > PMX_MAX_OUT) return fail(PMX_ERR_INVALID_ARGUMENT, "nout out of range");
   if (d->nparams < 1 || d->nparams > PMX_MAX_PARAMS) return fail(PMX_ERR_INVALID_ARGUMENT, "nparams out of range");
   if (!(d->rk4_h_max > 0.0)) return fail(PMX_ERR_INVALID_ARGUMENT, "rk4_h_max must be > 0");
+  if (d->ode_solver != PMX_SOLVER_RK4 && d->ode_solver != PMX_SOLVER_DOPRI5)
+    return fail(PMX_ERR_INVALID_ARGUMENT, "unknown ode_solver");
+  if (d->ode_solver == PMX_SOLVER_DOPRI5 && !(d->ode_rtol > 0.0 && d->ode_atol > 0.0))
+    return fail(PMX_ERR_INVALID_ARGUMENT, "the adaptive solver needs ode_rtol > 0 and ode_atol > 0");
   if (d->n_covariates != 0 || d->n_derived != 0 || d->n_bind != 0 || d->pmetrics_indexing)
     return fail(PMX_ERR_UNSUPPORTED, "covariates / derived parameters / pm indexing are not available to custom ODE bodies yet");
   int n_lag = 0;
@@ -380,7 +388,8 @@ pmx::CompileKey key_for(const pmx_model* m) {
     k.rate_input = 0;
     for (int i = 0; i < PMX_MAX_INPUTS; ++i)
       if (m->d.lag_param[i] >= 0) k.lag_mask |= (1u << i);
-    k.want_times = m->custom;  // a user body may be non-autonomous
+    // absolute piece times: a user body may be non-autonomous; the adaptive solver steps on [t0, t1] itself
+    k.want_times = m->custom || m->d.ode_solver == PMX_SOLVER_DOPRI5;
   }
   return k;
 }
@@ -569,6 +578,9 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
   a.m.pm = d.pmetrics_indexing ? 1 : 0;
   a.m.has_init = model->has_init ? 1 : 0;
   a.m.rk4_h_max = d.rk4_h_max;
+  a.m.ode_rtol = d.ode_rtol;
+  a.m.ode_atol = d.ode_atol;
+  a.adaptive = (d.eq_kind == PMX_EQ_ODE && d.ode_solver == PMX_SOLVER_DOPRI5) ? 1 : 0;
   std::memcpy(a.m.derived, d.derived, sizeof(d.derived));
   std::memcpy(a.m.bind, d.bind, sizeof(d.bind));
   std::memcpy(a.m.out, d.out, sizeof(d.out));
@@ -647,22 +659,23 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
       }
       jm = &it->second;
     }
-    const int lag = a.m.n_lag_slots > 0 ? 1 : 0, ll = a.ops.ll_obs != nullptr ? 1 : 0;
+    const int lag = a.m.n_lag_slots > 0 ? 1 : 0, ll = a.ops.ll_obs != nullptr ? 1 : 0, ad = a.adaptive ? 1 : 0;
     const int mode = a.mode == pmx::MODE_GRID ? 0 : 1;
-    static const char* const kNames[2][2] = {{"pmx_jit_ode_rk4_grid", "pmx_jit_ode_rk4_grid<lag>"},
-                                             {"pmx_jit_ode_rk4_pair", "pmx_jit_ode_rk4_pair<lag>"}};
-    name = kNames[mode][lag];
+    static const char* const kNames[2][2][2] = {
+        {{"pmx_jit_ode_rk4_grid", "pmx_jit_ode_rk4_grid<lag>"}, {"pmx_jit_ode_rk4_pair", "pmx_jit_ode_rk4_pair<lag>"}},
+        {{"pmx_jit_ode_dopri5_grid", "pmx_jit_ode_dopri5_grid<lag>"}, {"pmx_jit_ode_dopri5_pair", "pmx_jit_ode_dopri5_pair<lag>"}}};
+    name = kNames[ad][mode][lag];
     if (a.S <= 0 || (a.P <= 0 && !a.batch)) {
       e = hipSuccess;
     } else if (mode == 0) {
       const int64_t n_chunks = (a.S + a.s_chunk - 1) / a.s_chunk;
       void* args[] = {&a.m, &a.ops, &a.theta, &a.P, &a.S, &a.s_chunk, &a.n_ptiles, &a.pred, &a.ld, &a.status};
-      e = hipModuleLaunchKernel(jm->fn[0][lag][ll], static_cast<uint32_t>(n_chunks * a.n_ptiles), 1, 1, 256, 1, 1, 0,
+      e = hipModuleLaunchKernel(jm->fn[0][lag][ll][ad], static_cast<uint32_t>(n_chunks * a.n_ptiles), 1, 1, 256, 1, 1, 0,
                                 static_cast<hipStream_t>(stream), args, nullptr);
     } else {
       const int64_t n_pairs = a.batch ? a.S : a.S * a.P;
       void* args[] = {&a.m, &a.ops, &a.theta, &a.P, &a.S, &a.batch, &a.pred, &a.ld, &a.status};
-      e = hipModuleLaunchKernel(jm->fn[1][lag][ll], static_cast<uint32_t>((n_pairs + 255) / 256), 1, 1, 256, 1, 1, 0,
+      e = hipModuleLaunchKernel(jm->fn[1][lag][ll][ad], static_cast<uint32_t>((n_pairs + 255) / 256), 1, 1, 256, 1, 1, 0,
                                 static_cast<hipStream_t>(stream), args, nullptr);
     }
   } else {

@@ -33,6 +33,7 @@ struct DevModel {
   int32_t lag_param[4];               // slot -> theta index of the lag time
   int32_t lag_dest[4];                // slot -> state that receives the bolus
   double rk4_h_max;                   // ODE + lag: pieces split on the device recompute n = ceil(dt / h_max)
+  double ode_rtol, ode_atol;          // adaptive solver (PMX_SOLVER_DOPRI5)
 };
 constexpr int kMaxLagSlots = 4;
 

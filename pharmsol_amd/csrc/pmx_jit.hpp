@@ -24,7 +24,7 @@ bool jit_compile(const JitSpec& spec, std::vector<char>* code, std::string* log)
 
 struct JitModule {
   hipModule_t module = nullptr;
-  hipFunction_t fn[2][2][2] = {};  // [mode: 0 GRID, 1 PAIR][LAG][LL]
+  hipFunction_t fn[2][2][2][2] = {};  // [mode: 0 GRID, 1 PAIR][LAG][LL][ADAPT]
 };
 // Load a compiled code object on the CURRENT device and resolve the kernel entry points.
 hipError_t jit_load(const std::vector<char>& code, JitModule* out);

@@ -738,20 +738,20 @@ struct OdeModel<PMX_ODE_ONE_CMT_MM> {  // p=[vmax,km,v]
 };
 
 
-template <int MODEL, bool LAG, bool LL>
+template <int MODEL, bool LAG, bool LL, bool ADAPT>
 __global__ __launch_bounds__(kBlock) void pmx_ode_rk4_grid(DevModel m, DevOps ops, const double* __restrict__ theta,
                                                            int64_t P, int64_t S, int32_t s_chunk, int32_t n_ptiles,
                                                            double* __restrict__ pred, int64_t ld,
                                                            uint8_t* __restrict__ status) {
-  ode_grid_body<OdeModel<MODEL>, LAG, LL>(m, ops, theta, P, S, s_chunk, n_ptiles, pred, ld, status);
+  ode_grid_body<OdeModel<MODEL>, LAG, LL, ADAPT>(m, ops, theta, P, S, s_chunk, n_ptiles, pred, ld, status);
 }
 
-template <int MODEL, bool LAG, bool LL>
+template <int MODEL, bool LAG, bool LL, bool ADAPT>
 __global__ __launch_bounds__(kBlock) void pmx_ode_rk4_pair(DevModel m, DevOps ops, const double* __restrict__ theta,
                                                            int64_t P, int64_t S, int32_t batch,
                                                            double* __restrict__ pred, int64_t ld,
                                                            uint8_t* __restrict__ status) {
-  ode_pair_body<OdeModel<MODEL>, LAG, LL>(m, ops, theta, P, S, batch, pred, ld, status);
+  ode_pair_body<OdeModel<MODEL>, LAG, LL, ADAPT>(m, ops, theta, P, S, batch, pred, ld, status);
 }
 
 // ------------------------------------------------------------------------------------
@@ -819,36 +819,34 @@ hipError_t launch_analytical(const LaunchArgs& a, const char** name) {
   return hipGetLastError();
 }
 
-template <int MODEL, bool LAG>
-hipError_t launch_ode_l(const LaunchArgs& a, const char** name) {
+template <int MODEL, bool LAG, bool LL, bool ADAPT>
+hipError_t launch_ode_v(const LaunchArgs& a, const char** name) {
   hipStream_t st = static_cast<hipStream_t>(a.stream);
   if (a.mode == MODE_GRID) {
-    *name = LAG ? "pmx_ode_rk4_grid<lag>" : "pmx_ode_rk4_grid";
+    *name = ADAPT ? (LAG ? "pmx_ode_dopri5_grid<lag>" : "pmx_ode_dopri5_grid") : (LAG ? "pmx_ode_rk4_grid<lag>" : "pmx_ode_rk4_grid");
     const int64_t n_chunks = (a.S + a.s_chunk - 1) / a.s_chunk;
     const int64_t blocks = n_chunks * a.n_ptiles;
-    if (a.ops.ll_obs != nullptr)
-      hipLaunchKernelGGL((pmx_ode_rk4_grid<MODEL, LAG, true>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlock), 0, st, a.m,
-                         a.ops, a.theta, a.P, a.S, a.s_chunk, a.n_ptiles, a.pred, a.ld, a.status);
-    else
-      hipLaunchKernelGGL((pmx_ode_rk4_grid<MODEL, LAG, false>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlock), 0, st, a.m,
-                         a.ops, a.theta, a.P, a.S, a.s_chunk, a.n_ptiles, a.pred, a.ld, a.status);
+    hipLaunchKernelGGL((pmx_ode_rk4_grid<MODEL, LAG, LL, ADAPT>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlock), 0, st,
+                       a.m, a.ops, a.theta, a.P, a.S, a.s_chunk, a.n_ptiles, a.pred, a.ld, a.status);
   } else {
-    *name = LAG ? "pmx_ode_rk4_pair<lag>" : "pmx_ode_rk4_pair";
+    *name = ADAPT ? (LAG ? "pmx_ode_dopri5_pair<lag>" : "pmx_ode_dopri5_pair") : (LAG ? "pmx_ode_rk4_pair<lag>" : "pmx_ode_rk4_pair");
     const int64_t n_pairs = a.batch ? a.S : a.S * a.P;
     const int64_t blocks = (n_pairs + kBlock - 1) / kBlock;
-    if (a.ops.ll_obs != nullptr)
-      hipLaunchKernelGGL((pmx_ode_rk4_pair<MODEL, LAG, true>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlock), 0, st, a.m,
-                         a.ops, a.theta, a.P, a.S, a.batch, a.pred, a.ld, a.status);
-    else
-      hipLaunchKernelGGL((pmx_ode_rk4_pair<MODEL, LAG, false>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlock), 0, st, a.m,
-                         a.ops, a.theta, a.P, a.S, a.batch, a.pred, a.ld, a.status);
+    hipLaunchKernelGGL((pmx_ode_rk4_pair<MODEL, LAG, LL, ADAPT>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlock), 0, st,
+                       a.m, a.ops, a.theta, a.P, a.S, a.batch, a.pred, a.ld, a.status);
   }
   return hipGetLastError();
 }
 
 template <int MODEL>
 hipError_t launch_ode(const LaunchArgs& a, const char** name) {
-  return a.m.n_lag_slots > 0 ? launch_ode_l<MODEL, true>(a, name) : launch_ode_l<MODEL, false>(a, name);
+  const bool lag = a.m.n_lag_slots > 0, ll = a.ops.ll_obs != nullptr, ad = a.adaptive != 0;
+  if (lag) {
+    if (ll) return ad ? launch_ode_v<MODEL, true, true, true>(a, name) : launch_ode_v<MODEL, true, true, false>(a, name);
+    return ad ? launch_ode_v<MODEL, true, false, true>(a, name) : launch_ode_v<MODEL, true, false, false>(a, name);
+  }
+  if (ll) return ad ? launch_ode_v<MODEL, false, true, true>(a, name) : launch_ode_v<MODEL, false, true, false>(a, name);
+  return ad ? launch_ode_v<MODEL, false, false, true>(a, name) : launch_ode_v<MODEL, false, false, false>(a, name);
 }
 
 template <int KID>

@@ -48,6 +48,94 @@ __device__ __forceinline__ void rk4_step(const double* kp, double (&x)[M::NS], c
   for (int i = 0; i < NS; ++i) x[i] = x[i] + (h / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
 }
 
+// ---- adaptive: Dormand-Prince 5(4) ("dopri5" / ode45), PMX_SOLVER_DOPRI5 --------------------------------------
+// One ATTEMPTED step of length h from (t, x): fills xn with the 5th-order solution and returns the scaled error
+// norm rms(e_i / (atol + rtol max(|x_i|, |xn_i|))); the step is acceptable iff the result is <= 1.
+template <class M>
+__device__ __forceinline__ double dopri5_try(const DevModel& m, const double* kp, const double (&x)[M::NS],
+                                             const double (&rs)[M::NR], double t, double h, double (&xn)[M::NS]) {
+  constexpr int NS = M::NS;
+  double k1[NS], k2[NS], k3[NS], k4[NS], k5[NS], k6[NS], k7[NS], xt[NS];
+  ode_eval<M>(t, kp, x, rs, k1);
+#pragma unroll
+  for (int i = 0; i < NS; ++i) xt[i] = x[i] + h * (0.2 * k1[i]);
+  ode_eval<M>(t + 0.2 * h, kp, xt, rs, k2);
+#pragma unroll
+  for (int i = 0; i < NS; ++i) xt[i] = x[i] + h * ((3.0 / 40.0) * k1[i] + (9.0 / 40.0) * k2[i]);
+  ode_eval<M>(t + 0.3 * h, kp, xt, rs, k3);
+#pragma unroll
+  for (int i = 0; i < NS; ++i) xt[i] = x[i] + h * ((44.0 / 45.0) * k1[i] - (56.0 / 15.0) * k2[i] + (32.0 / 9.0) * k3[i]);
+  ode_eval<M>(t + 0.8 * h, kp, xt, rs, k4);
+#pragma unroll
+  for (int i = 0; i < NS; ++i)
+    xt[i] = x[i] + h * ((19372.0 / 6561.0) * k1[i] - (25360.0 / 2187.0) * k2[i] + (64448.0 / 6561.0) * k3[i] -
+                        (212.0 / 729.0) * k4[i]);
+  ode_eval<M>(t + (8.0 / 9.0) * h, kp, xt, rs, k5);
+#pragma unroll
+  for (int i = 0; i < NS; ++i)
+    xt[i] = x[i] + h * ((9017.0 / 3168.0) * k1[i] - (355.0 / 33.0) * k2[i] + (46732.0 / 5247.0) * k3[i] +
+                        (49.0 / 176.0) * k4[i] - (5103.0 / 18656.0) * k5[i]);
+  ode_eval<M>(t + h, kp, xt, rs, k6);
+#pragma unroll
+  for (int i = 0; i < NS; ++i)
+    xn[i] = x[i] + h * ((35.0 / 384.0) * k1[i] + (500.0 / 1113.0) * k3[i] + (125.0 / 192.0) * k4[i] -
+                        (2187.0 / 6784.0) * k5[i] + (11.0 / 84.0) * k6[i]);
+  ode_eval<M>(t + h, kp, xn, rs, k7);
+  double acc = 0.0;
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const double e = h * ((71.0 / 57600.0) * k1[i] - (71.0 / 16695.0) * k3[i] + (71.0 / 1920.0) * k4[i] -
+                          (17253.0 / 339200.0) * k5[i] + (22.0 / 525.0) * k6[i] - (1.0 / 40.0) * k7[i]);
+    const double sc = m.ode_atol + m.ode_rtol * fmax(fabs(x[i]), fabs(xn[i]));
+    const double q = e / sc;
+    acc += q * q;
+  }
+  return sqrt(acc / static_cast<double>(NS));
+}
+
+// Step-size controller state of a lane: `h` = the controller's current proposal (carried from piece to piece).
+struct AdaptState {
+  double h;
+  uint8_t failed;
+};
+
+// One attempt inside the piece [.., t1]: tries min(h, t1 - t, h_max); on acceptance advances (t, x).  Returns true
+// while the piece is unfinished.  A step that underflows (h < 1e-13 max(1,|t|)) marks the lane failed and jumps to
+// the end of the piece so that every lane terminates.
+template <class M>
+__device__ __forceinline__ bool dopri5_advance(const DevModel& m, const double* kp, double (&x)[M::NS],
+                                               const double (&rs)[M::NR], double& t, double t1, AdaptState& as) {
+  constexpr int NS = M::NS;
+  const double left = t1 - t;
+  if (!(left > 0.0)) return false;
+  double h = fmin(as.h, m.rk4_h_max);
+  const bool clipped = h >= left;
+  if (clipped) h = left;
+  double xn[NS];
+  const double err = dopri5_try<M>(m, kp, x, rs, t, h, xn);
+  const bool ok = err <= 1.0;  // (false for NaN)
+  // factor 0.9 err^(-1/5) in [0.2, 5]; no growth right after a rejection
+  double fac = (err > 0.0) ? 0.9 * pow(err, -0.2) : 5.0;
+  if (!(fac >= 0.2)) fac = 0.2;  // also catches NaN
+  if (fac > 5.0) fac = 5.0;
+  if (!ok && fac > 1.0) fac = 1.0;
+  const double h_next = h * fac;
+  if (ok) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) x[i] = xn[i];
+    t = clipped ? t1 : (t + h);
+    as.h = clipped ? fmax(as.h, h_next) : h_next;  // a step cut short by the piece end must not shrink the proposal
+    return !clipped;
+  }
+  as.h = h_next;
+  if (!(h_next > 1.0e-13 * fmax(1.0, fabs(t)))) {  // step-size underflow (or NaN): give up on this piece
+    as.failed = 1;
+    t = t1;
+    return false;
+  }
+  return true;
+}
+
 template <class M>
 struct OdeLane {
   double kp[M::NP];
@@ -123,11 +211,17 @@ __device__ __forceinline__ void ode_rates(const DevModel& m, const double* __res
 
 // One constant-rate piece [t0, t1] whose length is only known on the device (a lagged bolus split it):
 // n = ceil(dt / h_max) classic RK4 steps, the host compiler's rule (pmx_compile.cpp, ODE PROP ops).
-template <class M>
+template <class M, bool ADAPT>
 __device__ __forceinline__ void ode_piece(const DevModel& m, const double* kp, double (&x)[M::NS],
-                                          const double (&rs)[M::NR], double t0, double t1) {
+                                          const double (&rs)[M::NR], double t0, double t1, AdaptState& as) {
   const double dt = t1 - t0;
   if (!(dt > 0.0)) return;
+  if constexpr (ADAPT) {
+    double t = t0;
+    for (int32_t guard = 0; guard < 10000000 && dopri5_advance<M>(m, kp, x, rs, t, t1, as); ++guard) {
+    }
+    return;
+  }
   double nf = ceil(dt / m.rk4_h_max);
   if (!(nf >= 1.0)) nf = 1.0;
   if (nf > 1.0e7) nf = 1.0e7;  // a lane with an absurd lag must still terminate
@@ -139,10 +233,10 @@ __device__ __forceinline__ void ode_piece(const DevModel& m, const double* kp, d
 // lag_open_occasion / lag_prop of the ODE back-end: same merge rule, RK4 pieces instead of closed forms.
 // Between an early lagged bolus and the occasion's first remaining event no infusion can be active
 // (infusions are events of the occasion), so those pieces run with zero rates.
-template <class M>
+template <class M, bool ADAPT>
 __device__ __forceinline__ void ode_lag_open_occasion(const DevModel& m, const DevOps& ops, LagState& ls, int64_t occ,
                                                       double t_first, const double* kp, const double* __restrict__ th,
-                                                      double (&x)[M::NS]) {
+                                                      double (&x)[M::NS], AdaptState& as) {
   constexpr int NS = M::NS;
 #pragma unroll
   for (int k = 0; k < kMaxLagSlots; ++k) {
@@ -162,18 +256,18 @@ __device__ __forceinline__ void ode_lag_open_occasion(const DevModel& m, const D
     int which;
     const double tau = lag_next(m, ops, ls, which);
     if (!(tau < t_first)) break;
-    if (started) ode_piece<M>(m, kp, x, zero, t, tau);
+    if (started) ode_piece<M, ADAPT>(m, kp, x, zero, t, tau, as);
     t = tau;
     started = true;
     lag_apply_bolus<NS>(m, ops, ls, which, th, x);
   }
-  if (started && t_first < __longlong_as_double(0x7ff0000000000000LL)) ode_piece<M>(m, kp, x, zero, t, t_first);
+  if (started && t_first < __longlong_as_double(0x7ff0000000000000LL)) ode_piece<M, ADAPT>(m, kp, x, zero, t, t_first, as);
 }
 
-template <class M>
+template <class M, bool ADAPT>
 __device__ __forceinline__ void ode_lag_prop(const DevModel& m, const DevOps& ops, LagState& ls, double t0, double t1,
                                              const double* kp, const double (&rs)[M::NR],
-                                             const double* __restrict__ th, double (&x)[M::NS]) {
+                                             const double* __restrict__ th, double (&x)[M::NS], AdaptState& as) {
   constexpr int NS = M::NS;
   double t = t0;
   for (;;) {
@@ -181,15 +275,15 @@ __device__ __forceinline__ void ode_lag_prop(const DevModel& m, const DevOps& op
     const double tau = lag_next(m, ops, ls, which);
     if (!(tau < t1)) break;
     if (tau > t) {
-      ode_piece<M>(m, kp, x, rs, t, tau);
+      ode_piece<M, ADAPT>(m, kp, x, rs, t, tau, as);
       t = tau;
     }
     lag_apply_bolus<NS>(m, ops, ls, which, th, x);
   }
-  ode_piece<M>(m, kp, x, rs, t, t1);
+  ode_piece<M, ADAPT>(m, kp, x, rs, t, t1, as);
 }
 
-template <class M, bool LAG, bool LL>
+template <class M, bool LAG, bool LL, bool ADAPT>
 __device__ __forceinline__ void ode_grid_body(const DevModel& m, const DevOps& ops, const double* __restrict__ theta,
                                               int64_t P, int64_t S, int32_t s_chunk, int32_t n_ptiles,
                                               double* __restrict__ pred, int64_t ld, uint8_t* __restrict__ status) {
@@ -228,6 +322,9 @@ __device__ __forceinline__ void ode_grid_body(const DevModel& m, const DevOps& o
     for (int i = 0; i < NS; ++i) x[i] = 0.0;
     uint8_t st = st_lane;
     double ll_acc = 0.0;
+    AdaptState as;  // adaptive solver: the step-size proposal restarts with every subject
+    as.h = m.rk4_h_max;
+    as.failed = 0;
     for (int64_t o = o0; o < o1; ++o) {
       const uint32_t meta = uniform32(ops.op_meta[o]);
       const uint32_t kind = meta & 0xffu;
@@ -237,7 +334,9 @@ __device__ __forceinline__ void ode_grid_body(const DevModel& m, const DevOps& o
         double rs[M::NR];
         ode_rates<M>(m, ops.op_rate, o, ops.n_rate, rs);
         if constexpr (LAG) {
-          ode_lag_prop<M>(m, ops, ls, uniformf64(ops.op_t0[o]), uniformf64(ops.op_t1[o]), L.kp, rs, th, x);
+          ode_lag_prop<M, ADAPT>(m, ops, ls, uniformf64(ops.op_t0[o]), uniformf64(ops.op_t1[o]), L.kp, rs, th, x, as);
+        } else if constexpr (ADAPT) {
+          ode_piece<M, true>(m, L.kp, x, rs, uniformf64(ops.op_t0[o]), uniformf64(ops.op_t1[o]), as);
         } else {
           const double h = uniformf64(ops.op_b[o]);
           const int32_t n = static_cast<int32_t>(uniform32(static_cast<uint32_t>(ops.op_n[o])));
@@ -248,6 +347,10 @@ __device__ __forceinline__ void ode_grid_body(const DevModel& m, const DevOps& o
       } else if (kind == OP_OBS) {
         double y = ode_out<M>(m, L, x, io, a);
         if (LAG && st == PMX_PAIR_BAD_LAG) y = nanv;
+        if (ADAPT && as.failed) {  // step-size underflow somewhere before this row
+          if (st == PMX_PAIR_OK) st = PMX_PAIR_SOLVER_FAIL;
+          y = nanv;
+        }
         if constexpr (LL) {
           ll_accumulate(ops.ll_obs + row * 4, y, ll_acc);
         } else {
@@ -264,7 +367,7 @@ __device__ __forceinline__ void ode_grid_body(const DevModel& m, const DevOps& o
 #pragma unroll
         for (int i = 0; i < NS; ++i) x[i] = io ? L.xinit[i] : 0.0;
         if constexpr (LAG)
-          ode_lag_open_occasion<M>(m, ops, ls, static_cast<int64_t>(a), uniformf64(ops.op_t0[o]), L.kp, th, x);
+          ode_lag_open_occasion<M, ADAPT>(m, ops, ls, static_cast<int64_t>(a), uniformf64(ops.op_t0[o]), L.kp, th, x, as);
       }
     }
     if constexpr (LL) {
@@ -278,7 +381,7 @@ __device__ __forceinline__ void ode_grid_body(const DevModel& m, const DevOps& o
 // PAIR: each lane is a small state machine {cursor o, remaining RK4 steps}; one trip of the
 // wave loop performs either one RK4 step or one op per lane, so lanes in different segments
 // of different subjects still step in lock-step (divergent timelines, C4).
-template <class M, bool LAG, bool LL>
+template <class M, bool LAG, bool LL, bool ADAPT>
 __device__ __forceinline__ void ode_pair_body(const DevModel& m, const DevOps& ops, const double* __restrict__ theta,
                                               int64_t P, int64_t S, int32_t batch, double* __restrict__ pred,
                                               int64_t ld, uint8_t* __restrict__ status) {
@@ -321,6 +424,12 @@ __device__ __forceinline__ void ode_pair_body(const DevModel& m, const DevOps& o
   // custom bodies may read the time: the open piece's start and step count (stage time = t_piece + k h)
   double t_piece = 0.0;
   int32_t n_piece = 0;
+  // adaptive solver: the running piece [t_run, t_run_end] and the lane's step-size proposal
+  bool stepping = false;
+  double t_run = 0.0, t_run_end = 0.0;
+  AdaptState as;
+  as.h = m.rk4_h_max;
+  as.failed = 0;
   double ll_acc = 0.0;
   // LAG: an open PROP (or occasion opening) [t_cur, t_stop) that lagged boluses may still split
   bool in_prop = false;
@@ -328,26 +437,36 @@ __device__ __forceinline__ void ode_pair_body(const DevModel& m, const DevOps& o
   // ONE action per lane per trip (an RK4 step, a lag sub-piece decision, or an op), written as a single if / else
   // chain: with `continue`s the compiler rotates the stepping branch into an inner per-lane loop and lanes that
   // need an op wait for the longest piece in the wave (measured: C4 2.4 -> 3.9 ms).
-  while (rem > 0 || o < o1) {
-    if (rem > 0) {
-      double t = 0.0;
-      if constexpr (M::CUSTOM) t = t_piece + static_cast<double>(n_piece - rem) * h;
-      rk4_step<M>(L.kp, x, rs, t, h);
-      --rem;
+  while ((ADAPT ? stepping : rem > 0) || o < o1) {
+    if (ADAPT ? stepping : rem > 0) {
+      if constexpr (ADAPT) {
+        stepping = dopri5_advance<M>(m, L.kp, x, rs, t_run, t_run_end, as);  // one attempted step per trip
+      } else {
+        double t = 0.0;
+        if constexpr (M::CUSTOM) t = t_piece + static_cast<double>(n_piece - rem) * h;
+        rk4_step<M>(L.kp, x, rs, t, h);
+        --rem;
+      }
     } else if (LAG && in_prop) {
       int which;
       const double tau = lag_next(m, ops, ls, which);
       const bool bol = tau < t_stop;
       const double stop = bol ? tau : t_stop;
       if (stop > t_cur) {  // next sub-piece; n = ceil(dt / h_max) as ode_piece
-        const double dt = stop - t_cur;
-        double nf = ceil(dt / m.rk4_h_max);
-        if (!(nf >= 1.0)) nf = 1.0;
-        if (nf > 1.0e7) nf = 1.0e7;
-        rem = static_cast<int32_t>(nf);
-        h = dt / static_cast<double>(rem);
-        t_piece = t_cur;
-        n_piece = rem;
+        if constexpr (ADAPT) {
+          stepping = true;
+          t_run = t_cur;
+          t_run_end = stop;
+        } else {
+          const double dt = stop - t_cur;
+          double nf = ceil(dt / m.rk4_h_max);
+          if (!(nf >= 1.0)) nf = 1.0;
+          if (nf > 1.0e7) nf = 1.0e7;
+          rem = static_cast<int32_t>(nf);
+          h = dt / static_cast<double>(rem);
+          t_piece = t_cur;
+          n_piece = rem;
+        }
         t_cur = stop;
       } else if (bol) {
         lag_apply_bolus<NS>(m, ops, ls, which, th, x);
@@ -368,6 +487,10 @@ __device__ __forceinline__ void ode_pair_body(const DevModel& m, const DevOps& o
           t_cur = ops.op_t0[o];
           t_stop = ops.op_t1[o];
           next_op = false;
+        } else if constexpr (ADAPT) {
+          t_run = ops.op_t0[o];
+          t_run_end = ops.op_t1[o];
+          stepping = t_run_end > t_run;
         } else {
           h = ops.op_b[o];
           rem = ops.op_n[o];
@@ -379,6 +502,10 @@ __device__ __forceinline__ void ode_pair_body(const DevModel& m, const DevOps& o
       } else if (kind == OP_OBS) {
         double y = ode_out<M>(m, L, x, io, a);
         if (LAG && st == PMX_PAIR_BAD_LAG) y = nanv;
+        if (ADAPT && as.failed) {
+          if (st == PMX_PAIR_OK) st = PMX_PAIR_SOLVER_FAIL;
+          y = nanv;
+        }
         if constexpr (LL) {
           ll_accumulate(ops.ll_obs + row * 4, y, ll_acc);
         } else {

@@ -272,6 +272,8 @@ class Equation:
             else:
                 d.infusion_dest[idx] = dest
         d.rk4_h_max = self.rk4_h_max
+        d.ode_solver = getattr(self, "ode_solver", _abi.PMX_SOLVER_RK4)
+        d.ode_rtol, d.ode_atol = getattr(self, "ode_rtol", 1e-4), getattr(self, "ode_atol", 1e-4)
         return d
 
     def _kernel_id(self) -> int:
@@ -381,6 +383,23 @@ class ODE(Equation):
         m.fa = {str(k): v for k, v in (fa or {}).items()}
         m.rk4_h_max = float(h_max)
         return m.with_nstates(nstates).with_ndrugs(ndrugs).with_nout(nout)
+
+    ode_solver = _abi.PMX_SOLVER_RK4
+    ode_rtol = 1e-4  # the reference's defaults (ode/mod.rs:126-127)
+    ode_atol = 1e-4
+
+    def with_solver(self, solver: str) -> "ODE":
+        """``ODE::with_solver`` (ode/mod.rs:134-150).  The reference's diffsol solvers are replaced: ``"rk4"`` = fixed
+        step (default), ``"dopri5"`` = adaptive Dormand-Prince 5(4) with per-lane step control."""
+        self.ode_solver = {"rk4": _abi.PMX_SOLVER_RK4, "dopri5": _abi.PMX_SOLVER_DOPRI5}[solver]
+        self._handle = None
+        return self
+
+    def with_tolerances(self, rtol: float, atol: float) -> "ODE":
+        """``ODE::with_tolerances`` (ode/mod.rs:152-166); read by the adaptive solver."""
+        self.ode_rtol, self.ode_atol = float(rtol), float(atol)
+        self._handle = None
+        return self
 
     def with_step(self, h_max: float) -> "ODE":
         self.rk4_h_max = float(h_max)

@@ -47,12 +47,18 @@ def rel_err(a, b):
     return np.abs(a - b) / np.maximum(np.abs(b), 1e-9)
 
 
+def rel_err_floor(a, b):
+    """Relative error with a floor at 1e-3 of the largest value: an adaptive solver controls atol + rtol |x|, i.e.
+    it does not promise relative accuracy on a concentration that has decayed by ten orders of magnitude."""
+    return np.abs(a - b) / np.maximum(np.abs(b), 1e-3 * np.abs(b).max())
+
+
 # --------------------------------------------------------------------------- compile path (no GPU needed)
 def test_translation_unit_wraps_the_user_source_into_the_shared_walkers():
     m = ODE.custom(ONE_CMT, nstates=1, nparams=2)
     tu = runtime.jit_translation_unit(m)
     assert '#include "pmx_ode.hpp"' in tu and "pmx_dynamics(t, x, p, nullptr, r, nullptr, dx)" in tu
-    assert "NS = 1, NP = 2" in tu and tu.count("extern \"C\" __global__") == 8  # grid/pair x lag x loglik
+    assert "NS = 1, NP = 2" in tu and tu.count("extern \"C\" __global__") == 16  # grid/pair x lag x loglik x solver
     runtime.DeviceModel(m)  # hiprtc compiles for gfx950 without a device
 
 
@@ -192,3 +198,98 @@ PMX_DEVICE void pmx_outputs({SIG}y) {{ y[0] = x[0] / p[1]; }}
     want, wst = oracle.loglik(m2, flat2, em, th2)
     np.testing.assert_array_equal(st.cpu().numpy(), wst)
     assert (np.abs(ll.cpu().numpy() - want) / np.maximum(np.abs(want), 1.0)).max() < 1e-9
+
+
+# --------------------------------------------------------------------------- adaptive solver (PMX_SOLVER_DOPRI5)
+def _mm_subjects(rng, n):
+    subs = []
+    for i in range(n):
+        b = Subject.builder(f"m{i}").bolus(0.0, float(rng.uniform(100, 600)), 0)
+        if i % 2:
+            b = b.infusion(float(rng.uniform(1, 6)), float(rng.uniform(100, 400)), 0, float(rng.uniform(0.5, 3)))
+        for t in sorted(rng.uniform(0.1, 48, 6)):
+            b = b.missing_observation(float(t), 0)
+        subs.append(b.build())
+    return subs
+
+
+def test_oracle_dopri5_against_closed_form_and_fine_rk4():
+    rng = np.random.default_rng(31)
+    subs = _mm_subjects(rng, 10)
+    ma = Analytical.new("one_compartment", {0: Ratio(0, 1)}, nparams=2).with_nstates(1).with_ndrugs(1).with_nout(1)
+    mo = (ODE.new("one_cmt_iv", {0: Ratio(0, 1)}, nparams=2, h_max=4.0).with_nstates(1).with_ndrugs(1).with_nout(1)
+          .with_solver("dopri5").with_tolerances(1e-9, 1e-9))
+    th = np.stack([rng.uniform(0.05, 1.0, 8), rng.uniform(10, 50, 8)], axis=1)
+    want, _ = oracle.predict(ma, ma.flatten(Data(subs)), th)
+    got, st = oracle.predict(mo, mo.flatten(Data(subs)), th)
+    assert (st == 0).all() and rel_err_floor(got, want).max() < 1e-7
+    # looser tolerances -> proportionally larger error, still far inside the 1e-4 ODE budget at the reference's defaults
+    mo.with_tolerances(1e-4, 1e-4)
+    got, _ = oracle.predict(mo, mo.flatten(Data(subs)), th)
+    assert 1e-9 < rel_err_floor(got, want).max() < 1e-3
+    # nonlinear (Michaelis-Menten): against fixed-step RK4 at h = 0.002
+    mm_fix = ODE.new("one_cmt_mm", {0: Ratio(0, 2)}, nparams=3, h_max=0.002).with_nstates(1).with_ndrugs(1).with_nout(1)
+    mm_ad = (ODE.new("one_cmt_mm", {0: Ratio(0, 2)}, nparams=3, h_max=8.0).with_nstates(1).with_ndrugs(1).with_nout(1)
+             .with_solver("dopri5").with_tolerances(1e-10, 1e-10))
+    th3 = np.stack([rng.uniform(5, 30, 6), rng.uniform(1, 10, 6), rng.uniform(10, 40, 6)], axis=1)
+    a, _ = oracle.predict(mm_fix, mm_fix.flatten(Data(subs)), th3)
+    b, _ = oracle.predict(mm_ad, mm_ad.flatten(Data(subs)), th3)
+    assert rel_err_floor(b, a).max() < 1e-7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_support,batch", [(70, False), (4, False), (0, True)])
+def test_gpu_dopri5_builtin_models(n_support, batch):
+    rng = np.random.default_rng(32)
+    subs = _mm_subjects(rng, 50)
+    m = (ODE.new("two_cmt_iv", {0: Ratio(0, 3)}, nparams=4, h_max=6.0).with_nstates(2).with_ndrugs(1).with_nout(1)
+         .with_solver("dopri5").with_tolerances(1e-8, 1e-8))
+    flat = m.flatten(Data(subs))
+    th = synth.theta_c3(len(subs) if batch else n_support)
+    got, st = _gpu(m, flat, th, batch=batch)
+    want, wst = (oracle.predict_batch if batch else oracle.predict)(m, flat, th)
+    assert runtime.last_kernel_name() == ("pmx_ode_dopri5_pair" if (batch or n_support < 32) else "pmx_ode_dopri5_grid")
+    np.testing.assert_array_equal(st, wst)
+    # same algorithm, same tolerances; FMA contraction may move a step boundary, so agreement is at the solver's
+    # tolerance rather than at rounding level
+    assert rel_err_floor(got, want).max() < 1e-6
+    ma = Analytical.new("two_compartments", {0: Ratio(0, 3)}, nparams=4).with_nstates(2).with_ndrugs(1).with_nout(1)
+    exact, _ = (oracle.predict_batch if batch else oracle.predict)(ma, ma.flatten(Data(subs)), th)
+    assert rel_err_floor(got, exact).max() < 1e-5
+
+
+@pytest.mark.gpu
+def test_gpu_dopri5_custom_model_with_lag_and_step_underflow_flag():
+    from tests.test_gpu_parity import _lag_subjects
+
+    rng = np.random.default_rng(33)
+    src = f"""
+PMX_DEVICE void pmx_dynamics({SIG}dx) {{ dx[0] = -p[0] * x[0] + rateiv[0] + p[2] * sin(0.3 * t); }}
+PMX_DEVICE void pmx_outputs({SIG}y) {{ y[0] = x[0] / p[1]; }}
+"""
+    oracle.compile_custom(src)
+    m = (ODE.custom(src, nstates=1, nparams=5, lag={0: 3}, fa={0: 4}, h_max=5.0).with_solver("dopri5")
+         .with_tolerances(1e-8, 1e-8))
+    flat = m.flatten(Data(_lag_subjects(rng, 30)))
+    for n in (64, 3):
+        th = np.stack([rng.uniform(0.05, 0.4, n), rng.uniform(5, 40, n), rng.uniform(0, 5, n),
+                       np.round(rng.uniform(0, 3, n) * 2) / 2, rng.uniform(0.3, 1.0, n)], axis=1)
+        got, st = _gpu(m, flat, th)
+        want, wst = oracle.predict(m, flat, th)
+        assert runtime.last_kernel_name().startswith("pmx_jit_ode_dopri5_" + ("grid<lag>" if n >= 32 else "pair<lag>"))
+        np.testing.assert_array_equal(st, wst)
+        assert rel_err_floor(got, want).max() < 1e-6
+    # a right-hand side that blows up in finite time: the controller runs out of step size -> flagged, NaN rows
+    boom = f"""
+PMX_DEVICE void pmx_dynamics({SIG}dx) {{ dx[0] = p[0] * x[0] * x[0]; }}
+PMX_DEVICE void pmx_outputs({SIG}y) {{ y[0] = x[0]; }}
+"""
+    oracle.compile_custom(boom)
+    mb = ODE.custom(boom, nstates=1, nparams=1, h_max=1.0).with_solver("dopri5").with_tolerances(1e-6, 1e-6)
+    s = Subject.builder("b").bolus(0.0, 1.0, 0).missing_observation(0.5, 0).missing_observation(2.0, 0).build()
+    th = np.array([[1.0]] * 40)  # x' = x^2, x(0) = 1: singular at t = 1
+    got, st = _gpu(mb, mb.flatten(s), th)
+    want, wst = oracle.predict(mb, mb.flatten(s), th)
+    np.testing.assert_array_equal(st, wst)
+    assert (st == _abi.PMX_PAIR_SOLVER_FAIL).all() and np.isnan(got[1]).all()
+    assert rel_err_floor(got[0], np.full(40, 2.0)).max() < 1e-5  # x(0.5) = 1 / (1 - 0.5)
