@@ -243,3 +243,10 @@ def test_library_sorts_like_occasion_sort():
     assert kinds == [_abi.PMX_OP_RESET, _abi.PMX_OP_OBS, _abi.PMX_OP_PROP, _abi.PMX_OP_OBS, _abi.PMX_OP_BOLUS]
     want, _ = oracle.predict(m, flat, np.array([[0.3, 2.0]]))
     assert want[0, 0] == 0.0 and want[1, 0] == 0.0
+
+
+def test_graft_entry_build_is_consistent_with_the_library():
+    """`__graft_entry__.build()` is the driver's "does it build" check: it must pass against the ABI the tree has."""
+    import __graft_entry__ as g
+
+    g.build()
