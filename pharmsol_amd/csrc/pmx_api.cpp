@@ -375,6 +375,8 @@ pmx::CompileKey key_for(const pmx_model* m) {
     }
     const char* nl = std::getenv("PMX_DISABLE_LADDER");  // fresh exp() on every step (A/B and parity checks)
     k.ladder = !m->dyn && k.lag_mask == 0 && !(nl && nl[0] && nl[0] != '0');
+    k.n_derived = m->d.n_derived;
+    std::memcpy(k.derived, m->d.derived, sizeof(k.derived));
     const char* off = std::getenv("PMX_DISABLE_CLASSING");
     const bool disabled = off && off[0] && off[0] != '0';
     if (!disabled && !m->dyn && !m->d.pmetrics_indexing && m->d.n_covariates == 0 && k.lag_mask == 0 && !has_fa) {
@@ -419,7 +421,7 @@ int32_t get_stream(pmx_population* pop, const pmx::CompileKey& key, DeviceStream
   if ((rc = upload(os.op_b, &ds->dev.op_b, &ds->allocs)) != PMX_OK) return rc;
   if ((rc = upload(os.op_n, &ds->dev.op_n, &ds->allocs)) != PMX_OK) return rc;
   if ((rc = upload(os.op_rate, &ds->dev.op_rate, &ds->allocs)) != PMX_OK) return rc;
-  if ((rc = upload(os.op_cov, &ds->dev.op_cov, &ds->allocs)) != PMX_OK) return rc;
+  if ((rc = upload(os.op_fac, &ds->dev.op_fac, &ds->allocs)) != PMX_OK) return rc;
   if ((rc = upload(os.op_t0, &ds->dev.op_t0, &ds->allocs)) != PMX_OK) return rc;
   if ((rc = upload(os.op_t1, &ds->dev.op_t1, &ds->allocs)) != PMX_OK) return rc;
   if ((rc = upload(os.lagb_off, &ds->dev.lagb_off, &ds->allocs)) != PMX_OK) return rc;

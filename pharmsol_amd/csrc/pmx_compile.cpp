@@ -194,6 +194,7 @@ int32_t compile_ops(const HostPopulation& hp, const CompileKey& key, OpStream* o
   os->op_n.clear();
   os->op_rate.clear();
   os->op_cov.clear();
+  os->op_fac.clear();
   os->op_t0.clear();
   os->op_t1.clear();
   os->lagb_off.clear();
@@ -231,7 +232,20 @@ int32_t compile_ops(const HostPopulation& hp, const CompileKey& key, OpStream* o
         double v = 0.0;
         if (want_cov && !hp.interpolate(occ, c, t_cov, &v)) cov_missing = true;
         os->op_cov.push_back(v);
+        covv[c] = v;
       }
+      // the factors of every derived value at these covariates (expand/analytical.rs:254,286; bindings.rs:98-117),
+      // written exactly like the per-lane expression they replace
+      for (int32_t d = 0; d < key.n_derived; ++d)
+        for (int32_t k = 0; k < PMX_MAX_FACTORS; ++k) {
+          double fac = 1.0;
+          if (want_cov && k < key.derived[d].n_factors) {
+            const pmx_factor& f = key.derived[d].f[k];
+            const double cv = covv[f.cov];
+            fac = (f.op == PMX_F_POW) ? std::pow(cv / f.ref, f.coef) : (1.0 + f.coef * (cv - f.ref));
+          }
+          os->op_fac.push_back(fac);
+        }
     }
   };
 

@@ -17,6 +17,7 @@
 #pragma once
 
 #include <cstdint>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -67,13 +68,18 @@ struct CompileKey {
   int32_t class_g = 0;     // analytical GRID: members per chunk of the classed kernel (0 = no class plan)
   uint32_t lag_mask = 0;   // bit i: boluses on input i are delayed by a theta-dependent lag -> kept OUT of the
                            // op stream and merged per lane on the device (Occasion::add_lagtime, structs.rs:611-643)
+  // covariate factors of the model's derived values (theta * f0 * f1): lane-independent, so the host evaluates
+  // pow((cov/ref), e) / 1 + a (cov - ref) once per op instead of every lane on every op (op_fac)
+  int32_t n_derived = 0;
+  pmx_derived derived[PMX_MAX_DERIVED] = {};
   bool want_times = false; // PROP ops carry absolute [t0, t1) even without lag (custom ODE bodies may read the time)
   bool ladder = false;     // analytical, theta-only coefficients, no lag: PROP ops carry the exponential-ladder code
                            // (bits 27-29 of op_meta, pmx_structures.hpp ladder_pow)
   bool operator==(const CompileKey& o) const {
     return eq_kind == o.eq_kind && cov_time_mode == o.cov_time_mode && rk4_h_max == o.rk4_h_max &&
            n_rate == o.n_rate && rate_input == o.rate_input && class_g == o.class_g && lag_mask == o.lag_mask &&
-           ladder == o.ladder && want_times == o.want_times;
+           ladder == o.ladder && want_times == o.want_times && n_derived == o.n_derived &&
+           std::memcmp(derived, o.derived, sizeof(derived)) == 0;
   }
 };
 
@@ -87,6 +93,7 @@ struct OpStream {
   std::vector<int32_t> op_n;         // ODE PROP: RK4 step count (empty for analytical)
   std::vector<double> op_rate;       // ODE: [n_ops * n_rate] rateiv per PROP (empty for analytical)
   std::vector<double> op_cov;        // [n_ops * n_cov] covariates seen by the op (empty if n_cov == 0)
+  std::vector<double> op_fac;        // [n_ops * n_derived * PMX_MAX_FACTORS] the derived values' factors at those covariates
   // lag models only (key.lag_mask != 0):
   std::vector<double> op_t0, op_t1;  // absolute [start, end] of every PROP; RESET: op_t0 = time of the occasion's
                                      // first remaining event (+inf if none), op_a = global occasion index

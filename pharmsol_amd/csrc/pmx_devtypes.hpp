@@ -47,7 +47,7 @@ struct DevOps {
   const double* op_b;           // [n_ops]
   const int32_t* op_n;          // [n_ops] (ODE)
   const double* op_rate;        // [n_ops*n_rate] (ODE)
-  const double* op_cov;         // [n_ops*n_cov]
+  const double* op_fac;         // [n_ops*n_derived*PMX_MAX_FACTORS] covariate factors of the derived values (host-evaluated)
   const double* op_t0;          // lag models: absolute start of each PROP / first event time of a RESET's occasion
   const double* op_t1;          // lag models: absolute end of each PROP
   const int64_t* lagb_off;      // [(n_occasions*n_lag_slots)+1]

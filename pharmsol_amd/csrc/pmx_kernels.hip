@@ -37,18 +37,18 @@ namespace pmx {
 
 namespace {
 
-// derive: derived[d] = ((theta[src] * f0) * f1), covariates as seen by the op
-// (expand/analytical.rs:254,286; bindings.rs:98-117).  `base` = theta[src_param].
-__device__ __forceinline__ double apply_factors(const pmx_derived& dd, double base, const double* cov) {
+// derive: derived[d] = ((theta[src] * f0) * f1) (expand/analytical.rs:254,286; bindings.rs:98-117).  The factors
+// depend on the op's covariates only, not on the lane: the host evaluated them (pmx_compile.cpp op_fac); `fac` points
+// at this op's [n_derived][PMX_MAX_FACTORS] block, `d` = index of the derived value, `base` = theta[src_param].
+__device__ __forceinline__ double apply_factors(const DevModel& m, int d, double base, const double* __restrict__ fac) {
   double v = base;
 #pragma unroll
   for (int k = 0; k < PMX_MAX_FACTORS; ++k) {
-    if (k < dd.n_factors) {
-      const pmx_factor& f = dd.f[k];
-      const double cv = cov[f.cov];
-      const double fac = (f.op == PMX_F_POW) ? pow(cv / f.ref, f.coef) : (1.0 + f.coef * (cv - f.ref));
-      v = v * fac;
-    }
+    double f = 1.0;
+#pragma unroll
+    for (int dd = 0; dd < PMX_MAX_DERIVED; ++dd)
+      if (dd == d && k < m.derived[dd].n_factors) f = fac[dd * PMX_MAX_FACTORS + k];
+    v = v * f;
   }
   return v;
 }
@@ -100,19 +100,31 @@ __device__ __forceinline__ void lane_setup(const DevModel& m, const double* __re
   }
 }
 
-// PROP with covariate-derived kernel parameters: rebuild the coefficients for this op.
+// PROP with covariate-derived kernel parameters: this op's rate constants in the structure's native order.
 template <int KID>
-__device__ __forceinline__ bool lane_prepare_dyn(const DevModel& m, LaneModel<KID>& L, const double* cov) {
+__device__ __forceinline__ void lane_params_dyn(const DevModel& m, const LaneModel<KID>& L, const double* cov,
+                                                double (&q)[LaneModel<KID>::NKP]) {
   using LM = LaneModel<KID>;
-  double kp[LM::NKP], q[LM::NKP];
+  double kp[LM::NKP];
 #pragma unroll
   for (int j = 0; j < LM::NKP; ++j) {
     double v = L.kp_base[j];
-    if (m.bind[j].src == PMX_SRC_DERIVED) v = apply_factors(m.derived[m.bind[j].index], v, cov);
+    if (m.bind[j].src == PMX_SRC_DERIVED) v = apply_factors(m, m.bind[j].index, v, cov);
     kp[j] = v;
   }
   to_native_params<KID>(kp, q);
-  return LM::S::prepare(q, L.coef);
+}
+// ... and the segment's propagator applied (fused prepare + make, pmx_structures.hpp make_prop_dyn)
+template <int KID>
+__device__ __forceinline__ bool lane_advance_dyn(const DevModel& m, const LaneModel<KID>& L, const double* cov,
+                                                 double (&x)[LaneModel<KID>::NS], double dt, double r) {
+  using LM = LaneModel<KID>;
+  double q[LM::NKP];
+  lane_params_dyn<KID>(m, L, cov, q);
+  typename LM::S::Prop pr;
+  const bool ok = make_prop_dyn<LM::ST>(q, dt, pr);
+  LM::S::apply(pr, x, r);
+  return ok;
 }
 
 template <int KID>
@@ -135,7 +147,7 @@ __device__ __forceinline__ double lane_out(const DevModel& m, const LaneModel<KI
   }
   double xs = select_state<LM::NS>(x, state - m.pm);
   if (m.pm && state == 0) xs = xpad;
-  if (vsrc == PMX_SRC_DERIVED) return xs / apply_factors(m.derived[vidx], vbase, cov);
+  if (vsrc == PMX_SRC_DERIVED) return xs / apply_factors(m, vidx, vbase, cov);
   return xs * inv;
 }
 
@@ -258,16 +270,13 @@ __global__ __launch_bounds__(kBlock, (!LAG && LaneModel<KID>::NS <= 2) ? 4 : 1) 
       const uint32_t kind = meta & 0xffu;
       const int io = static_cast<int>((meta >> 8) & 0xffffu);
       const double a = c_op_a[o];
-      const double* cov = ops.op_cov + o * m.n_cov;
+      const double* cov = ops.op_fac + o * (m.n_derived * PMX_MAX_FACTORS);  // this op's covariate factors
       if (kind == OP_PROP) {
         const double r = c_op_b[o];
-        if constexpr (DYN) {
-          if (!lane_prepare_dyn<KID>(m, L, cov)) st = PMX_PAIR_COMPLEX_ROOTS;
-        }
         if constexpr (LAG) {
           lag_prop<LM::ST, NS>(m, ops, ls, c_op_t0[o], c_op_t1[o], r, L.coef, th, x);
         } else if constexpr (DYN) {
-          advance<LM::ST>(L.coef, x, a, r);
+          if (!lane_advance_dyn<KID>(m, L, cov, x, a, r)) st = PMX_PAIR_COMPLEX_ROOTS;
         } else {
           // exponential ladder (pmx_compile.cpp ladder_code): bits 27-29 relate this PROP's length to the previous one's
           const uint32_t rung = (meta >> 27) & 7u;
@@ -614,14 +623,13 @@ __global__ __launch_bounds__(kBlock) void pmx_analytical_pair(DevModel m, DevOps
     const uint32_t kind = meta & 0xffu;
     const int io = static_cast<int>((meta >> 8) & 0xffffu);
     const double a = ops.op_a[o];
-    const double* cov = ops.op_cov + o * m.n_cov;
+    const double* cov = ops.op_fac + o * (m.n_derived * PMX_MAX_FACTORS);  // this op's covariate factors
     if (kind == OP_PROP) {
       const double r = ops.op_b[o];
-      if constexpr (DYN) {
-        if (!lane_prepare_dyn<KID>(m, L, cov)) st = PMX_PAIR_COMPLEX_ROOTS;
-      }
       if constexpr (LAG) {
         lag_prop<LM::ST, NS>(m, ops, ls, ops.op_t0[o], ops.op_t1[o], r, L.coef, th, x);
+      } else if constexpr (DYN) {
+        if (!lane_advance_dyn<KID>(m, L, cov, x, a, r)) st = PMX_PAIR_COMPLEX_ROOTS;
       } else {
         advance<LM::ST>(L.coef, x, a, r);
       }

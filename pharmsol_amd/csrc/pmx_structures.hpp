@@ -270,8 +270,9 @@ struct ThreeCore {
   double l[3];
   double c[27];  // c[3*j + i]: row-major matrix entry j (0..8), eigenvalue i  == reference c_{3j+i+1}
   double d[9];   // d[3*row + i] = C_{row,1}^{(i)} / l_i        (infusion vector quotients)
-  // eigen-solve + coefficients: three_compartment_models.rs:24-77
-  __device__ __forceinline__ bool prepare(double k10, double k12, double k13, double k21, double k31) {
+  // the cubic's three real roots by the trigonometric method: three_compartment_models.rs:24-45
+  __device__ __forceinline__ static bool eigen(double k10, double k12, double k13, double k21, double k31,
+                                               double (&l)[3]) {
     const double a = k10 + k12 + k13 + k21 + k31;
     const double b = k10 * k21 + k13 * k21 + k10 * k31 + k12 * k31 + k21 * k31;
     const double cc = k10 * k21 * k31;
@@ -290,6 +291,14 @@ struct ThreeCore {
     l[0] = a / 3.0 + cr * (cs + rt3 * sn);
     l[1] = a / 3.0 + cr * (cs - rt3 * sn);
     l[2] = a / 3.0 - (2.0 * cr * cs);
+    return ok;
+  }
+  // eigen-solve + coefficients: three_compartment_models.rs:24-77
+  __device__ __forceinline__ bool prepare(double k10, double k12, double k13, double k21, double k31) {
+    const bool ok = eigen(k10, k12, k13, k21, k31, l);
+    return prepare_tables(k10, k12, k13, k21, k31) && ok;
+  }
+  __device__ __forceinline__ bool prepare_tables(double k10, double k12, double k13, double k21, double k31) {
     const double K = k10 + k12 + k13;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -311,7 +320,7 @@ struct ThreeCore {
       d[1 * 3 + i] = c[3 * 3 + i] * il;
       d[2 * 3 + i] = c[6 * 3 + i] * il;
     }
-    return ok;
+    return true;
   }
 };
 struct ThreeProp {
@@ -324,6 +333,60 @@ struct ThreeProp {
     for (int k = 0; k < 3; ++k) j[k] = o0 * t.d[3 * k] + o1 * t.d[3 * k + 1] + o2 * t.d[3 * k + 2];
   }
 };
+
+// Fused prepare + make for lanes whose rate constants change with EVERY segment (covariate-derived parameters):
+// one pass over the three eigenvalues that accumulates the transition matrix, the infusion response and (ABS) the
+// absorption vector directly, never holding the 27 + 9 (+ 9) coefficient tables (the tabled form needs 255 VGPRs
+// and runs one wave per SIMD).  Same terms as ThreeCore::prepare_tables + ThreeProp::make, summed in the same
+// eigenvalue order.
+template <bool ABS>
+__device__ __forceinline__ bool three_direct(double k10, double k12, double k13, double k21, double k31, double ka,
+                                             double dt, ThreeProp& p, double& ea, double (&g)[3]) {
+  double l[3];
+  const bool ok = ThreeCore::eigen(k10, k12, k13, k21, k31, l);
+  const double K = k10 + k12 + k13;
+  if constexpr (ABS) ea = exp(-ka * dt);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) p.m[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    p.j[k] = 0.0;
+    g[k] = 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double li = l[i];
+    const double lo1 = l[(i + 1) % 3], lo2 = l[(i + 2) % 3];
+    const double inv = 1.0 / ((lo1 - li) * (lo2 - li));
+    const double u = k21 - li, v = k31 - li, w = K - li;
+    const double e = exp(-(li * dt));
+    const double c0 = u * v * inv, c3 = k12 * v * inv, c6 = k13 * u * inv;
+    p.m[0] = fma(c0, e, p.m[0]);
+    p.m[1] = fma(k21 * v * inv, e, p.m[1]);
+    p.m[2] = fma(k31 * u * inv, e, p.m[2]);
+    p.m[3] = fma(c3, e, p.m[3]);
+    p.m[4] = fma((w * v - k13 * k31) * inv, e, p.m[4]);
+    p.m[5] = fma(k12 * k31 * inv, e, p.m[5]);
+    p.m[6] = fma(c6, e, p.m[6]);
+    p.m[7] = fma(k21 * k13 * inv, e, p.m[7]);
+    p.m[8] = fma((w * u - k12 * k21) * inv, e, p.m[8]);
+    const double o = (1.0 - e) * (1.0 / li);
+    p.j[0] = fma(c0, o, p.j[0]);
+    p.j[1] = fma(c3, o, p.j[1]);
+    p.j[2] = fma(c6, o, p.j[2]);
+    if constexpr (ABS) {
+      const double q = (e - ea) * (1.0 / (ka - li));
+      g[0] = fma(c0, q, g[0]);
+      g[1] = fma(c3, q, g[1]);
+      g[2] = fma(c6, q, g[2]);
+    }
+  }
+  if constexpr (ABS) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) g[k] *= ka;
+  }
+  return ok;
+}
 
 template <>
 struct Structure<S_THREE> {
@@ -343,6 +406,10 @@ struct Structure<S_THREE> {
     for (int i = 0; i < 3; ++i) e[i] = exp(-(c.t.l[i] * dt));
   }
   __device__ __forceinline__ static void from_exps(const Coef& c, const double (&e)[NE], Prop& p) { p.p.make(c.t, e); }
+  __device__ __forceinline__ static bool make_prop_dyn(const double* kp, double dt, Prop& p) {
+    double ea_unused, g_unused[3];
+    return three_direct<false>(kp[0], kp[1], kp[2], kp[3], kp[4], 0.0, dt, p.p, ea_unused, g_unused);
+  }
   __device__ __forceinline__ static void apply(const Prop& q, double (&x)[NS], double r) {
     const ThreeProp& p = q.p;
     const double y0 = p.m[0] * x[0] + p.m[1] * x[1] + p.m[2] * x[2] + p.j[0] * r;
@@ -392,6 +459,9 @@ struct Structure<S_THREE_ABS> {
 #pragma unroll
     for (int k = 0; k < 3; ++k) p.g[k] = (d0 * c.f[3 * k] + d1 * c.f[3 * k + 1] + d2 * c.f[3 * k + 2]) * c.ka;  // (:230)
   }
+  __device__ __forceinline__ static bool make_prop_dyn(const double* kp, double dt, Prop& p) {
+    return three_direct<true>(kp[1], kp[2], kp[3], kp[4], kp[5], kp[0], dt, p.p, p.ea, p.g);
+  }
   __device__ __forceinline__ static void apply(const Prop& q, double (&x)[NS], double r) {
     const ThreeProp& p = q.p;
     const double g = x[0];
@@ -424,6 +494,20 @@ __device__ __forceinline__ void ladder_pow(double (&e)[NE], uint32_t n) {
     const double b = e[i];
     const double sq = b * b;
     e[i] = (n == 2u) ? sq : ((n == 3u) ? sq * b : sq * sq);
+  }
+}
+
+// covariate-derived rate constants: prepare + make for ONE segment.  Structures with a fused form provide
+// make_prop_dyn; the others go through their Coef.
+template <int ST>
+__device__ __forceinline__ bool make_prop_dyn(const double* kp, double dt, typename Structure<ST>::Prop& p) {
+  if constexpr (ST == S_THREE || ST == S_THREE_ABS) {
+    return Structure<ST>::make_prop_dyn(kp, dt, p);
+  } else {
+    typename Structure<ST>::Coef c;
+    const bool ok = Structure<ST>::prepare(kp, c);
+    make_prop<ST>(c, dt, p);
+    return ok;
   }
 }
 
