@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--no-status", action="store_true", help="do not write the per-pair status bytes")
     ap.add_argument("--loglik", action="store_true",
                     help="time the fused log-likelihood entry (pmx_loglik_device) instead of predictions: output S x P")
+    ap.add_argument("--ragged", action="store_true",
+                    help="C3 with per-subject jittered sampling times (no shared design, no related step lengths)")
     ap.add_argument("--ld", type=int, default=0, help="leading dimension of the prediction rows (>= support points; 0 = dense)")
     ap.add_argument("--no-class", action="store_true",
                     help="A/B: disable the classed kernel (shared-design propagator reuse); every subject walks the generic kernel")
@@ -101,7 +103,7 @@ def main():
             S_local, P = 10_000, 1
         model = synth.model_two_cpt_iv()
         theta = synth.theta_c3(P) if args.workload == "c3" else synth.theta_c2()
-        flat_global = synth.population_c23(S_local * world)
+        flat_global = synth.population_c23(S_local * world, ragged=args.ragged)
         label = f"C{'3' if args.workload == 'c3' else '2'}: two_compartments analytical, {S_local} subjects/GPU x {P} support points, 8 events/subject"
         dtype_tol = 1e-6
     elif args.workload == "c4":

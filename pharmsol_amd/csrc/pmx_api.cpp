@@ -430,7 +430,9 @@ int32_t get_stream(pmx_population* pop, const pmx::CompileKey& key, DeviceStream
   ds->dev.n_rate = key.n_rate;
   if (key.class_g > 0) {
     pmx::ClassPlan cp;
-    pmx::build_class_plan(pop->hp, os, key.class_g, key.class_g / 2, &cp, key.ladder);
+    int32_t min_class = key.class_g / 2;
+    if (const char* e = std::getenv("PMX_TUNE_MIN_CLASS")) min_class = std::atoi(e) > 0 ? std::atoi(e) : min_class;  // tuning experiments
+    pmx::build_class_plan(pop->hp, os, key.class_g, min_class, &cp, key.ladder);
     if (cp.n_chunks > 0) {
       if ((rc = upload(cp.prog_meta, &ds->cls.prog_meta, &ds->allocs)) != PMX_OK) return rc;
       if ((rc = upload(cp.prog_dt, &ds->cls.prog_dt, &ds->allocs)) != PMX_OK) return rc;

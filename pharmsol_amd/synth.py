@@ -73,12 +73,18 @@ def model_three_cpt_abs_wt(cov_time: str = "segment_dt"):
 _C23_OBS_T = np.array([0.5, 1.0, 2.0, 4.0, 8.0, 12.0, 24.0])
 
 
-def population_c23(n_subjects: int) -> FlatPopulation:
-    """C2/C3 schedule: infusion(t=0, amt=500*(1+0.001*(s mod 1000)), dur=0.5) + 7 missing observations."""
+def population_c23(n_subjects: int, ragged: bool = False) -> FlatPopulation:
+    """C2/C3 schedule: infusion(t=0, amt=500*(1+0.001*(s mod 1000)), dur=0.5) + 7 missing observations.
+    ``ragged``: every subject's sampling times are jittered by up to +-10 % (a clinical dataset with recorded
+    times instead of protocol times): no two subjects share a design, no step is a multiple of another."""
     S = n_subjects
     E = 8
     s = np.arange(S)
     t = np.tile(np.concatenate([[0.0], _C23_OBS_T]), S)
+    if ragged:
+        jit = 1.0 + 0.2 * (SplitMix64(SEED ^ 0x7A66).uniform(S * E) - 0.5)
+        jit[0::E] = 1.0
+        t = t * jit
     v = np.full(S * E, np.nan)
     v[0::E] = 500.0 * (1.0 + 0.001 * (s % 1000))
     dur = np.zeros(S * E)
