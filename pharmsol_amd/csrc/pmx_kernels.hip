@@ -531,14 +531,22 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
         if constexpr (LL) {
           // fold the G predictions into the members' sums instead of storing them (ll_accumulate, per member;
           // the observed values and sigma terms are wave-uniform scalar fetches)
+          // the step's 3 x G scalars are fetched unconditionally and up front (a few wide s_loads instead of 3 G
+          // dependent ones behind the weight test: the kernel was scalar-fetch-latency bound)
           const auto ov = as_const(cp.cobs) + cobs_off;
+          double ov_y[G], ov_c[G], ov_w[G];
 #pragma unroll
           for (int j = 0; j < G; ++j) {
-            const double w = ov[2 * G + j];
-            if (w != 0.0) {  // wave-uniform; weight 0 = missing observation (or chunk padding)
+            ov_y[j] = ov[j];
+            ov_c[j] = ov[G + j];
+            ov_w[j] = ov[2 * G + j];
+          }
+#pragma unroll
+          for (int j = 0; j < G; ++j) {
+            if (ov_w[j] != 0.0) {  // wave-uniform; weight 0 = missing observation (or chunk padding)
               const double y = select_state<NS>(x[j], out_state) * inv_vol;
-              const double d = ov[j] - y;
-              ll_acc[j] += ov[G + j] - (d * d) * w;
+              const double d = ov_y[j] - y;
+              ll_acc[j] += ov_c[j] - (d * d) * ov_w[j];
             }
           }
           cobs_off += 3 * G;
