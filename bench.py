@@ -100,7 +100,7 @@ def main():
     batch = False
     if args.workload in ("c3", "c2"):
         if args.workload == "c2":
-            S_local, P = 10_000, 1
+            S_local, P = (10_000 if args.subjects == 100_000 else args.subjects), 1
         model = synth.model_two_cpt_iv()
         theta = synth.theta_c3(P) if args.workload == "c3" else synth.theta_c2()
         flat_global = synth.population_c23(S_local * world, ragged=args.ragged)

@@ -320,9 +320,11 @@ typedef struct pmx_error_model {
  *                                const double* rateiv, const double* derived, double* x);    // iff has_init
  *
  * `rateiv[i]` is the active infusion rate of input i (the body adds it where the route goes, like a hand-written
- * closure), `p` the support point in model order; `cov` and `derived` are NULL in this build (covariates are not
- * available to custom bodies yet).  desc: eq_kind = PMX_EQ_ODE, kernel = PMX_ODE_CUSTOM, nstates/ndrugs/nout/
- * nparams, rk4_h_max, lag_param/fa_param/bolus_dest as for built-in models; `out[]` is ignored.  The source is
+ * closure), `p` the support point in model order, `cov[c]` covariate c of the subject's current occasion
+ * interpolated at `t` (every stage of every step, like `fetch_cov!(cov, t, ..)`; NULL when n_covariates = 0);
+ * `derived` is NULL (compute derived values in the body).  desc: eq_kind = PMX_EQ_ODE, kernel = PMX_ODE_CUSTOM,
+ * nstates/ndrugs/nout/nparams/n_covariates, rk4_h_max, ode_solver, lag_param/fa_param/bolus_dest as for built-in
+ * models; `out[]` is ignored.  The source is
  * compiled for gfx950 at creation time (no device needed; PMX_ERR_INVALID_ARGUMENT + the compiler log in
  * pmx_last_error() on a compile error) and runs through the same walkers, RK4 stepper, lag/fa handling and fused
  * log-likelihood as the built-in bodies. */

@@ -542,6 +542,12 @@ static void model_seq_eq(const ctx_t* c, double* pv, double t) {
   if (c->m->kernel == PMX_ORACLE_K_TEST_SEQ_ACCUM) pv[0] += 1.0; /* analytical/mod.rs:499-501 */
 }
 
+/* covariates of the current occasion at time t (fetch_cov!, src/lib.rs:433-443); NaN where interpolation fails */
+static void cov_values(const ctx_t* c, double t, double* cv) {
+  for (int i = 0; i < c->m->n_covariates; i++)
+    if (cov_interp(&c->cov[i], t, &cv[i])) cv[i] = NAN;
+}
+
 /* User bodies of a PMX_ODE_CUSTOM model (the closures of ODE::new, ode/mod.rs:115-132), argument order of the
  * reference's compiled kernels (src/dsl/native.rs:45-53).  Registered by the test harness, which builds the very
  * source text the device compiles with gcc (oracle/__init__.py compile_custom). */
@@ -559,7 +565,9 @@ void pmx_oracle_set_custom(void* dynamics, void* outputs, void* init) {
 static int model_out(const ctx_t* c, const double* x, const double* theta, double t_obs, double* y) {
   const pmx_model_desc* m = c->m;
   if (m->eq_kind == PMX_EQ_ODE && m->kernel == PMX_ODE_CUSTOM) {
-    g_custom_outputs(t_obs, x, theta, 0, 0, 0, y); /* y zeroed by the caller */
+    double cv[PMX_MAX_COVARIATES];
+    cov_values(c, t_obs, cv);
+    g_custom_outputs(t_obs, x, theta, m->n_covariates ? cv : 0, 0, 0, y); /* y zeroed by the caller */
     return 0;
   }
   double derived[PMX_MAX_DERIVED];
@@ -695,10 +703,13 @@ static void ode_rhs(int model, const double* x, const double* p, double* dx) {
 
 /* PmRhs::call_inplace (closure.rs:344-357) + the ode! route injection
  * dx[dest] += rateiv[i] (expand/ode.rs:380-406). */
-static void ode_f(const pmx_model_desc* m, double t, const double* x, const double* p, const double* rate, double* dx) {
+static void ode_f(const ctx_t* c, double t, const double* x, const double* p, const double* rate, double* dx) {
+  const pmx_model_desc* m = c->m;
   if (m->kernel == PMX_ODE_CUSTOM) { /* the body adds rateiv itself, like a hand-written closure */
+    double cv[PMX_MAX_COVARIATES];
+    cov_values(c, t, cv);
     for (int i = 0; i < m->nstates; i++) dx[i] = 0.0;
-    g_custom_dynamics(t, x, p, 0, rate, 0, dx);
+    g_custom_dynamics(t, x, p, m->n_covariates ? cv : 0, rate, 0, dx);
     return;
   }
   ode_rhs(m->kernel, x, p, dx);
@@ -711,7 +722,8 @@ static void ode_f(const pmx_model_desc* m, double t, const double* x, const doub
 }
 
 /* One constant-rate piece [t0, t1] with n = ceil((t1-t0)/h_max) classic RK4 steps. */
-static void rk4_piece(const pmx_model_desc* m, double* x, const double* p, const double* rate, double t0, double t1) {
+static void rk4_piece(const ctx_t* c, double* x, const double* p, const double* rate, double t0, double t1) {
+  const pmx_model_desc* m = c->m;
   double dt = t1 - t0;
   if (!(dt > 0.0)) return;
   double nf = ceil(dt / m->rk4_h_max);
@@ -722,43 +734,44 @@ static void rk4_piece(const pmx_model_desc* m, double* x, const double* p, const
   double k1[PMX_MAX_STATES], k2[PMX_MAX_STATES], k3[PMX_MAX_STATES], k4[PMX_MAX_STATES], xt[PMX_MAX_STATES];
   for (int64_t s = 0; s < n; s++) {
     double t = t0 + (double)s * h; /* stage times t, t + h/2, t + h/2, t + h */
-    ode_f(m, t, x, p, rate, k1);
+    ode_f(c, t, x, p, rate, k1);
     for (int i = 0; i < ns; i++) xt[i] = x[i] + (0.5 * h) * k1[i];
-    ode_f(m, t + 0.5 * h, xt, p, rate, k2);
+    ode_f(c, t + 0.5 * h, xt, p, rate, k2);
     for (int i = 0; i < ns; i++) xt[i] = x[i] + (0.5 * h) * k2[i];
-    ode_f(m, t + 0.5 * h, xt, p, rate, k3);
+    ode_f(c, t + 0.5 * h, xt, p, rate, k3);
     for (int i = 0; i < ns; i++) xt[i] = x[i] + h * k3[i];
-    ode_f(m, t + h, xt, p, rate, k4);
+    ode_f(c, t + h, xt, p, rate, k4);
     for (int i = 0; i < ns; i++) x[i] = x[i] + (h / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
   }
 }
 
 /* ---- PMX_SOLVER_DOPRI5: Dormand-Prince 5(4) with step-size control (the build's stand-in for the reference's
  * adaptive diffsol solvers; same rule set as pmx_ode.hpp dopri5_try / dopri5_advance). ---------------------- */
-static double dopri5_try(const pmx_model_desc* m, const double* x, const double* p, const double* rate, double t, double h,
+static double dopri5_try(const ctx_t* c, const double* x, const double* p, const double* rate, double t, double h,
                          double* xn) {
+  const pmx_model_desc* m = c->m;
   int ns = m->nstates;
   double k1[PMX_MAX_STATES], k2[PMX_MAX_STATES], k3[PMX_MAX_STATES], k4[PMX_MAX_STATES], k5[PMX_MAX_STATES],
       k6[PMX_MAX_STATES], k7[PMX_MAX_STATES], xt[PMX_MAX_STATES];
-  ode_f(m, t, x, p, rate, k1);
+  ode_f(c, t, x, p, rate, k1);
   for (int i = 0; i < ns; i++) xt[i] = x[i] + h * (0.2 * k1[i]);
-  ode_f(m, t + 0.2 * h, xt, p, rate, k2);
+  ode_f(c, t + 0.2 * h, xt, p, rate, k2);
   for (int i = 0; i < ns; i++) xt[i] = x[i] + h * ((3.0 / 40.0) * k1[i] + (9.0 / 40.0) * k2[i]);
-  ode_f(m, t + 0.3 * h, xt, p, rate, k3);
+  ode_f(c, t + 0.3 * h, xt, p, rate, k3);
   for (int i = 0; i < ns; i++) xt[i] = x[i] + h * ((44.0 / 45.0) * k1[i] - (56.0 / 15.0) * k2[i] + (32.0 / 9.0) * k3[i]);
-  ode_f(m, t + 0.8 * h, xt, p, rate, k4);
+  ode_f(c, t + 0.8 * h, xt, p, rate, k4);
   for (int i = 0; i < ns; i++)
     xt[i] = x[i] + h * ((19372.0 / 6561.0) * k1[i] - (25360.0 / 2187.0) * k2[i] + (64448.0 / 6561.0) * k3[i] -
                         (212.0 / 729.0) * k4[i]);
-  ode_f(m, t + (8.0 / 9.0) * h, xt, p, rate, k5);
+  ode_f(c, t + (8.0 / 9.0) * h, xt, p, rate, k5);
   for (int i = 0; i < ns; i++)
     xt[i] = x[i] + h * ((9017.0 / 3168.0) * k1[i] - (355.0 / 33.0) * k2[i] + (46732.0 / 5247.0) * k3[i] +
                         (49.0 / 176.0) * k4[i] - (5103.0 / 18656.0) * k5[i]);
-  ode_f(m, t + h, xt, p, rate, k6);
+  ode_f(c, t + h, xt, p, rate, k6);
   for (int i = 0; i < ns; i++)
     xn[i] = x[i] + h * ((35.0 / 384.0) * k1[i] + (500.0 / 1113.0) * k3[i] + (125.0 / 192.0) * k4[i] -
                         (2187.0 / 6784.0) * k5[i] + (11.0 / 84.0) * k6[i]);
-  ode_f(m, t + h, xn, p, rate, k7);
+  ode_f(c, t + h, xn, p, rate, k7);
   double acc = 0.0;
   for (int i = 0; i < ns; i++) {
     double e = h * ((71.0 / 57600.0) * k1[i] - (71.0 / 16695.0) * k3[i] + (71.0 / 1920.0) * k4[i] -
@@ -775,8 +788,9 @@ typedef struct {
   int failed;
 } adapt_t;
 
-static void dopri5_piece(const pmx_model_desc* m, double* x, const double* p, const double* rate, double t0, double t1,
+static void dopri5_piece(const ctx_t* c, double* x, const double* p, const double* rate, double t0, double t1,
                          adapt_t* as) {
+  const pmx_model_desc* m = c->m;
   double t = t0;
   for (int64_t guard = 0; guard < 10000000; guard++) {
     double left = t1 - t;
@@ -785,7 +799,7 @@ static void dopri5_piece(const pmx_model_desc* m, double* x, const double* p, co
     int clipped = h >= left;
     if (clipped) h = left;
     double xn[PMX_MAX_STATES];
-    double err = dopri5_try(m, x, p, rate, t, h, xn);
+    double err = dopri5_try(c, x, p, rate, t, h, xn);
     int ok = err <= 1.0;
     double fac = (err > 0.0) ? 0.9 * pow(err, -0.2) : 5.0;
     if (!(fac >= 0.2)) fac = 0.2;
@@ -839,7 +853,11 @@ static int simulate_pair(const pmx_model_desc* m, const pmx_population_desc* pop
     if (occ_index == 0) {
       for (int i = 0; i < m->nstates; i++)
         if (m->init_param[i] >= 0) x[i] = theta[m->init_param[i]];
-      if (m->eq_kind == PMX_EQ_ODE && m->kernel == PMX_ODE_CUSTOM && g_custom_init) g_custom_init(0.0, x, theta, 0, 0, 0, x);
+      if (m->eq_kind == PMX_EQ_ODE && m->kernel == PMX_ODE_CUSTOM && g_custom_init) {
+        double cv[PMX_MAX_COVARIATES];
+        cov_values(&ctx, 0.0, cv);
+        g_custom_init(0.0, x, theta, m->n_covariates ? cv : 0, 0, 0, x);
+      }
     }
     /* resolve_occasion_events: clone + process_events (equation/mod.rs:247-273, structs.rs:681-690) */
     int64_t e0 = pop->occ_ev_off[oc], e1 = pop->occ_ev_off[oc + 1];
@@ -974,9 +992,9 @@ static int simulate_pair(const pmx_model_desc* m, const pmx_population_desc* pop
               if (s <= t && t < en) rate[sc->inf[k].input] += sc->inf[k].amount / sc->inf[k].duration;
             }
             if (m->ode_solver == PMX_SOLVER_DOPRI5)
-              dopri5_piece(m, x, theta, rate, t, stop, &adapt);
+              dopri5_piece(&ctx, x, theta, rate, t, stop, &adapt);
             else
-              rk4_piece(m, x, theta, rate, t, stop);
+              rk4_piece(&ctx, x, theta, rate, t, stop);
             t = stop;
           }
         }

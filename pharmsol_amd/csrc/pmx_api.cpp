@@ -294,8 +294,10 @@ int32_t check_custom_desc(const pmx_model_desc* d, const char* source) {
     return fail(PMX_ERR_INVALID_ARGUMENT, "unknown ode_solver");
   if (d->ode_solver == PMX_SOLVER_DOPRI5 && !(d->ode_rtol > 0.0 && d->ode_atol > 0.0))
     return fail(PMX_ERR_INVALID_ARGUMENT, "the adaptive solver needs ode_rtol > 0 and ode_atol > 0");
-  if (d->n_covariates != 0 || d->n_derived != 0 || d->n_bind != 0 || d->pmetrics_indexing)
-    return fail(PMX_ERR_UNSUPPORTED, "covariates / derived parameters / pm indexing are not available to custom ODE bodies yet");
+  if (d->n_covariates < 0 || d->n_covariates > PMX_MAX_COVARIATES)
+    return fail(PMX_ERR_INVALID_ARGUMENT, "n_covariates out of range");
+  if (d->n_derived != 0 || d->n_bind != 0 || d->pmetrics_indexing)
+    return fail(PMX_ERR_UNSUPPORTED, "derived-parameter descriptors / pm indexing do not apply to custom ODE bodies (compute them in the body)");
   int n_lag = 0;
   for (int i = 0; i < PMX_MAX_INPUTS; ++i) {
     if (d->lag_param[i] >= d->nparams || d->fa_param[i] >= d->nparams)
@@ -313,6 +315,7 @@ pmx::JitSpec spec_of(const pmx_model_desc* d, const char* source, int32_t has_in
   sp.nout = d->nout;
   sp.ninputs = d->ndrugs > 0 ? d->ndrugs : 1;
   sp.has_init = has_init != 0;
+  sp.ncov = d->n_covariates;
   sp.source = source;
   return sp;
 }
@@ -428,6 +431,18 @@ int32_t get_stream(pmx_population* pop, const pmx::CompileKey& key, DeviceStream
   if ((rc = upload(os.lagb_time, &ds->dev.lagb_time, &ds->allocs)) != PMX_OK) return rc;
   if ((rc = upload(os.lagb_amount, &ds->dev.lagb_amount, &ds->allocs)) != PMX_OK) return rc;
   ds->dev.n_rate = key.n_rate;
+  ds->dev.n_cov = 0;
+  if (key.eq_kind == PMX_EQ_ODE && pop->hp.n_cov > 0) {  // covariate segments for bodies that read them at stage times
+    const auto& hp = pop->hp;
+    ds->dev.n_cov = hp.n_cov;
+    if ((rc = upload(hp.cov_seg_off, &ds->dev.cov_seg_off, &ds->allocs)) != PMX_OK) return rc;
+    if ((rc = upload(hp.seg_from, &ds->dev.seg_from, &ds->allocs)) != PMX_OK) return rc;
+    if ((rc = upload(hp.seg_to, &ds->dev.seg_to, &ds->allocs)) != PMX_OK) return rc;
+    if ((rc = upload(hp.seg_slope, &ds->dev.seg_slope, &ds->allocs)) != PMX_OK) return rc;
+    if ((rc = upload(hp.seg_icpt, &ds->dev.seg_icpt, &ds->allocs)) != PMX_OK) return rc;
+    if ((rc = upload(hp.cov_first_t, &ds->dev.cov_first_t, &ds->allocs)) != PMX_OK) return rc;
+    if ((rc = upload(hp.cov_first_v, &ds->dev.cov_first_v, &ds->allocs)) != PMX_OK) return rc;
+  }
   if (key.class_g > 0) {
     pmx::ClassPlan cp;
     int32_t min_class = key.class_g / 2;

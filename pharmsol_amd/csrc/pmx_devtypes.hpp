@@ -59,7 +59,15 @@ struct DevOps {
   double* ll_out;               // [n_subjects x ll_ld]
   int64_t ll_ld;
   int32_t n_rate;
-  int32_t pad_;
+  int32_t n_cov;                // covariates per occasion (the segment tables below; custom ODE bodies read them)
+  // covariate segments of every (occasion, covariate) cell, as HostPopulation holds them (covariate.rs:189-214)
+  const int64_t* cov_seg_off;   // [n_occasions*n_cov + 1]
+  const double* seg_from;
+  const double* seg_to;
+  const double* seg_slope;      // NaN = carry-forward segment
+  const double* seg_icpt;
+  const double* cov_first_t;    // [n_occasions*n_cov]
+  const double* cov_first_v;
 };
 
 }  // namespace pmx

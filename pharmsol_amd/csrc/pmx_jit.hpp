@@ -10,7 +10,7 @@
 namespace pmx {
 
 struct JitSpec {
-  int32_t nstates = 1, nparams = 1, nout = 1, ninputs = 1;
+  int32_t nstates = 1, nparams = 1, nout = 1, ninputs = 1, ncov = 0;
   bool has_init = false;
   std::string source;  // definitions of pmx_dynamics / pmx_outputs (/ pmx_init), see include/pmx.h
 };

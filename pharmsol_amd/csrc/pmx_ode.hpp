@@ -11,18 +11,54 @@ namespace {
 // ------------------------------------------------------------------------------------
 // ODE: built-in diffeq bodies + classic RK4 (fixed step per constant-rate piece)
 // ------------------------------------------------------------------------------------
+// Everything a lane needs besides its state.  `ops` / `occ` let a custom body read its covariates at any time t
+// (device-side Covariate::interpolate over the occasion's segments, covariate.rs:216-241).
+template <class M>
+struct OdeLane {
+  double kp[M::NP];
+  double inv_vol[PMX_MAX_OUT];
+  double xinit[M::NS];
+  const DevOps* ops;
+  int64_t occ;  // global occasion index of the occasion being walked
+};
+
+// Covariate c of occasion `occ` at time t: first segment with from <= t < to (linear: slope * t + intercept, two
+// roundings like the reference; carry-forward: the stored value); before the first observation its value; the last
+// segment is open-ended.  NaN when nothing matches (the reference's MissingSegments error).
+__device__ __forceinline__ double cov_at(const DevOps& ops, int64_t occ, int c, double t) {
+  const int64_t cell = occ * ops.n_cov + c;
+  const int64_t s0 = ops.cov_seg_off[cell], s1 = ops.cov_seg_off[cell + 1];
+  if (t < ops.cov_first_t[cell]) return ops.cov_first_v[cell];
+  double v = __longlong_as_double(0x7ff8000000000000LL);
+  for (int64_t sg = s0; sg < s1; ++sg) {
+    if (ops.seg_from[sg] <= t && t < ops.seg_to[sg]) {
+      const double sl = ops.seg_slope[sg], ic = ops.seg_icpt[sg];
+      v = (sl != sl) ? ic : __dadd_rn(__dmul_rn(sl, t), ic);
+      break;
+    }
+  }
+  return v;
+}
+
 // Model policy M (a built-in diffeq body below, or the wrapper pmx_jit.cpp generates around a user's source):
 //   NS, NP, CENTRAL, CUSTOM, NR (length of the rate vector: NS per-state rates for built-ins, the model's inputs
 //   for custom bodies, which add rateiv themselves like a hand-written ODE::new closure)
 //   built-in:  rhs(p, x, dx)                       autonomous; the walker adds the per-state rates
 //   custom:    rhs(t, p, x, rateiv, dx), out(t, p, x, y), init(p, x); NOUT, HAS_INIT
 template <class M>
-__device__ __forceinline__ void ode_eval(double t, const double* kp, const double (&x)[M::NS], const double (&rs)[M::NR],
+__device__ __forceinline__ void ode_eval(double t, const OdeLane<M>& L, const double (&x)[M::NS], const double (&rs)[M::NR],
                                          double (&dx)[M::NS]) {
   if constexpr (M::CUSTOM) {
-    M::rhs(t, kp, x, rs, dx);
+    if constexpr (M::NCOV > 0) {
+      double cov[M::NCOV];
+#pragma unroll
+      for (int c = 0; c < M::NCOV; ++c) cov[c] = cov_at(*L.ops, L.occ, c, t);
+      M::rhs(t, L.kp, x, rs, cov, dx);
+    } else {
+      M::rhs(t, L.kp, x, rs, nullptr, dx);
+    }
   } else {
-    M::rhs(kp, x, dx);
+    M::rhs(L.kp, x, dx);
 #pragma unroll
     for (int i = 0; i < M::NS; ++i) dx[i] += rs[i];
   }
@@ -30,20 +66,20 @@ __device__ __forceinline__ void ode_eval(double t, const double* kp, const doubl
 
 // one classic RK4 step from t to t + h (rs constant over the piece)
 template <class M>
-__device__ __forceinline__ void rk4_step(const double* kp, double (&x)[M::NS], const double (&rs)[M::NR], double t,
+__device__ __forceinline__ void rk4_step(const OdeLane<M>& L, double (&x)[M::NS], const double (&rs)[M::NR], double t,
                                          double h) {
   constexpr int NS = M::NS;
   double k1[NS], k2[NS], k3[NS], k4[NS], xt[NS];
-  ode_eval<M>(t, kp, x, rs, k1);
+  ode_eval<M>(t, L, x, rs, k1);
 #pragma unroll
   for (int i = 0; i < NS; ++i) xt[i] = x[i] + (0.5 * h) * k1[i];
-  ode_eval<M>(t + 0.5 * h, kp, xt, rs, k2);
+  ode_eval<M>(t + 0.5 * h, L, xt, rs, k2);
 #pragma unroll
   for (int i = 0; i < NS; ++i) xt[i] = x[i] + (0.5 * h) * k2[i];
-  ode_eval<M>(t + 0.5 * h, kp, xt, rs, k3);
+  ode_eval<M>(t + 0.5 * h, L, xt, rs, k3);
 #pragma unroll
   for (int i = 0; i < NS; ++i) xt[i] = x[i] + h * k3[i];
-  ode_eval<M>(t + h, kp, xt, rs, k4);
+  ode_eval<M>(t + h, L, xt, rs, k4);
 #pragma unroll
   for (int i = 0; i < NS; ++i) x[i] = x[i] + (h / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
 }
@@ -52,35 +88,35 @@ __device__ __forceinline__ void rk4_step(const double* kp, double (&x)[M::NS], c
 // One ATTEMPTED step of length h from (t, x): fills xn with the 5th-order solution and returns the scaled error
 // norm rms(e_i / (atol + rtol max(|x_i|, |xn_i|))); the step is acceptable iff the result is <= 1.
 template <class M>
-__device__ __forceinline__ double dopri5_try(const DevModel& m, const double* kp, const double (&x)[M::NS],
+__device__ __forceinline__ double dopri5_try(const DevModel& m, const OdeLane<M>& L, const double (&x)[M::NS],
                                              const double (&rs)[M::NR], double t, double h, double (&xn)[M::NS]) {
   constexpr int NS = M::NS;
   double k1[NS], k2[NS], k3[NS], k4[NS], k5[NS], k6[NS], k7[NS], xt[NS];
-  ode_eval<M>(t, kp, x, rs, k1);
+  ode_eval<M>(t, L, x, rs, k1);
 #pragma unroll
   for (int i = 0; i < NS; ++i) xt[i] = x[i] + h * (0.2 * k1[i]);
-  ode_eval<M>(t + 0.2 * h, kp, xt, rs, k2);
+  ode_eval<M>(t + 0.2 * h, L, xt, rs, k2);
 #pragma unroll
   for (int i = 0; i < NS; ++i) xt[i] = x[i] + h * ((3.0 / 40.0) * k1[i] + (9.0 / 40.0) * k2[i]);
-  ode_eval<M>(t + 0.3 * h, kp, xt, rs, k3);
+  ode_eval<M>(t + 0.3 * h, L, xt, rs, k3);
 #pragma unroll
   for (int i = 0; i < NS; ++i) xt[i] = x[i] + h * ((44.0 / 45.0) * k1[i] - (56.0 / 15.0) * k2[i] + (32.0 / 9.0) * k3[i]);
-  ode_eval<M>(t + 0.8 * h, kp, xt, rs, k4);
+  ode_eval<M>(t + 0.8 * h, L, xt, rs, k4);
 #pragma unroll
   for (int i = 0; i < NS; ++i)
     xt[i] = x[i] + h * ((19372.0 / 6561.0) * k1[i] - (25360.0 / 2187.0) * k2[i] + (64448.0 / 6561.0) * k3[i] -
                         (212.0 / 729.0) * k4[i]);
-  ode_eval<M>(t + (8.0 / 9.0) * h, kp, xt, rs, k5);
+  ode_eval<M>(t + (8.0 / 9.0) * h, L, xt, rs, k5);
 #pragma unroll
   for (int i = 0; i < NS; ++i)
     xt[i] = x[i] + h * ((9017.0 / 3168.0) * k1[i] - (355.0 / 33.0) * k2[i] + (46732.0 / 5247.0) * k3[i] +
                         (49.0 / 176.0) * k4[i] - (5103.0 / 18656.0) * k5[i]);
-  ode_eval<M>(t + h, kp, xt, rs, k6);
+  ode_eval<M>(t + h, L, xt, rs, k6);
 #pragma unroll
   for (int i = 0; i < NS; ++i)
     xn[i] = x[i] + h * ((35.0 / 384.0) * k1[i] + (500.0 / 1113.0) * k3[i] + (125.0 / 192.0) * k4[i] -
                         (2187.0 / 6784.0) * k5[i] + (11.0 / 84.0) * k6[i]);
-  ode_eval<M>(t + h, kp, xn, rs, k7);
+  ode_eval<M>(t + h, L, xn, rs, k7);
   double acc = 0.0;
 #pragma unroll
   for (int i = 0; i < NS; ++i) {
@@ -103,7 +139,7 @@ struct AdaptState {
 // while the piece is unfinished.  A step that underflows (h < 1e-13 max(1,|t|)) marks the lane failed and jumps to
 // the end of the piece so that every lane terminates.
 template <class M>
-__device__ __forceinline__ bool dopri5_advance(const DevModel& m, const double* kp, double (&x)[M::NS],
+__device__ __forceinline__ bool dopri5_advance(const DevModel& m, const OdeLane<M>& L, double (&x)[M::NS],
                                                const double (&rs)[M::NR], double& t, double t1, AdaptState& as) {
   constexpr int NS = M::NS;
   const double left = t1 - t;
@@ -112,7 +148,7 @@ __device__ __forceinline__ bool dopri5_advance(const DevModel& m, const double* 
   const bool clipped = h >= left;
   if (clipped) h = left;
   double xn[NS];
-  const double err = dopri5_try<M>(m, kp, x, rs, t, h, xn);
+  const double err = dopri5_try<M>(m, L, x, rs, t, h, xn);
   const bool ok = err <= 1.0;  // (false for NaN)
   // factor 0.9 err^(-1/5) in [0.2, 5]; no growth right after a rejection
   double fac = (err > 0.0) ? 0.9 * pow(err, -0.2) : 5.0;
@@ -137,13 +173,6 @@ __device__ __forceinline__ bool dopri5_advance(const DevModel& m, const double* 
 }
 
 template <class M>
-struct OdeLane {
-  double kp[M::NP];
-  double inv_vol[PMX_MAX_OUT];
-  double xinit[M::NS];
-};
-
-template <class M>
 __device__ __forceinline__ void ode_lane_setup(const DevModel& m, const double* __restrict__ th, OdeLane<M>& L) {
 #pragma unroll
   for (int j = 0; j < M::NP; ++j) L.kp[j] = th[j];
@@ -151,8 +180,7 @@ __device__ __forceinline__ void ode_lane_setup(const DevModel& m, const double* 
 #pragma unroll
     for (int o = 0; o < PMX_MAX_OUT; ++o) L.inv_vol[o] = 1.0;
 #pragma unroll
-    for (int i = 0; i < M::NS; ++i) L.xinit[i] = 0.0;
-    if constexpr (M::HAS_INIT) M::init(L.kp, L.xinit);
+    for (int i = 0; i < M::NS; ++i) L.xinit[i] = 0.0;  // (custom bodies initialise at RESET: ode_reset)
     return;
   }
 #pragma unroll
@@ -165,6 +193,28 @@ __device__ __forceinline__ void ode_lane_setup(const DevModel& m, const double* 
   for (int i = 0; i < M::NS; ++i) L.xinit[i] = (m.has_init && m.init_param[i] >= 0) ? th[m.init_param[i]] : 0.0;
 }
 
+// RESET: x = 0, plus the model's init for an occasion of index 0 (`with_init`; ode/mod.rs:536-549).  A custom body
+// is evaluated here, per subject, because it may read covariates (at t = 0).
+template <class M>
+__device__ __forceinline__ void ode_reset(const OdeLane<M>& L, int with_init, double (&x)[M::NS]) {
+#pragma unroll
+  for (int i = 0; i < M::NS; ++i) x[i] = with_init ? L.xinit[i] : 0.0;
+  if constexpr (M::CUSTOM) {
+    if constexpr (M::HAS_INIT) {
+      if (with_init) {
+        if constexpr (M::NCOV > 0) {
+          double cov[M::NCOV];
+#pragma unroll
+          for (int c = 0; c < M::NCOV; ++c) cov[c] = cov_at(*L.ops, L.occ, c, 0.0);
+          M::init(L.kp, cov, x);
+        } else {
+          M::init(L.kp, nullptr, x);
+        }
+      }
+    }
+  }
+}
+
 template <class M>
 __device__ __forceinline__ double ode_out(const DevModel& m, const OdeLane<M>& L,
                                           const double (&x)[M::NS], int outeq, double t) {
@@ -172,7 +222,14 @@ __device__ __forceinline__ double ode_out(const DevModel& m, const OdeLane<M>& L
     double y[M::NOUT];
 #pragma unroll
     for (int o = 0; o < M::NOUT; ++o) y[o] = 0.0;
-    M::out(t, L.kp, x, y);
+    if constexpr (M::NCOV > 0) {
+      double cov[M::NCOV];
+#pragma unroll
+      for (int c = 0; c < M::NCOV; ++c) cov[c] = cov_at(*L.ops, L.occ, c, t);
+      M::out(t, L.kp, x, cov, y);
+    } else {
+      M::out(t, L.kp, x, nullptr, y);
+    }
     double v = y[0];
 #pragma unroll
     for (int o = 1; o < M::NOUT; ++o) v = (o == outeq) ? y[o] : v;
@@ -212,13 +269,13 @@ __device__ __forceinline__ void ode_rates(const DevModel& m, const double* __res
 // One constant-rate piece [t0, t1] whose length is only known on the device (a lagged bolus split it):
 // n = ceil(dt / h_max) classic RK4 steps, the host compiler's rule (pmx_compile.cpp, ODE PROP ops).
 template <class M, bool ADAPT>
-__device__ __forceinline__ void ode_piece(const DevModel& m, const double* kp, double (&x)[M::NS],
+__device__ __forceinline__ void ode_piece(const DevModel& m, const OdeLane<M>& L, double (&x)[M::NS],
                                           const double (&rs)[M::NR], double t0, double t1, AdaptState& as) {
   const double dt = t1 - t0;
   if (!(dt > 0.0)) return;
   if constexpr (ADAPT) {
     double t = t0;
-    for (int32_t guard = 0; guard < 10000000 && dopri5_advance<M>(m, kp, x, rs, t, t1, as); ++guard) {
+    for (int32_t guard = 0; guard < 10000000 && dopri5_advance<M>(m, L, x, rs, t, t1, as); ++guard) {
     }
     return;
   }
@@ -227,7 +284,7 @@ __device__ __forceinline__ void ode_piece(const DevModel& m, const double* kp, d
   if (nf > 1.0e7) nf = 1.0e7;  // a lane with an absurd lag must still terminate
   const int32_t n = static_cast<int32_t>(nf);
   const double h = dt / static_cast<double>(n);
-  for (int32_t k = 0; k < n; ++k) rk4_step<M>(kp, x, rs, t0 + static_cast<double>(k) * h, h);
+  for (int32_t k = 0; k < n; ++k) rk4_step<M>(L, x, rs, t0 + static_cast<double>(k) * h, h);
 }
 
 // lag_open_occasion / lag_prop of the ODE back-end: same merge rule, RK4 pieces instead of closed forms.
@@ -235,7 +292,7 @@ __device__ __forceinline__ void ode_piece(const DevModel& m, const double* kp, d
 // (infusions are events of the occasion), so those pieces run with zero rates.
 template <class M, bool ADAPT>
 __device__ __forceinline__ void ode_lag_open_occasion(const DevModel& m, const DevOps& ops, LagState& ls, int64_t occ,
-                                                      double t_first, const double* kp, const double* __restrict__ th,
+                                                      double t_first, const OdeLane<M>& L, const double* __restrict__ th,
                                                       double (&x)[M::NS], AdaptState& as) {
   constexpr int NS = M::NS;
 #pragma unroll
@@ -256,17 +313,17 @@ __device__ __forceinline__ void ode_lag_open_occasion(const DevModel& m, const D
     int which;
     const double tau = lag_next(m, ops, ls, which);
     if (!(tau < t_first)) break;
-    if (started) ode_piece<M, ADAPT>(m, kp, x, zero, t, tau, as);
+    if (started) ode_piece<M, ADAPT>(m, L, x, zero, t, tau, as);
     t = tau;
     started = true;
     lag_apply_bolus<NS>(m, ops, ls, which, th, x);
   }
-  if (started && t_first < __longlong_as_double(0x7ff0000000000000LL)) ode_piece<M, ADAPT>(m, kp, x, zero, t, t_first, as);
+  if (started && t_first < __longlong_as_double(0x7ff0000000000000LL)) ode_piece<M, ADAPT>(m, L, x, zero, t, t_first, as);
 }
 
 template <class M, bool ADAPT>
 __device__ __forceinline__ void ode_lag_prop(const DevModel& m, const DevOps& ops, LagState& ls, double t0, double t1,
-                                             const double* kp, const double (&rs)[M::NR],
+                                             const OdeLane<M>& L, const double (&rs)[M::NR],
                                              const double* __restrict__ th, double (&x)[M::NS], AdaptState& as) {
   constexpr int NS = M::NS;
   double t = t0;
@@ -275,12 +332,12 @@ __device__ __forceinline__ void ode_lag_prop(const DevModel& m, const DevOps& op
     const double tau = lag_next(m, ops, ls, which);
     if (!(tau < t1)) break;
     if (tau > t) {
-      ode_piece<M, ADAPT>(m, kp, x, rs, t, tau, as);
+      ode_piece<M, ADAPT>(m, L, x, rs, t, tau, as);
       t = tau;
     }
     lag_apply_bolus<NS>(m, ops, ls, which, th, x);
   }
-  ode_piece<M, ADAPT>(m, kp, x, rs, t, t1, as);
+  ode_piece<M, ADAPT>(m, L, x, rs, t, t1, as);
 }
 
 template <class M, bool LAG, bool LL, bool ADAPT>
@@ -297,6 +354,8 @@ __device__ __forceinline__ void ode_grid_body(const DevModel& m, const DevOps& o
   const double* __restrict__ th = theta + pc * m.nparams;
   OdeLane<M> L;
   ode_lane_setup<M>(m, th, L);
+  L.ops = &ops;
+  L.occ = 0;
   uint8_t st_lane = PMX_PAIR_OK;
   LagState ls;
   if constexpr (LAG) {
@@ -334,15 +393,15 @@ __device__ __forceinline__ void ode_grid_body(const DevModel& m, const DevOps& o
         double rs[M::NR];
         ode_rates<M>(m, ops.op_rate, o, ops.n_rate, rs);
         if constexpr (LAG) {
-          ode_lag_prop<M, ADAPT>(m, ops, ls, uniformf64(ops.op_t0[o]), uniformf64(ops.op_t1[o]), L.kp, rs, th, x, as);
+          ode_lag_prop<M, ADAPT>(m, ops, ls, uniformf64(ops.op_t0[o]), uniformf64(ops.op_t1[o]), L, rs, th, x, as);
         } else if constexpr (ADAPT) {
-          ode_piece<M, true>(m, L.kp, x, rs, uniformf64(ops.op_t0[o]), uniformf64(ops.op_t1[o]), as);
+          ode_piece<M, true>(m, L, x, rs, uniformf64(ops.op_t0[o]), uniformf64(ops.op_t1[o]), as);
         } else {
           const double h = uniformf64(ops.op_b[o]);
           const int32_t n = static_cast<int32_t>(uniform32(static_cast<uint32_t>(ops.op_n[o])));
           double t0 = 0.0;  // only a custom (possibly non-autonomous) body reads the time
           if constexpr (M::CUSTOM) t0 = uniformf64(ops.op_t0[o]);
-          for (int32_t k = 0; k < n; ++k) rk4_step<M>(L.kp, x, rs, t0 + static_cast<double>(k) * h, h);
+          for (int32_t k = 0; k < n; ++k) rk4_step<M>(L, x, rs, t0 + static_cast<double>(k) * h, h);
         }
       } else if (kind == OP_OBS) {
         double y = ode_out<M>(m, L, x, io, a);
@@ -364,10 +423,10 @@ __device__ __forceinline__ void ode_grid_body(const DevModel& m, const DevOps& o
 #pragma unroll
         for (int i = 0; i < NS; ++i) x[i] += (i == dest) ? amt : 0.0;
       } else {
-#pragma unroll
-        for (int i = 0; i < NS; ++i) x[i] = io ? L.xinit[i] : 0.0;
+        L.occ = static_cast<int64_t>(a);
+        ode_reset<M>(L, io, x);
         if constexpr (LAG)
-          ode_lag_open_occasion<M, ADAPT>(m, ops, ls, static_cast<int64_t>(a), uniformf64(ops.op_t0[o]), L.kp, th, x, as);
+          ode_lag_open_occasion<M, ADAPT>(m, ops, ls, static_cast<int64_t>(a), uniformf64(ops.op_t0[o]), L, th, x, as);
       }
     }
     if constexpr (LL) {
@@ -395,6 +454,8 @@ __device__ __forceinline__ void ode_pair_body(const DevModel& m, const DevOps& o
   const double* __restrict__ th = theta + (batch ? s : p) * m.nparams;
   OdeLane<M> L;
   ode_lane_setup<M>(m, th, L);
+  L.ops = &ops;
+  L.occ = 0;
   uint8_t st = PMX_PAIR_OK;
   LagState ls;
   if constexpr (LAG) {
@@ -440,11 +501,11 @@ __device__ __forceinline__ void ode_pair_body(const DevModel& m, const DevOps& o
   while ((ADAPT ? stepping : rem > 0) || o < o1) {
     if (ADAPT ? stepping : rem > 0) {
       if constexpr (ADAPT) {
-        stepping = dopri5_advance<M>(m, L.kp, x, rs, t_run, t_run_end, as);  // one attempted step per trip
+        stepping = dopri5_advance<M>(m, L, x, rs, t_run, t_run_end, as);  // one attempted step per trip
       } else {
         double t = 0.0;
         if constexpr (M::CUSTOM) t = t_piece + static_cast<double>(n_piece - rem) * h;
-        rk4_step<M>(L.kp, x, rs, t, h);
+        rk4_step<M>(L, x, rs, t, h);
         --rem;
       }
     } else if (LAG && in_prop) {
@@ -519,8 +580,8 @@ __device__ __forceinline__ void ode_pair_body(const DevModel& m, const DevOps& o
 #pragma unroll
         for (int j = 0; j < NS; ++j) x[j] += (j == dest) ? amt : 0.0;
       } else {
-#pragma unroll
-        for (int j = 0; j < NS; ++j) x[j] = io ? L.xinit[j] : 0.0;
+        L.occ = static_cast<int64_t>(a);
+        ode_reset<M>(L, io, x);
         if constexpr (LAG) {
           const int64_t occ = static_cast<int64_t>(a);
 #pragma unroll

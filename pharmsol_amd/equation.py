@@ -367,12 +367,15 @@ class ODE(Equation):
 
     @staticmethod
     def custom(source: str, *, nstates: int, nparams: int, ndrugs: int = 1, nout: int = 1, has_init: bool = False,
-               lag: Optional[Dict[int, int]] = None, fa: Optional[Dict[int, int]] = None, h_max: float = 0.02) -> "ODE":
+               covariates: Optional[Sequence[str]] = None, lag: Optional[Dict[int, int]] = None,
+               fa: Optional[Dict[int, int]] = None, h_max: float = 0.02) -> "ODE":
         """``ODE::new(diffeq, lag, fa, init, out)`` with USER bodies (ode/mod.rs:115-132): ``source`` is C/HIP text
         defining ``pmx_dynamics`` / ``pmx_outputs`` (/ ``pmx_init``) as described in include/pmx.h; the library
         compiles it for gfx950 with hiprtc.  Index-based like ``ODE::new``: data labels are dense numeric indices,
-        a bolus on input i goes to state i."""
+        a bolus on input i goes to state i.  ``covariates`` names the subject covariates the bodies read as
+        ``cov[0..]`` (interpolated at the time of every right-hand-side evaluation, like ``fetch_cov!``)."""
         m = ODE()
+        m.covariates = list(covariates or [])
         m.kernel_name = "custom"
         m.source = str(source)
         m.has_init = bool(has_init)

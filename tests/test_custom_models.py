@@ -57,7 +57,7 @@ def rel_err_floor(a, b):
 def test_translation_unit_wraps_the_user_source_into_the_shared_walkers():
     m = ODE.custom(ONE_CMT, nstates=1, nparams=2)
     tu = runtime.jit_translation_unit(m)
-    assert '#include "pmx_ode.hpp"' in tu and "pmx_dynamics(t, x, p, nullptr, r, nullptr, dx)" in tu
+    assert '#include "pmx_ode.hpp"' in tu and "pmx_dynamics(t, x, p, cov, r, nullptr, dx)" in tu
     assert "NS = 1, NP = 2" in tu and tu.count("extern \"C\" __global__") == 16  # grid/pair x lag x loglik x solver
     runtime.DeviceModel(m)  # hiprtc compiles for gfx950 without a device
 
@@ -80,7 +80,7 @@ def test_descriptor_rules_for_custom_models():
 
     h = C.c_void_p()
     assert _ffi.lib().pmx_model_create(C.byref(d), C.byref(h)) == _abi.PMX_ERR_INVALID_ARGUMENT  # needs the source
-    d.n_covariates = 1
+    d.pmetrics_indexing = 1
     assert _ffi.lib().pmx_model_create_custom(C.byref(d), ONE_CMT.encode(), 0, C.byref(h)) == _abi.PMX_ERR_UNSUPPORTED
     d = m.desc()
     d.rk4_h_max = 0.0
@@ -293,3 +293,78 @@ PMX_DEVICE void pmx_outputs({SIG}y) {{ y[0] = x[0]; }}
     np.testing.assert_array_equal(st, wst)
     assert (st == _abi.PMX_PAIR_SOLVER_FAIL).all() and np.isnan(got[1]).all()
     assert rel_err_floor(got[0], np.full(40, 2.0)).max() < 1e-5  # x(0.5) = 1 / (1 - 0.5)
+
+
+# --------------------------------------------------------------------------- covariates inside custom bodies
+# examples/covariates.rs: one-compartment oral model whose elimination is scaled by time-varying creatinine and age
+COV_SRC = f"""
+PMX_DEVICE void pmx_dynamics({SIG}dx) {{
+  const double ka = p[0], ke = p[1];
+  const double scaled_ke = ke * pow(cov[0] / 75.0, 0.75) * pow(cov[1] / 25.0, 0.5);
+  dx[0] = -ka * x[0];
+  dx[1] = ka * x[0] - scaled_ke * x[1];
+}}
+PMX_DEVICE void pmx_outputs({SIG}y) {{ y[0] = x[1] / p[3]; }}
+"""
+
+
+def _covariates_example_subject():
+    return (Subject.builder("id1").bolus(0.0, 100.0, 0).repeat(2, 2.0).observation(0.5, 0.1, 0).observation(1.0, 0.4, 0)
+            .observation(2.0, 1.0, 0).observation(2.5, 1.1, 0).covariate("creatinine", 0.0, 80.0)
+            .covariate("creatinine", 1.0, 40.0).covariate("age", 0.0, 25.0).missing_observation(8.0, 0).build())
+
+
+def test_oracle_covariates_example_against_piecewise_reasoning():
+    """examples/covariates.rs through the oracle: with constant covariates the model is the closed-form
+    one_compartment_with_absorption at ke' = ke (cr/75)^0.75 (age/25)^0.5; with the example's time-varying creatinine
+    it must sit between the two constant-creatinine solutions after t = 0."""
+    oracle.compile_custom(COV_SRC)
+    m = ODE.custom(COV_SRC, nstates=2, nparams=4, covariates=["creatinine", "age"], lag={0: 2}, h_max=0.01)
+    th = np.array([[1.0, 0.2, 0.0, 70.0]])
+    s_var = _covariates_example_subject()
+    got, st = oracle.predict(m, m.flatten(s_var), th)
+    assert (st == 0).all() and np.isfinite(got).all()
+
+    def const_cr(cr):
+        s = (Subject.builder("c").bolus(0.0, 100.0, 0).repeat(2, 2.0).missing_observation(0.5, 0).missing_observation(1.0, 0)
+             .missing_observation(2.0, 0).missing_observation(2.5, 0).covariate("creatinine", 0.0, cr).covariate("age", 0.0, 25.0)
+             .missing_observation(8.0, 0).build())
+        p, _ = oracle.predict(m, m.flatten(s), th)
+        ke = 0.2 * (cr / 75.0) ** 0.75
+        ma = Analytical.new("one_compartment_with_absorption", {0: Ratio(1, 2)}, nparams=3).with_nstates(2).with_ndrugs(1).with_nout(1)
+        pa, _ = oracle.predict(ma, ma.flatten(s), np.array([[1.0, ke, 70.0]]))
+        assert rel_err(p, pa).max() < 1e-8  # constant covariates: the closed form
+        return p[:, 0]
+
+    hi, lo = const_cr(80.0), const_cr(40.0)  # more creatinine clearance -> faster elimination -> lower curve
+    assert (got[1:, 0] > hi[1:]).all() and (got[1:, 0] < lo[1:]).all()
+
+
+@pytest.mark.gpu
+def test_gpu_custom_model_with_time_varying_covariates():
+    oracle.compile_custom(COV_SRC)
+    rng = np.random.default_rng(41)
+    for solver in ("rk4", "dopri5"):
+        m = ODE.custom(COV_SRC, nstates=2, nparams=4, covariates=["creatinine", "age"], lag={0: 2}, h_max=0.02)
+        if solver == "dopri5":
+            m = m.with_step(2.0).with_solver("dopri5").with_tolerances(1e-8, 1e-8)
+        subs = [_covariates_example_subject()]
+        for i in range(40):
+            b = Subject.builder(f"s{i}").bolus(0.0, float(rng.uniform(50, 200)), 0).repeat(int(rng.integers(0, 3)), 6.0)
+            for t in sorted(rng.uniform(0.2, 30, 6)):
+                b = b.missing_observation(float(t), 0)
+            for t in sorted(rng.uniform(0, 24, int(rng.integers(1, 4)))):
+                b = b.covariate("creatinine", float(np.round(t, 1)), float(rng.uniform(30, 120)))
+            b = b.covariate("age", 0.0, float(rng.uniform(20, 80)))
+            if i % 3 == 0:
+                b = b.reset().bolus(0.0, 80.0, 0).missing_observation(3.0, 0).covariate("creatinine", 0.0, 60.0).covariate("age", 0.0, 50.0)
+            subs.append(b.build())
+        flat = m.flatten(Data(subs))
+        for n in (48, 3):
+            th = np.stack([rng.uniform(0.5, 2.0, n), rng.uniform(0.05, 0.5, n), np.round(rng.uniform(0, 2, n) * 2) / 2,
+                           rng.uniform(20, 90, n)], axis=1)
+            got, st = _gpu(m, flat, th)
+            want, wst = oracle.predict(m, flat, th)
+            np.testing.assert_array_equal(st, wst)
+            tol = 1e-9 if solver == "rk4" else 1e-6
+            assert rel_err_floor(got, want).max() < tol, (solver, n, rel_err_floor(got, want).max())
