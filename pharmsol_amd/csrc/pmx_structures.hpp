@@ -283,14 +283,39 @@ struct ThreeCore {
     const double alpha = sqrt(-q);
     const double beta = -n / 2.0;
     const double gamma = sqrt(beta * beta + alpha * alpha);
-    const double theta = atan2(alpha, beta);
-    const double cr = cbrt(gamma);  // reference: gamma.powf(1.0/3.0)
-    double sn, cs;
-    sincos(theta / 3.0, &sn, &cs);
+    // The reference takes theta = atan2(alpha, beta), gamma^(1/3) and cos/sin(theta/3) (:36-45), i.e. the principal
+    // cube root z = cr (cs + i sn) of w = beta + i alpha.  Three f64 transcendentals per segment dominate a
+    // covariate model's cost, so z is seeded in single precision (1e-7) and polished with two Newton steps
+    // z <- (2 z + w / z^2) / 3 in f64 (quadratic: 1e-7 -> 1e-14 -> rounding).  Outside the float range the f64
+    // functions are used directly.
+    double zr, zi;
+    if (gamma > 1.0e-30 && gamma < 1.0e30) {
+      const float thf = atan2f(static_cast<float>(alpha), static_cast<float>(beta));
+      const float crf = cbrtf(static_cast<float>(gamma));
+      float snf, csf;
+      sincosf(thf * (1.0f / 3.0f), &snf, &csf);
+      zr = static_cast<double>(crf * csf);
+      zi = static_cast<double>(crf * snf);
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const double z2r = zr * zr - zi * zi, z2i = 2.0 * zr * zi;
+        const double inv = 1.0 / (z2r * z2r + z2i * z2i);
+        const double qr = (beta * z2r + alpha * z2i) * inv, qi = (alpha * z2r - beta * z2i) * inv;
+        zr = (2.0 * zr + qr) * (1.0 / 3.0);
+        zi = (2.0 * zi + qi) * (1.0 / 3.0);
+      }
+    } else {
+      const double theta = atan2(alpha, beta);
+      const double cr = cbrt(gamma);  // reference: gamma.powf(1.0/3.0)
+      double sn, cs;
+      sincos(theta / 3.0, &sn, &cs);
+      zr = cr * cs;
+      zi = cr * sn;
+    }
     const double rt3 = 1.7320508075688772;
-    l[0] = a / 3.0 + cr * (cs + rt3 * sn);
-    l[1] = a / 3.0 + cr * (cs - rt3 * sn);
-    l[2] = a / 3.0 - (2.0 * cr * cs);
+    l[0] = a / 3.0 + (zr + rt3 * zi);
+    l[1] = a / 3.0 + (zr - rt3 * zi);
+    l[2] = a / 3.0 - 2.0 * zr;
     return ok;
   }
   // eigen-solve + coefficients: three_compartment_models.rs:24-77
