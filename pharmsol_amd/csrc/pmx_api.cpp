@@ -689,7 +689,8 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
     } else if (mode == 0) {
       const int64_t n_chunks = (a.S + a.s_chunk - 1) / a.s_chunk;
       void* args[] = {&a.m, &a.ops, &a.theta, &a.P, &a.S, &a.s_chunk, &a.n_ptiles, &a.pred, &a.ld, &a.status};
-      e = hipModuleLaunchKernel(jm->fn[0][lag][ll][ad], static_cast<uint32_t>(n_chunks * a.n_ptiles), 1, 1, 256, 1, 1, 0,
+      e = hipModuleLaunchKernel(jm->fn[0][lag][ll][ad], static_cast<uint32_t>(n_chunks * a.n_ptiles), 1, 1,
+                                a.P <= 64 ? 64u : (a.P <= 128 ? 128u : 256u), 1, 1, 0,
                                 static_cast<hipStream_t>(stream), args, nullptr);
     } else {
       const int64_t n_pairs = a.batch ? a.S : a.S * a.P;
