@@ -639,7 +639,14 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
     a.cls.chunk_obs_off = lc->d_chunk_obs_off;
     if (lc->any_censored) a.use_classes = 0;  // the classed blocks carry {value, const, weight} only: censored rows take the generic walk
   }
-  if (!batch && P >= 32) {
+  // GRID (lane = support point, wave-uniform op stream) vs PAIR (lane = pair, divergent streams): measured crossovers
+  // (tools/pairgrid_sweep.sh) are 8 support points when the classed kernel serves most subjects, ~48 when every
+  // subject goes through the generic walker (a GRID wave with few live lanes still pays the whole walk); ODE: 32.
+  int64_t grid_min_p = 32;
+  if (d.eq_kind == PMX_EQ_ANALYTICAL)
+    grid_min_p = (a.use_classes && 2 * ds->n_classed_subjects >= a.S) ? 8 : 48;
+  if (const char* e = std::getenv("PMX_TUNE_GRID_MIN_P")) grid_min_p = std::atoi(e) > 0 ? std::atoi(e) : grid_min_p;  // tuning experiments
+  if (!batch && P >= grid_min_p) {
     a.mode = pmx::MODE_GRID;
     a.n_ptiles = static_cast<int32_t>((P + 255) / 256);
     // enough blocks to fill 256 CUs several times over, few enough that the per-block

@@ -281,8 +281,10 @@ def test_bioavailability_alone_and_on_ode():
     rng = np.random.default_rng(79)
     subs = _lag_subjects(rng, 30)
     m = Analytical.new("one_compartment", {0: Ratio(0, 1)}, nparams=3, fa={0: 2}).with_nstates(1).with_ndrugs(1).with_nout(1)
-    th = np.stack([rng.uniform(0.05, 0.5, 40), rng.uniform(5, 50, 40), rng.uniform(0.2, 1.0, 40)], axis=1)
+    th = np.stack([rng.uniform(0.05, 0.5, 64), rng.uniform(5, 50, 64), rng.uniform(0.2, 1.0, 64)], axis=1)
     assert_parity(m, m.flatten(Data(subs)), th, TOL_ANALYTICAL, expect_kernel="pmx_analytical_grid")
+    # below the generic walker's GRID/PAIR crossover (48 support points) the same model takes the PAIR kernel
+    assert_parity(m, m.flatten(Data(subs)), th[:40], TOL_ANALYTICAL, expect_kernel="pmx_analytical_pair")
     mo = ODE.new("one_cmt_iv", {0: Ratio(0, 1)}, nparams=3, h_max=0.01).with_nstates(1).with_ndrugs(1).with_nout(1)
     mo.fa = {"0": 2}
     assert_parity(mo, mo.flatten(Data(subs)), th, TOL_ODE, expect_kernel="pmx_ode_rk4_grid")
@@ -480,3 +482,19 @@ def test_pmetrics_csv_population_end_to_end():
     assert flat.n_subjects == 40 and flat.n_occasions == 60
     th = np.stack([rng.uniform(0.05, 0.4, 48), rng.uniform(10, 60, 48)], axis=1)
     assert_parity(eq, flat, th, TOL_ANALYTICAL, expect_kernel="pmx_analytical_grid<dyn>")
+
+
+def test_small_support_grids_pick_the_measured_lane_mapping():
+    """Shared designs go through the classed GRID kernel from 8 support points (64-thread blocks), ragged ones switch
+    from PAIR to GRID at 48 (tools/pairgrid_sweep.sh); every mapping gives the same numbers."""
+    rng = np.random.default_rng(101)
+    m, flat, theta = synth.config_c3(120, 64)
+    for n, kernel in ((4, "pmx_analytical_pair"), (8, "pmx_analytical_classed"), (33, "pmx_analytical_classed"),
+                      (64, "pmx_analytical_classed")):
+        assert_parity(m, flat, theta[:n], TOL_ANALYTICAL, expect_kernel=kernel)
+    subs = [models.random_subject(rng) for _ in range(40)]
+    mr = models.handwritten_analytical("two_compartments", 0, 4).with_ndrugs(1)
+    fr = mr.flatten(Data(subs))
+    for n, kernel in ((20, "pmx_analytical_pair"), (47, "pmx_analytical_pair"), (48, "pmx_analytical_grid"),
+                      (100, "pmx_analytical_grid"), (130, "pmx_analytical_grid")):
+        assert_parity(mr, fr, synth.theta_c3(n), TOL_ANALYTICAL, expect_kernel=kernel)
