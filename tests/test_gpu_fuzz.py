@@ -1,0 +1,161 @@
+"""Randomised combinations of everything the path supports (structure x CL form x pm_ indexing x init x lag x fa x
+multi-occasion x shared/ragged designs x covariate-derived parameters x lane mapping x prediction / log-likelihood),
+GPU against the CPU oracle.  Each case is seeded; a failure prints its recipe."""
+import numpy as np
+import pytest
+
+import oracle
+from pharmsol_amd import (ODE, Analytical, AssayErrorModel, AssayErrorModels, Data, ErrorPoly, Pow, Ratio, Scaled, Subject,
+                          _abi, analytical, bolus, infusion, runtime, synth)
+from tests import models
+
+pytestmark = pytest.mark.gpu
+
+STRUCTS = {  # name -> (n states, n kernel params, central state, theta builder)
+    "one_compartment": (1, 1, 0), "one_compartment_cl": (1, 2, 0),
+    "one_compartment_with_absorption": (2, 2, 1), "one_compartment_cl_with_absorption": (2, 3, 1),
+    "two_compartments": (2, 3, 0), "two_compartments_cl": (2, 4, 0),
+    "two_compartments_with_absorption": (3, 4, 1), "two_compartments_cl_with_absorption": (3, 5, 1),
+    "three_compartments": (3, 5, 0), "three_compartments_cl": (3, 6, 0),
+    "three_compartments_with_absorption": (4, 6, 1), "three_compartments_cl_with_absorption": (4, 7, 1),
+}
+
+
+def kernel_theta(name, n, rng):
+    """Kernel-order parameters with real eigenvalues (micro-constants from the C3/C5 generators, CL forms derived)."""
+    t2, t3 = synth.theta_c3(n, synth.SplitMix64(int(rng.integers(1 << 30)))), synth.theta_c5(n, synth.SplitMix64(int(rng.integers(1 << 30))))
+    ke, kcp, kpc = t2[:, 0], t2[:, 1], t2[:, 2]
+    ka, k10, k12, k13, k21, k31 = (t3[:, i] for i in range(6))
+    v = rng.uniform(10, 60, n)
+    if name == "one_compartment":
+        return np.stack([ke], 1)
+    if name == "one_compartment_cl":
+        return np.stack([ke * v, v], 1)
+    if name == "one_compartment_with_absorption":
+        return np.stack([ka, ke], 1)
+    if name == "one_compartment_cl_with_absorption":
+        return np.stack([ka, ke * v, v], 1)
+    if name == "two_compartments":
+        return np.stack([ke, kcp, kpc], 1)
+    if name == "two_compartments_cl":  # cl, q, vc, vp
+        return np.stack([ke * v, kcp * v, v, kcp * v / kpc], 1)
+    if name == "two_compartments_with_absorption":  # ke, ka, kcp, kpc
+        return np.stack([ke, ka, kcp, kpc], 1)
+    if name == "two_compartments_cl_with_absorption":  # ka, cl, q, vc, vp
+        return np.stack([ka, ke * v, kcp * v, v, kcp * v / kpc], 1)
+    if name == "three_compartments":
+        return np.stack([k10, k12, k13, k21, k31], 1)
+    if name == "three_compartments_cl":  # cl, q2, q3, vc, v2, v3
+        return np.stack([k10 * v, k12 * v, k13 * v, v, k12 * v / k21, k13 * v / k31], 1)
+    if name == "three_compartments_with_absorption":
+        return np.stack([ka, k10, k12, k13, k21, k31], 1)
+    return np.stack([ka, k10 * v, k12 * v, k13 * v, v, k12 * v / k21, k13 * v / k31], 1)
+
+
+def build_case(seed):
+    rng = np.random.default_rng(seed)
+    name = list(STRUCTS)[int(rng.integers(0, len(STRUCTS)))]
+    ns, nk, central = STRUCTS[name]
+    pm = bool(rng.random() < 0.2)
+    use_lag = bool(rng.random() < 0.3) and not pm
+    use_fa = bool(rng.random() < 0.3)
+    use_init = bool(rng.random() < 0.3)
+    shared = bool(rng.random() < 0.4)
+    multi = bool(rng.random() < 0.4)
+    n_sub = int(rng.integers(3, 40))
+    n_support = int(rng.choice([1, 3, 9, 40, 70, 300]))
+    batch = bool(rng.random() < 0.15)
+    # theta layout: kernel params | v | lag | fa | init
+    cols = nk
+    v_col = cols
+    cols += 1
+    lag_col = fa_col = init_col = None
+    if use_lag:
+        lag_col, cols = cols, cols + 1
+    if use_fa:
+        fa_col, cols = cols, cols + 1
+    if use_init:
+        init_col, cols = cols, cols + 1
+    off = 1 if pm else 0
+    m = Analytical.new(("pm_" if pm else "") + name, {0: Ratio(central + off, v_col)}, nparams=cols,
+                       init={central + off: init_col} if use_init else None,
+                       lag={off: lag_col} if use_lag else None, fa={off: fa_col} if use_fa else None)
+    m = m.with_nstates(ns + off).with_ndrugs(1 + off).with_nout(1)
+    subs = []
+    if shared:
+        proto = models.random_subject(rng, multi_occasion=multi)
+        for i in range(n_sub):
+            b = Subject.builder(f"s{i}")
+            for oi, occ in enumerate(proto.occasions):
+                if oi:
+                    b = b.reset()
+                for ev in occ.events:
+                    if hasattr(ev, "duration"):
+                        b = b.infusion(ev.time, ev.amount * (1 + 0.01 * i), off, ev.duration)
+                    elif hasattr(ev, "amount"):
+                        b = b.bolus(ev.time, ev.amount * (1 + 0.01 * i), off)
+                    else:
+                        b = b.missing_observation(ev.time, 0)
+            subs.append(b.build())
+    else:
+        for _ in range(n_sub):
+            s = models.random_subject(rng, multi_occasion=multi)
+            for occ in s.occasions:
+                for ev in occ.events:
+                    if hasattr(ev, "input"):
+                        ev.input = off
+            subs.append(s)
+        if rng.random() < 0.3:
+            subs.insert(int(rng.integers(0, len(subs))), Subject.builder("empty").build())
+    n = len(subs) if batch else n_support
+    th = [kernel_theta(name, n, rng), rng.uniform(10, 80, (n, 1))]
+    if use_lag:
+        th.append(np.round(rng.uniform(0, 3, (n, 1)) * 2) / 2)
+    if use_fa:
+        th.append(rng.uniform(0.3, 1.0, (n, 1)))
+    if use_init:
+        th.append(rng.uniform(0, 50, (n, 1)))
+    theta = np.concatenate(th, axis=1)
+    recipe = dict(seed=seed, structure=name, pm=pm, lag=use_lag, fa=use_fa, init=use_init, shared=shared, multi=multi,
+                  subjects=len(subs), support=n_support, batch=batch)
+    return m, subs, theta, batch, recipe
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_random_analytical_configuration(seed):
+    import torch
+
+    m, subs, theta, batch, recipe = build_case(1000 + seed)
+    flat = m.flatten(Data(subs))
+    pop = runtime.DevicePopulation(flat, 0)
+    pred, st = runtime.predict(m, pop, np.ascontiguousarray(theta), batch=batch)
+    torch.cuda.synchronize()
+    got, st = pred.cpu().numpy(), st.cpu().numpy()
+    want, wst = (oracle.predict_batch if batch else oracle.predict)(m, flat, theta)
+    assert got.shape == want.shape, recipe
+    np.testing.assert_array_equal(st, wst, err_msg=str(recipe))
+    ok = np.isfinite(want)
+    np.testing.assert_array_equal(np.isfinite(got), ok, err_msg=str(recipe))
+    if ok.any():
+        scale = np.maximum(np.abs(want[ok]), 1e-9 * np.abs(want[ok]).max() + 1e-300)
+        err = (np.abs(got[ok] - want[ok]) / scale).max()
+        assert err < 1e-6, (err, recipe, runtime.last_kernel_name())
+    if not batch and seed % 3 == 0 and flat.n_observations:  # the same case through the fused log-likelihood
+        rng = np.random.default_rng(seed)
+        vals = np.abs(np.where(np.isfinite(want[:, 0]), want[:, 0], 1.0)) * np.exp(rng.normal(0, 0.2, want.shape[0])) + 0.05
+        vals[rng.random(vals.shape) < 0.2] = np.nan
+        order_ok = all(list(map(lambda e: e.time, o.events)) == sorted(e.time for e in o.events) for s in subs for o in s.occasions)
+        if order_ok:
+            flat.ev_value = flat.ev_value.copy()
+            flat.ev_value[flat.ev_kind == _abi.PMX_EV_OBSERVATION] = vals
+            em = AssayErrorModels.empty().add(0, AssayErrorModel.additive(ErrorPoly(0.05, 0.1, 0.0, 0.0), 0.1))
+            pop2 = runtime.DevicePopulation(flat, 0)
+            ll, lst = runtime.loglik(m, pop2, em, np.ascontiguousarray(theta))
+            torch.cuda.synchronize()
+            wll, wlst = oracle.loglik(m, flat, em, theta)
+            np.testing.assert_array_equal(lst.cpu().numpy(), wlst, err_msg=str(recipe))
+            okl = np.isfinite(wll)
+            gl = ll.cpu().numpy()
+            np.testing.assert_array_equal(np.isfinite(gl), okl, err_msg=str(recipe))
+            if okl.any():
+                assert (np.abs(gl[okl] - wll[okl]) / np.maximum(np.abs(wll[okl]), 1.0)).max() < 1e-6, recipe
