@@ -159,3 +159,63 @@ def test_random_analytical_configuration(seed):
             np.testing.assert_array_equal(np.isfinite(gl), okl, err_msg=str(recipe))
             if okl.any():
                 assert (np.abs(gl[okl] - wll[okl]) / np.maximum(np.abs(wll[okl]), 1.0)).max() < 1e-6, recipe
+
+
+ODE_MODELS = {  # name -> (n states, n diffeq params, central)
+    "one_cmt_iv": (1, 1, 0), "one_cmt_oral": (2, 2, 1), "two_cmt_iv": (2, 3, 0), "two_cmt_oral": (3, 4, 1),
+    "three_cmt_iv": (3, 5, 0), "three_cmt_oral": (4, 6, 1), "one_cmt_mm": (1, 3, 0),
+}
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_ode_configuration(seed):
+    import torch
+
+    rng = np.random.default_rng(5000 + seed)
+    name = list(ODE_MODELS)[int(rng.integers(0, len(ODE_MODELS)))]
+    ns, nk, central = ODE_MODELS[name]
+    use_lag, use_fa = bool(rng.random() < 0.4), bool(rng.random() < 0.3)
+    adaptive = bool(rng.random() < 0.4)
+    batch = bool(rng.random() < 0.2)
+    n_support = int(rng.choice([2, 20, 40, 90]))
+    mm = name == "one_cmt_mm"
+    cols = nk + (0 if mm else 1)  # the MM body's third parameter is its volume
+    v_col = 2 if mm else nk
+    lag_col = fa_col = None
+    if use_lag:
+        lag_col, cols = cols, cols + 1
+    if use_fa:
+        fa_col, cols = cols, cols + 1
+    m = ODE.new(name, {0: Ratio(central, v_col)}, nparams=cols, lag={0: lag_col} if use_lag else None,
+                fa={0: fa_col} if use_fa else None, h_max=0.05).with_nstates(ns).with_ndrugs(1).with_nout(1)
+    if adaptive:
+        m = m.with_step(4.0).with_solver("dopri5").with_tolerances(1e-8, 1e-8)
+    subs = [models.random_subject(rng, multi_occasion=bool(rng.random() < 0.3)) for _ in range(int(rng.integers(3, 25)))]
+    n = len(subs) if batch else n_support
+    if mm:
+        th = [np.stack([rng.uniform(5, 30, n), rng.uniform(1, 10, n), rng.uniform(10, 40, n)], 1)]
+    else:
+        src = {1: synth.theta_c3(n)[:, :1], 2: np.stack([synth.theta_c5(n)[:, 0], synth.theta_c3(n)[:, 0]], 1),
+               3: synth.theta_c3(n)[:, :3],
+               4: np.concatenate([synth.theta_c3(n)[:, :1], synth.theta_c5(n)[:, :1], synth.theta_c3(n)[:, 1:3]], 1),
+               5: synth.theta_c5(n)[:, 1:6], 6: synth.theta_c5(n)[:, :6]}[nk]
+        th = [src, rng.uniform(10, 80, (n, 1))]
+    if use_lag:
+        th.append(np.round(rng.uniform(0, 3, (n, 1)) * 2) / 2)
+    if use_fa:
+        th.append(rng.uniform(0.3, 1.0, (n, 1)))
+    theta = np.concatenate(th, axis=1)
+    recipe = dict(seed=seed, model=name, lag=use_lag, fa=use_fa, adaptive=adaptive, batch=batch, support=n_support)
+    flat = m.flatten(Data(subs))
+    pop = runtime.DevicePopulation(flat, 0)
+    pred, st = runtime.predict(m, pop, np.ascontiguousarray(theta), batch=batch)
+    torch.cuda.synchronize()
+    got, st = pred.cpu().numpy(), st.cpu().numpy()
+    want, wst = (oracle.predict_batch if batch else oracle.predict)(m, flat, theta)
+    np.testing.assert_array_equal(st, wst, err_msg=str(recipe))
+    ok = np.isfinite(want)
+    np.testing.assert_array_equal(np.isfinite(got), ok, err_msg=str(recipe))
+    if ok.any():
+        scale = np.maximum(np.abs(want[ok]), 1e-3 * np.abs(want[ok]).max() + 1e-300)
+        err = (np.abs(got[ok] - want[ok]) / scale).max()
+        assert err < (2e-6 if adaptive else 1e-9), (err, recipe, runtime.last_kernel_name())
