@@ -119,28 +119,29 @@ __device__ __forceinline__ void lag_apply_bolus(const DevModel& m, const DevOps&
 // Censored rows (q[3] = +1/(sigma sqrt 2): BLOQ, -1/(sigma sqrt 2): ALOQ) take the log CDF / log survival
 // function of distributions.rs:52-103, with statrs' Normal::cdf = 0.5 erfc((mean - x)/(sigma sqrt 2)); a tail
 // that underflows falls back to the reference's asymptote (|z| > 37) or poisons the sum with NaN (its Err).
-__device__ __forceinline__ void ll_accumulate(const double* __restrict__ q, double y, double& acc) {
+// censored row, out of line: erfc + two logs would otherwise sit in every log-likelihood kernel's register budget
+// (the generic GRID kernel spilled 140 bytes and lost a wave of occupancy for a branch most datasets never take)
+__device__ __noinline__ double ll_censored_term(double obs, double y, double pdf, double cs) {
+  const double inv = fabs(cs);
+  const double d = obs - y;
+  const double cdf = 0.5 * erfc((y - obs) * inv);
+  const double z = d * (inv * 1.4142135623730951);  // (obs - pred) / sigma
+  const double nanv = __longlong_as_double(0x7ff8000000000000LL);
+  if (cs > 0.0)  // BLOQ: ln P(X <= obs)
+    return (cdf > 0.0) ? log(cdf) : ((z < -37.0) ? pdf - log(fabs(z)) : nanv);
+  const double sf = 1.0 - cdf;  // ALOQ: ln P(X > obs), computed as 1 - cdf like the reference
+  return (sf > 0.0) ? log(sf) : ((z > 37.0) ? pdf - log(z) : nanv);
+}
+
+// (Q = const double* for per-lane rows, cptr<double> where the row is wave-uniform: scalar fetches)
+template <class Q>
+__device__ __forceinline__ void ll_accumulate(Q q, double y, double& acc) {
   const double w = q[2];
   if (w != 0.0) {  // weight 0 = missing observation: contributes 0 whatever the prediction (prediction.rs:107-111)
     const double d = q[0] - y;
     const double pdf = q[1] - (d * d) * w;
     const double cs = q[3];
-    if (cs == 0.0) {  // wave-uniform
-      acc += pdf;
-    } else {
-      const double inv = fabs(cs);
-      const double cdf = 0.5 * erfc((y - q[0]) * inv);
-      const double z = d * (inv * 1.4142135623730951);  // (obs - pred) / sigma
-      const double nanv = __longlong_as_double(0x7ff8000000000000LL);
-      double ll;
-      if (cs > 0.0) {  // BLOQ: ln P(X <= obs)
-        ll = (cdf > 0.0) ? log(cdf) : ((z < -37.0) ? pdf - log(fabs(z)) : nanv);
-      } else {  // ALOQ: ln P(X > obs), computed as 1 - cdf like the reference
-        const double sf = 1.0 - cdf;
-        ll = (sf > 0.0) ? log(sf) : ((z > 37.0) ? pdf - log(z) : nanv);
-      }
-      acc += ll;
-    }
+    acc += (cs == 0.0) ? pdf : ll_censored_term(q[0], y, pdf, cs);
   }
 }
 

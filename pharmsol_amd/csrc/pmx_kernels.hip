@@ -294,7 +294,7 @@ __global__ __launch_bounds__(kBlock, (!LAG && LaneModel<KID>::NS <= 2) ? 4 : ((!
         double y = lane_out<KID>(m, L, x, xpad, io, cov);
         if (st == PMX_PAIR_COMPLEX_ROOTS || st == PMX_PAIR_BAD_LAG) y = nanv;
         if constexpr (LL) {
-          ll_accumulate(ops.ll_obs + row * 4, y, ll_acc);
+          ll_accumulate(as_const(ops.ll_obs) + row * 4, y, ll_acc);  // row is wave-uniform: scalar fetches
         } else {
           if (st == PMX_PAIR_OK && !isfinite(y)) st = PMX_PAIR_NONFINITE;
           if (lane_ok) pred[row * ld + p] = y;

@@ -411,7 +411,7 @@ __device__ __forceinline__ void ode_grid_body(const DevModel& m, const DevOps& o
           y = nanv;
         }
         if constexpr (LL) {
-          ll_accumulate(ops.ll_obs + row * 4, y, ll_acc);
+          ll_accumulate(as_const(ops.ll_obs) + row * 4, y, ll_acc);
         } else {
           if (st == PMX_PAIR_OK && !isfinite(y)) st = PMX_PAIR_NONFINITE;
           if (lane_ok) pred[row * ld + p] = y;
