@@ -31,6 +31,33 @@
 
 namespace pmx {
 
+// exp() for the propagators' arguments (-lambda dt: finite, almost always <= 0).  Same scheme as the library's
+// (n = rint(x log2 e), r = x - n ln2 in two pieces, polynomial, scale by 2^n) without its special-case selects:
+// degree-13 Taylor on |r| <= ln2/2 (truncation 4e-18), Horner in FMAs; v_ldexp saturates to 0 / inf by itself and NaN
+// propagates.  ~19 VALU instructions instead of ~30, results within 1-2 ulp of the library's.  (Keeping the 16
+// constants resident in VGPRs instead of literals was tried for the generic kernel: one wave of occupancy less,
+// 6 % slower.)
+__device__ __forceinline__ double pmx_exp(double x) {
+  const double n = __builtin_rint(x * 1.4426950408889634074);
+  double r = fma(n, -6.93147180369123816490e-01, x);  // ln2 high part: 21 trailing zero bits, n * hi is exact
+  r = fma(n, -1.90821492927058770002e-10, r);
+  double p = 1.6059043836821614599e-10;  // 1/13!
+  p = fma(p, r, 2.0876756987868098979e-09);
+  p = fma(p, r, 2.5052108385441718775e-08);
+  p = fma(p, r, 2.7557319223985890653e-07);
+  p = fma(p, r, 2.7557319223985892511e-06);
+  p = fma(p, r, 2.4801587301587301566e-05);
+  p = fma(p, r, 1.9841269841269841253e-04);
+  p = fma(p, r, 1.3888888888888889419e-03);
+  p = fma(p, r, 8.3333333333333332177e-03);
+  p = fma(p, r, 4.1666666666666664354e-02);
+  p = fma(p, r, 1.6666666666666665741e-01);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, static_cast<int>(n));
+}
+
 enum StructId : int { S_ONE = 0, S_ONE_ABS = 1, S_TWO = 2, S_TWO_ABS = 3, S_THREE = 4, S_THREE_ABS = 5 };
 
 // kernel id (include/pmx.h PMX_K_*) -> structure / CL flag, usable on host and device
@@ -104,7 +131,7 @@ struct Structure<S_ONE> {
     return true;
   }
   static constexpr int NE = 1;
-  __device__ __forceinline__ static void exps(const Coef& c, double dt, double (&e)[NE]) { e[0] = exp(-c.ke * dt); }
+  __device__ __forceinline__ static void exps(const Coef& c, double dt, double (&e)[NE]) { e[0] = pmx_exp(-c.ke * dt); }
   __device__ __forceinline__ static void from_exps(const Coef& c, const double (&e)[NE], Prop& p) {
     p.e = e[0];
     p.j = c.inv_ke * (1.0 - p.e);
@@ -132,8 +159,8 @@ struct Structure<S_ONE_ABS> {
   }
   static constexpr int NE = 2;
   __device__ __forceinline__ static void exps(const Coef& c, double dt, double (&e)[NE]) {
-    e[0] = exp(-c.ka * dt);
-    e[1] = exp(-c.ke * dt);
+    e[0] = pmx_exp(-c.ka * dt);
+    e[1] = pmx_exp(-c.ke * dt);
   }
   __device__ __forceinline__ static void from_exps(const Coef& c, const double (&e)[NE], Prop& p) {
     p.ea = e[0];
@@ -201,8 +228,8 @@ struct Structure<S_TWO> {
   __device__ __forceinline__ static bool prepare(const double* kp, Coef& c) { return c.t.prepare(kp[0], kp[1], kp[2]); }
   static constexpr int NE = 2;
   __device__ __forceinline__ static void exps(const Coef& c, double dt, double (&e)[NE]) {
-    e[0] = exp(-c.t.l1 * dt);
-    e[1] = exp(-c.t.l2 * dt);
+    e[0] = pmx_exp(-c.t.l1 * dt);
+    e[1] = pmx_exp(-c.t.l2 * dt);
   }
   __device__ __forceinline__ static void from_exps(const Coef& c, const double (&e)[NE], Prop& p) {
     p.p.make(c.t, e[0], e[1]);
@@ -240,9 +267,9 @@ struct Structure<S_TWO_ABS> {
   }
   static constexpr int NE = 3;
   __device__ __forceinline__ static void exps(const Coef& c, double dt, double (&e)[NE]) {
-    e[0] = exp(-c.t.l1 * dt);
-    e[1] = exp(-c.t.l2 * dt);
-    e[2] = exp(-c.ka * dt);
+    e[0] = pmx_exp(-c.t.l1 * dt);
+    e[1] = pmx_exp(-c.t.l2 * dt);
+    e[2] = pmx_exp(-c.ka * dt);
   }
   __device__ __forceinline__ static void from_exps(const Coef& c, const double (&e)[NE], Prop& p) {
     const double e1 = e[0];
@@ -370,7 +397,7 @@ __device__ __forceinline__ bool three_direct(double k10, double k12, double k13,
   double l[3];
   const bool ok = ThreeCore::eigen(k10, k12, k13, k21, k31, l);
   const double K = k10 + k12 + k13;
-  if constexpr (ABS) ea = exp(-ka * dt);
+  if constexpr (ABS) ea = pmx_exp(-ka * dt);
 #pragma unroll
   for (int k = 0; k < 9; ++k) p.m[k] = 0.0;
 #pragma unroll
@@ -384,7 +411,7 @@ __device__ __forceinline__ bool three_direct(double k10, double k12, double k13,
     const double lo1 = l[(i + 1) % 3], lo2 = l[(i + 2) % 3];
     const double inv = 1.0 / ((lo1 - li) * (lo2 - li));
     const double u = k21 - li, v = k31 - li, w = K - li;
-    const double e = exp(-(li * dt));
+    const double e = pmx_exp(-(li * dt));
     const double c0 = u * v * inv, c3 = k12 * v * inv, c6 = k13 * u * inv;
     p.m[0] = fma(c0, e, p.m[0]);
     p.m[1] = fma(k21 * v * inv, e, p.m[1]);
@@ -428,7 +455,7 @@ struct Structure<S_THREE> {
   static constexpr int NE = 3;
   __device__ __forceinline__ static void exps(const Coef& c, double dt, double (&e)[NE]) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) e[i] = exp(-(c.t.l[i] * dt));
+    for (int i = 0; i < 3; ++i) e[i] = pmx_exp(-(c.t.l[i] * dt));
   }
   __device__ __forceinline__ static void from_exps(const Coef& c, const double (&e)[NE], Prop& p) { p.p.make(c.t, e); }
   __device__ __forceinline__ static bool make_prop_dyn(const double* kp, double dt, Prop& p) {
@@ -473,8 +500,8 @@ struct Structure<S_THREE_ABS> {
   static constexpr int NE = 4;
   __device__ __forceinline__ static void exps(const Coef& c, double dt, double (&e4)[NE]) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) e4[i] = exp(-(c.t.l[i] * dt));
-    e4[3] = exp(-c.ka * dt);
+    for (int i = 0; i < 3; ++i) e4[i] = pmx_exp(-(c.t.l[i] * dt));
+    e4[3] = pmx_exp(-c.ka * dt);
   }
   __device__ __forceinline__ static void from_exps(const Coef& c, const double (&e4)[NE], Prop& p) {
     const double e[3] = {e4[0], e4[1], e4[2]};
@@ -500,7 +527,7 @@ struct Structure<S_THREE_ABS> {
   }
 };
 
-// make_prop = the exp() calls + the coefficient combination
+// make_prop = the pmx_exp() calls + the coefficient combination
 template <int ST>
 __device__ __forceinline__ void make_prop(const typename Structure<ST>::Coef& c, double dt, typename Structure<ST>::Prop& p) {
   double e[Structure<ST>::NE];
@@ -509,9 +536,9 @@ __device__ __forceinline__ void make_prop(const typename Structure<ST>::Coef& c,
 }
 
 // The exponential ladder: when a step's length is n x the previous step's (n = 2, 3, 4; sampling designs on
-// 0.5/1/2/4/8/12/24 h grids are exactly that), exp(-lambda n dt) = exp(-lambda dt)^n costs n-1 multiplies instead of
-// an exp() call.  Each rung multiplies the relative error of the previous one by n; the host caps the
-// cumulative factor (pmx_compile.cpp ladder_codes), which keeps the deviation from a fresh exp() below 1e-12.
+// 0.5/1/2/4/8/12/24 h grids are exactly that), pmx_exp(-lambda n dt) = pmx_exp(-lambda dt)^n costs n-1 multiplies instead of
+// an pmx_exp() call.  Each rung multiplies the relative error of the previous one by n; the host caps the
+// cumulative factor (pmx_compile.cpp ladder_codes), which keeps the deviation from a fresh pmx_exp() below 1e-12.
 template <int NE>
 __device__ __forceinline__ void ladder_pow(double (&e)[NE], uint32_t n) {
 #pragma unroll
