@@ -187,8 +187,9 @@ class Equation {
   ~Equation() {
     if (handle_) pmx_model_destroy(handle_);
   }
-  Equation(const Equation& o) : desc_(o.desc_), params_(o.params_), outputs_(o.outputs_), routes_(o.routes_),
-                                covariates_(o.covariates_), has_metadata_(o.has_metadata_) {}
+  Equation(const Equation& o) : desc_(o.desc_), source_(o.source_), has_init_(o.has_init_), params_(o.params_),
+                                outputs_(o.outputs_), routes_(o.routes_), covariates_(o.covariates_),
+                                has_metadata_(o.has_metadata_) {}
   Equation& operator=(const Equation&) = delete;
 
   Equation& with_nstates(int n) { desc_.nstates = n; return invalidate(); }
@@ -291,6 +292,27 @@ class Equation {
           !throw_on_pair_failure);
   }
 
+  /// log_likelihood_matrix(&eq, &data, &theta, &error_models, _) (likelihood/matrix.rs:52-106): ll is
+  /// [n_subjects x n_support] row-major.  `error_models[o]` = the model of output equation o (kind PMX_EM_NONE for
+  /// outputs without one); observed values come from the subjects' `observation(..)` events.
+  void log_likelihood_matrix(const Data& data, const std::vector<double>& theta, int64_t n_support,
+                             const std::vector<pmx_error_model>& error_models, int device, std::vector<double>* ll,
+                             std::vector<uint8_t>* status, bool throw_on_pair_failure = false) {
+    if (static_cast<int64_t>(theta.size()) != n_support * desc_.nparams)
+      throw Error(PMX_ERR_INVALID_ARGUMENT, "theta must hold n_support x nparams values");
+    if (static_cast<int>(error_models.size()) != desc_.nout)
+      throw Error(PMX_ERR_INVALID_ARGUMENT, "one error model per output equation");
+    Flat flat = flatten(data);
+    pmx_population* pop = nullptr;
+    pmx_population_desc d = flat.desc();
+    check(pmx_population_create(&d, device, &pop));
+    struct Guard { pmx_population* p; ~Guard() { pmx_population_destroy(p); } } guard{pop};
+    ll->assign(data.size() * static_cast<size_t>(n_support), std::numeric_limits<double>::quiet_NaN());
+    status->assign(data.size() * static_cast<size_t>(n_support), 0);
+    check(pmx_loglik(handle(), pop, error_models.data(), theta.data(), n_support, ll->data(), n_support, status->data()),
+          !throw_on_pair_failure);
+  }
+
   // Flattened population (the pmx_population_desc arrays), exposed for tests.
   struct Flat {
     std::vector<int64_t> subj_occ_off{0}, occ_ev_off{0}, cov_knot_off{0};
@@ -362,25 +384,35 @@ class Equation {
     desc_.nstates = desc_.ndrugs = desc_.nout = 5;  // Neqs::default (analytical/mod.rs:93)
     desc_.nparams = nparams;
     desc_.rk4_h_max = 0.02;
+    desc_.ode_solver = PMX_SOLVER_RK4;
+    desc_.ode_rtol = desc_.ode_atol = 1e-4;  // the reference's defaults (ode/mod.rs:126-127)
     for (int i = 0; i < PMX_MAX_STATES; ++i) desc_.init_param[i] = -1;
     for (int i = 0; i < PMX_MAX_INPUTS; ++i)
       desc_.lag_param[i] = desc_.fa_param[i] = desc_.bolus_dest[i] = desc_.infusion_dest[i] = -1;
   }
   pmx_model_desc desc_;
-
- private:
-  static bool is_numeric(const std::string& s) {
-    return !s.empty() && std::all_of(s.begin(), s.end(), [](char c) { return c >= '0' && c <= '9'; });
-  }
+  std::string source_;  // user ODE bodies (ODE::custom)
+  bool has_init_ = false;
   Equation& invalidate() {
     if (handle_) pmx_model_destroy(handle_);
     handle_ = nullptr;
     return *this;
   }
+
+ private:
+  static bool is_numeric(const std::string& s) {
+    return !s.empty() && std::all_of(s.begin(), s.end(), [](char c) { return c >= '0' && c <= '9'; });
+  }
   pmx_model* handle() {
-    if (!handle_) check(pmx_model_create(&desc_, &handle_));
+    if (!handle_) {
+      if (!source_.empty())
+        check(pmx_model_create_custom(&desc_, source_.c_str(), has_init_ ? 1 : 0, &handle_));
+      else
+        check(pmx_model_create(&desc_, &handle_));
+    }
     return handle_;
   }
+
   std::vector<std::string> params_, outputs_;
   std::vector<Route> routes_;
   std::vector<std::string> covariates_;
@@ -397,6 +429,20 @@ class Analytical : public Equation {
 class ODE : public Equation {
  public:
   ODE(int32_t model, int32_t nparams, double h_max = 0.02) : Equation(PMX_EQ_ODE, model, nparams) { desc_.rk4_h_max = h_max; }
+  /// ODE::new(diffeq, lag, fa, init, out) with USER bodies: `source` defines pmx_dynamics / pmx_outputs (/ pmx_init)
+  /// as described in pmx.h; the library compiles it for gfx950 with hiprtc.
+  static ODE custom(const std::string& source, int nstates, int nparams, int ndrugs = 1, int nout = 1, bool has_init = false,
+                    double h_max = 0.02) {
+    ODE m(PMX_ODE_CUSTOM, nparams, h_max);
+    m.with_nstates(nstates).with_ndrugs(ndrugs).with_nout(nout);
+    m.source_ = source;
+    m.has_init_ = has_init;
+    return m;
+  }
+  /// ODE::with_solver / with_tolerances (ode/mod.rs:134-166): PMX_SOLVER_RK4 (fixed step) | PMX_SOLVER_DOPRI5.
+  ODE& with_solver(int32_t solver) { desc_.ode_solver = solver; invalidate(); return *this; }
+  ODE& with_tolerances(double rtol, double atol) { desc_.ode_rtol = rtol; desc_.ode_atol = atol; invalidate(); return *this; }
+  ODE& with_step(double h_max) { desc_.rk4_h_max = h_max; invalidate(); return *this; }
 };
 
 }  // namespace equation

@@ -145,16 +145,87 @@ static void test_gpu_ode_dose_conservation() {
   CHECK(pr.predictions.size() == 1 && std::fabs(pr.predictions[0].prediction - 200.0) / 200.0 < 1e-4);
 }
 
+#define CHECK_CLOSE(a, b, rtol)                                                                      \
+  do {                                                                                               \
+    const double a_ = (a), b_ = (b);                                                                 \
+    if (!(std::fabs(a_ - b_) <= (rtol) * std::fmax(std::fabs(b_), 1e-300))) {                        \
+      std::printf("FAIL %s:%d  %s = %.17g, expected %.17g\n", __FILE__, __LINE__, #a, a_, b_);      \
+      ++failures;                                                                                    \
+    }                                                                                                \
+  } while (0)
+
+// user ODE bodies + adaptive solver + fused log-likelihood through the C++ facade, against the oracle / closed forms
+static const char* kOneCmtSrc = R"SRC(
+PMX_DEVICE void pmx_dynamics(double t, const double* x, const double* p, const double* cov, const double* rateiv,
+                             const double* derived, double* dx) { dx[0] = -p[0] * x[0] + rateiv[0]; }
+PMX_DEVICE void pmx_outputs(double t, const double* x, const double* p, const double* cov, const double* rateiv,
+                            const double* derived, double* y) { y[0] = x[0] / p[1]; }
+)SRC";
+
+static void test_custom_source_compiles_without_gpu() {
+  // hiprtc needs no device: creation compiles the source; a typo comes back with the compiler's message
+  pmx_model_desc d{};
+  d.eq_kind = PMX_EQ_ODE;
+  d.kernel = PMX_ODE_CUSTOM;
+  d.nstates = 1; d.ndrugs = 1; d.nout = 1; d.nparams = 2; d.rk4_h_max = 0.02;
+  d.ode_rtol = d.ode_atol = 1e-4;
+  for (int i = 0; i < PMX_MAX_STATES; ++i) d.init_param[i] = -1;
+  for (int i = 0; i < PMX_MAX_INPUTS; ++i) d.lag_param[i] = d.fa_param[i] = d.bolus_dest[i] = d.infusion_dest[i] = -1;
+  pmx_model* m = nullptr;
+  CHECK(pmx_model_create_custom(&d, kOneCmtSrc, 0, &m) == PMX_OK);
+  pmx_model_destroy(m);
+  std::string bad = kOneCmtSrc;
+  bad.replace(bad.find("x[0] +"), 6, "q[0] +");
+  CHECK(pmx_model_create_custom(&d, bad.c_str(), 0, &m) == PMX_ERR_INVALID_ARGUMENT);
+  CHECK(std::string(pmx_last_error()).find("undeclared identifier 'q'") != std::string::npos);
+}
+
+static void test_gpu_custom_ode_dopri5_and_loglik() {
+  ODE m = ODE::custom(kOneCmtSrc, 1, 2);
+  m.with_step(4.0).with_solver(PMX_SOLVER_DOPRI5).with_tolerances(1e-9, 1e-9);
+  Subject s = Subject::builder("c").bolus(0.0, 100.0, 0).observation(1.0, 7.5, 0).observation(4.0, 4.0, 0)
+                  .missing_observation(8.0, 0).build();
+  const double ke = 0.2, v = 10.0;
+  auto pred = m.estimate_predictions(s, Parameters::dense({ke, v})).flat_predictions();
+  CHECK(pred.size() == 3);
+  for (size_t i = 0; i < 3; ++i) {
+    const double t = (i == 0 ? 1.0 : (i == 1 ? 4.0 : 8.0));
+    CHECK_CLOSE(pred[i], 100.0 / v * std::exp(-ke * t), 1e-7);
+  }
+  // log-likelihood: additive error, sigma^2 = (0.1 + 0.1 y)^2 + 0.2^2, the missing observation contributes nothing
+  std::vector<pmx_error_model> em(1);
+  em[0].kind = PMX_EM_ADDITIVE;
+  em[0].reserved = 0;
+  em[0].c[0] = 0.1; em[0].c[1] = 0.1; em[0].c[2] = 0.0; em[0].c[3] = 0.0;
+  em[0].scalar = 0.2;
+  std::vector<double> ll;
+  std::vector<uint8_t> st;
+  m.log_likelihood_matrix({s}, {ke, v, 0.3, 12.0}, 2, em, 0, &ll, &st);
+  CHECK(ll.size() == 2 && st[0] == 0 && st[1] == 0);
+  auto lnpdf = [](double obs, double p, double sig) {
+    return -0.5 * 1.8378770664093453 - std::log(sig) - (obs - p) * (obs - p) / (2.0 * sig * sig);
+  };
+  for (int k = 0; k < 2; ++k) {
+    const double kk = k ? 0.3 : ke, vv = k ? 12.0 : v;
+    const double p1 = 100.0 / vv * std::exp(-kk * 1.0), p4 = 100.0 / vv * std::exp(-kk * 4.0);
+    const double want = lnpdf(7.5, p1, std::sqrt(std::pow(0.1 + 0.75, 2) + 0.04)) +
+                        lnpdf(4.0, p4, std::sqrt(std::pow(0.1 + 0.4, 2) + 0.04));
+    CHECK_CLOSE(ll[static_cast<size_t>(k)], want, 1e-6);
+  }
+}
+
 int main(int argc, char** argv) {
   const std::string mode = argc > 1 ? argv[1] : "cpu";
   try {
     test_builder_and_sort();
     test_labels_and_parameters();
     test_compile_without_gpu();
+    test_custom_source_compiles_without_gpu();
     if (mode == "gpu") {
       test_gpu_readme();
       test_gpu_two_compartment_matrix_vs_oracle();
       test_gpu_ode_dose_conservation();
+      test_gpu_custom_ode_dopri5_and_loglik();
     } else {
       // no device: the facade must fail loudly, never fall back to a CPU path
       bool threw = false;
