@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <memory>
 #include <map>
 #include <mutex>
@@ -72,7 +73,7 @@ struct DeviceStream {
     const int64_t* d_chunk_obs_off = nullptr;
     bool any_censored = false;
   };
-  std::vector<LLCache> ll_cache;
+  std::deque<LLCache> ll_cache;  // (deque: entries handed out by pointer must survive later push_backs)
   std::vector<void*> allocs;
   int32_t max_input_used = -1;
   int64_t n_ops = 0, n_prop = 0;

@@ -498,3 +498,61 @@ def test_small_support_grids_pick_the_measured_lane_mapping():
     for n, kernel in ((20, "pmx_analytical_pair"), (47, "pmx_analytical_pair"), (48, "pmx_analytical_grid"),
                       (100, "pmx_analytical_grid"), (130, "pmx_analytical_grid")):
         assert_parity(mr, fr, synth.theta_c3(n), TOL_ANALYTICAL, expect_kernel=kernel)
+
+
+def test_handles_are_shared_by_concurrent_host_threads():
+    """`Equation: Sync` (equation/mod.rs:377): the reference calls one model from many rayon threads.  Eight host threads
+    share one model handle and one population handle (first use races on the lazily built op stream / class plan /
+    log-likelihood tables / hiprtc module) and must all get the single-threaded answer."""
+    import threading
+
+    import torch
+
+    from pharmsol_amd import AssayErrorModel, AssayErrorModels, ErrorPoly
+
+    rng = np.random.default_rng(7)
+    m, flat, theta = synth.config_c3(96, 64)
+    vals = rng.uniform(1, 9, flat.n_observations)
+    flat.ev_value = flat.ev_value.copy()
+    flat.ev_value[flat.ev_kind == _abi.PMX_EV_OBSERVATION] = vals
+    em = AssayErrorModels.empty().add(0, AssayErrorModel.additive(ErrorPoly(0.05, 0.1, 0.0, 0.0), 0.1))
+    src = '''
+PMX_DEVICE void pmx_dynamics(double t, const double* x, const double* p, const double* cov, const double* rateiv,
+                             const double* derived, double* dx) {
+  dx[0] = -(p[0] + p[1]) * x[0] + p[2] * x[1] + rateiv[0];
+  dx[1] = p[1] * x[0] - p[2] * x[1];
+}
+PMX_DEVICE void pmx_outputs(double t, const double* x, const double* p, const double* cov, const double* rateiv,
+                            const double* derived, double* y) { y[0] = x[0] / p[3]; }
+'''
+    from pharmsol_amd import ODE
+
+    mc = ODE.custom(src, nstates=2, nparams=4, h_max=0.05)
+    pop = runtime.DevicePopulation(flat, 0)
+    thetas = [synth.theta_c3(64, synth.SplitMix64(100 + i)) for i in range(8)]
+    results, errors = [None] * 8, []
+
+    def work(i):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                p, _ = runtime.predict(m, pop, thetas[i])
+                ll, _ = runtime.loglik(m, pop, em, thetas[i])
+                pc, _ = runtime.predict(mc, pop, thetas[i])
+            stream.synchronize()
+            results[i] = (p.cpu().numpy(), ll.cpu().numpy(), pc.cpu().numpy())
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(8):
+        want, _ = oracle.predict(m, flat, thetas[i])
+        wll, _ = oracle.loglik(m, flat, em, thetas[i])
+        assert rel_err(results[i][0], want).max() < TOL_ANALYTICAL
+        assert (np.abs(results[i][1] - wll) / np.maximum(np.abs(wll), 1.0)).max() < 1e-9
+        assert rel_err(results[i][2], want).max() < 1e-4  # the same two-compartment system through RK4 (h <= 0.05)
