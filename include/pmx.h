@@ -337,7 +337,12 @@ void pmx_free_text(char* text);
  *   ll   [n_subjects x ld_ll], ll[s*ld_ll + p]  (the reference's Array2 (n_subjects, n_support); it stores
  *        that matrix column-major, matrix.rs:60 — same logical matrix, support point fastest here)
  *   status [n_subjects x n_support] as for pmx_predict; a non-finite sum sets PMX_PAIR_NONFINITE
- *        (PharmsolError::NonFiniteLikelihood, prediction.rs:119-124) */
+ *        (PharmsolError::NonFiniteLikelihood, prediction.rs:119-124)
+ * The sigma terms are derived from `em` on the device, stream-ordered before the kernel (changing the error model
+ * between calls costs two small kernels, no host pass and no upload).  MissingErrorModel is reported by both
+ * forms (PMX_ERR_ERROR_MODEL).  An invalid sigma (NegativeSigma / NonFiniteSigma, error_model.rs:1073-1077) is
+ * found on the device: pmx_loglik returns PMX_ERR_ERROR_MODEL; pmx_loglik_device cannot fail after the fact, the
+ * affected subjects' rows come back NaN with PMX_PAIR_NONFINITE. */
 int32_t pmx_loglik(const pmx_model* model, const pmx_population* pop, const pmx_error_model* em,
                    const double* theta, int64_t n_support, double* ll, int64_t ld_ll, uint8_t* status);
 int32_t pmx_loglik_device(const pmx_model* model, const pmx_population* pop, const pmx_error_model* em,

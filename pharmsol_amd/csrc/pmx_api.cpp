@@ -65,20 +65,32 @@ struct DeviceStream {
   std::vector<int64_t> h_chunk_row;      // [n_chunks*G]
   std::vector<int32_t> h_chunk_nobs;     // [n_chunks] observations per member of the chunk's class
   std::vector<int32_t> h_chunk_n;        // [n_chunks] live members
-  // per error-model cache of the sigma terms (they depend on (population, error model) only)
+  // Sigma tables of the log-likelihood, per set of error models.  They are filled ON THE DEVICE
+  // (pmx_kernels.hip pmx_ll_prepare_*), stream-ordered before the kernel that reads them: an optimiser that changes
+  // gamma / lambda every call pays two ~10 us kernels, not a host pass over every observation plus a 40 MB upload.
+  // A small LRU of slots; uses of one slot are chained through its event so that a slot is never rewritten while a
+  // kernel on another stream still reads it.
   struct LLCache {
     std::vector<pmx_error_model> em;
-    const double* d_obs = nullptr;        // [n_obs][4]
-    const double* d_cobs = nullptr;       // classed blocks
-    const int64_t* d_chunk_obs_off = nullptr;
-    bool any_censored = false;
+    double* d_obs = nullptr;   // [n_obs][4]
+    double* d_cobs = nullptr;  // classed blocks
+    int32_t* d_err = nullptr;  // invalid-sigma counter of the last fill
+    hipEvent_t ev = nullptr;   // last use (fill or read) of this slot
+    int64_t stamp = 0;         // LRU
+    int32_t host_users = 0;    // host threads between "picked" and "launched"
   };
-  std::deque<LLCache> ll_cache;  // (deque: entries handed out by pointer must survive later push_backs)
+  std::deque<LLCache> ll_cache;  // (deque: slots handed out by pointer must survive later push_backs)
+  int64_t ll_stamp = 0;
+  const int32_t* d_chunk_nobs = nullptr;     // [n_chunks]
+  const int64_t* d_chunk_obs_off = nullptr;  // [n_chunks] offsets into a slot's cobs
+  int64_t cobs_size = 0;
   std::vector<void*> allocs;
   int32_t max_input_used = -1;
   int64_t n_ops = 0, n_prop = 0;
   ~DeviceStream() {
     for (void* p : allocs) (void)hipFree(p);
+    for (auto& c : ll_cache)
+      if (c.ev) (void)hipEventDestroy(c.ev);
   }
 };
 
@@ -109,6 +121,18 @@ struct pmx_population {
   int device = 0;
   pmx::HostPopulation hp;
   std::mutex mu;
+  // what the log-likelihood tables are computed from, uploaded at the first pmx_loglik* call
+  bool ll_ready = false;
+  const double* d_obs_y = nullptr;
+  const int32_t* d_obs_outeq = nullptr;
+  const double* d_obs_poly = nullptr;
+  const int8_t* d_obs_cens = nullptr;
+  uint32_t valued_outeq_mask = 0;  // bit q: some observation on output q carries a value
+  bool any_censored = false;
+  std::vector<void*> ll_allocs;
+  ~pmx_population() {
+    for (void* p : ll_allocs) (void)hipFree(p);
+  }
   std::vector<std::unique_ptr<DeviceStream>> streams;  // one per model flavour, built lazily
 };
 
@@ -469,6 +493,17 @@ int32_t get_stream(pmx_population* pop, const pmx::CompileKey& key, DeviceStream
         for (int64_t o = cp.cls_prog_off[cl]; o < cp.cls_prog_off[cl + 1]; ++o) nobs += (cp.prog_meta[static_cast<size_t>(o)] >> 24) & 1u;
         ds->h_chunk_nobs[static_cast<size_t>(c)] = nobs;
       }
+      {  // where each chunk's [observation][value|const|weight][G] block starts in a slot's cobs
+        std::vector<int64_t> off(static_cast<size_t>(cp.n_chunks));
+        int64_t at = 0;
+        for (int64_t c = 0; c < cp.n_chunks; ++c) {
+          off[static_cast<size_t>(c)] = at;
+          at += static_cast<int64_t>(ds->h_chunk_nobs[static_cast<size_t>(c)]) * 3 * cp.G;
+        }
+        ds->cobs_size = at;
+        if ((rc = upload(ds->h_chunk_nobs, &ds->d_chunk_nobs, &ds->allocs)) != PMX_OK) return rc;
+        if ((rc = upload(off, &ds->d_chunk_obs_off, &ds->allocs)) != PMX_OK) return rc;
+      }
       ds->cls.n_chunks = cp.n_chunks;
       ds->cls.n_generic = static_cast<int64_t>(cp.generic_subjects.size());
       ds->cls.G = cp.G;
@@ -480,93 +515,106 @@ int32_t get_stream(pmx_population* pop, const pmx::CompileKey& key, DeviceStream
   return PMX_OK;
 }
 
-// Sigma terms of every observation for one error-model set (AssayErrorModel::sigma, error_model.rs:1045-1080;
-// lognormpdf's sigma-only parts, distributions.rs:31-34), cached per (population flavour, error models).
-int32_t get_ll_cache(const pmx_model* model, pmx_population* pop, DeviceStream* ds, const pmx_error_model* em,
-                     const DeviceStream::LLCache** out) {
-  constexpr double kLog2Pi = 1.8378770664093453;  // distributions.rs:12
+// Pick (or fill) the slot holding the sigma tables for `em`.  On return the slot is pinned (host_users) and `stream`
+// is ordered after the slot's last use; the caller launches its kernel and then calls release_ll_slot.
+int32_t acquire_ll_slot(const pmx_model* model, pmx_population* pop, DeviceStream* ds, const pmx_error_model* em,
+                        void* stream, DeviceStream::LLCache** out) {
   const int nout = model->d.nout;
-  std::lock_guard<std::mutex> lock(pop->mu);
-  for (const auto& c : ds->ll_cache)
-    if (static_cast<int>(c.em.size()) == nout && std::memcmp(c.em.data(), em, sizeof(pmx_error_model) * nout) == 0) {
-      *out = &c;
-      return PMX_OK;
-    }
   const auto& hp = pop->hp;
-  std::vector<double> obs4(static_cast<size_t>(hp.n_obs) * 4, 0.0);
-  bool any_censored = false;
-  for (int64_t r = 0; r < hp.n_obs; ++r) {
-    const double y = hp.obs_value[static_cast<size_t>(r)];
-    if (std::isnan(y)) continue;  // observation is None: weight 0
-    const int q = hp.obs_outeq[static_cast<size_t>(r)];
+  std::lock_guard<std::mutex> lock(pop->mu);
+  if (!pop->ll_ready) {  // observation-side inputs, once per population
+    int32_t rc;
+    std::vector<int32_t> oq(hp.obs_outeq.begin(), hp.obs_outeq.end());
+    if ((rc = upload(hp.obs_value, &pop->d_obs_y, &pop->ll_allocs)) != PMX_OK) return rc;
+    if ((rc = upload(oq, &pop->d_obs_outeq, &pop->ll_allocs)) != PMX_OK) return rc;
+    if ((rc = upload(hp.obs_errorpoly, &pop->d_obs_poly, &pop->ll_allocs)) != PMX_OK) return rc;
+    if ((rc = upload(hp.obs_censor, &pop->d_obs_cens, &pop->ll_allocs)) != PMX_OK) return rc;
+    for (int64_t r = 0; r < hp.n_obs; ++r) {
+      if (std::isnan(hp.obs_value[static_cast<size_t>(r)])) continue;
+      const int q = hp.obs_outeq[static_cast<size_t>(r)];
+      if (q >= 0 && q < 32) pop->valued_outeq_mask |= (1u << q);
+      if (!hp.obs_censor.empty() && hp.obs_censor[static_cast<size_t>(r)] != PMX_CENSOR_NONE) pop->any_censored = true;
+    }
+    pop->ll_ready = true;
+  }
+  for (int q = 0; q < 32; ++q) {
+    if (!((pop->valued_outeq_mask >> q) & 1u)) continue;
     if (q >= nout) return fail(PMX_ERR_OUTEQ_OUT_OF_RANGE, "observation outeq >= nout");
-    const pmx_error_model& e = em[q];
-    // the observation's own polynomial wins over the model's (error_model.rs:1051-1054)
-    const double* poly = e.c;
-    if (!hp.obs_errorpoly.empty() && !std::isnan(hp.obs_errorpoly[static_cast<size_t>(r) * 4]))
-      poly = &hp.obs_errorpoly[static_cast<size_t>(r) * 4];
-    const double alpha = poly[0] + poly[1] * y + poly[2] * (y * y) + poly[3] * (y * y * y);
-    double sigma;
-    if (e.kind == PMX_EM_ADDITIVE) sigma = std::sqrt(alpha * alpha + e.scalar * e.scalar);
-    else if (e.kind == PMX_EM_PROPORTIONAL) sigma = e.scalar * alpha;
-    else return fail(PMX_ERR_ERROR_MODEL, "MissingErrorModel: output " + std::to_string(q) + " has observations but no error model");
-    if (sigma < 0.0) return fail(PMX_ERR_ERROR_MODEL, "NegativeSigma");
-    if (!std::isfinite(sigma)) return fail(PMX_ERR_ERROR_MODEL, "NonFiniteSigma");
-    obs4[static_cast<size_t>(r) * 4 + 0] = y;
-    obs4[static_cast<size_t>(r) * 4 + 1] = -0.5 * kLog2Pi - std::log(sigma);
-    obs4[static_cast<size_t>(r) * 4 + 2] = 1.0 / (2.0 * sigma * sigma);
-    // censored rows: +-1/(sigma sqrt 2), the scale of statrs' Normal::cdf = 0.5 erfc((mean - x)/(sigma sqrt 2));
-    // sign = which tail (distributions.rs:52-103).  0 = uncensored.
-    const int8_t cz = hp.obs_censor.empty() ? int8_t(PMX_CENSOR_NONE) : hp.obs_censor[static_cast<size_t>(r)];
-    if (cz != PMX_CENSOR_NONE) {
-      if (!(sigma > 0.0)) return fail(PMX_ERR_ERROR_MODEL, "NegativeSigma: a censored observation needs sigma > 0 (Normal::new)");
-      obs4[static_cast<size_t>(r) * 4 + 3] = (cz == PMX_CENSOR_BLOQ ? 1.0 : -1.0) / (sigma * 1.4142135623730951);
-      any_censored = true;
-    }
+    if (em[q].kind != PMX_EM_ADDITIVE && em[q].kind != PMX_EM_PROPORTIONAL)
+      return fail(PMX_ERR_ERROR_MODEL, "MissingErrorModel: output " + std::to_string(q) + " has observations but no error model");
   }
-  DeviceStream::LLCache c;
-  c.any_censored = any_censored;
-  c.em.assign(em, em + nout);
-  int32_t rc;
-  if ((rc = upload(obs4, &c.d_obs, &ds->allocs)) != PMX_OK) return rc;
-  if (ds->cls.n_chunks > 0) {  // classed blocks: per chunk [observation k][value | const | weight][G]
-    const int G = ds->cls.G;
-    std::vector<int64_t> off(static_cast<size_t>(ds->cls.n_chunks));
-    std::vector<double> cobs;
-    for (int64_t ch = 0; ch < ds->cls.n_chunks; ++ch) {
-      off[static_cast<size_t>(ch)] = static_cast<int64_t>(cobs.size());
-      const int32_t nobs = ds->h_chunk_nobs[static_cast<size_t>(ch)];
-      const size_t base = cobs.size();
-      cobs.resize(base + static_cast<size_t>(nobs) * 3 * G, 0.0);
-      for (int j = 0; j < G; ++j) {
-        const int64_t row0 = ds->h_chunk_row[static_cast<size_t>(ch * G + j)];
-        // padding members have row 0 and must stay weight 0: recognise them through chunk_n at launch time instead
-        for (int32_t k = 0; k < nobs; ++k) {
-          const size_t r = static_cast<size_t>(row0 + k);
-          for (int f = 0; f < 3; ++f) cobs[base + (static_cast<size_t>(k) * 3 + f) * G + j] = obs4[r * 4 + f];
-        }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  DeviceStream::LLCache* slot = nullptr;
+  for (auto& c : ds->ll_cache)
+    if (static_cast<int>(c.em.size()) == nout && std::memcmp(c.em.data(), em, sizeof(pmx_error_model) * nout) == 0) {
+      slot = &c;
+      break;
+    }
+  const bool hit = slot != nullptr;
+  if (!hit) {
+    constexpr size_t kSlots = 4;
+    if (ds->ll_cache.size() >= kSlots)  // least recently used slot nobody is about to launch on
+      for (auto& c : ds->ll_cache)
+        if (c.host_users == 0 && (slot == nullptr || c.stamp < slot->stamp)) slot = &c;
+    if (slot == nullptr) {
+      ds->ll_cache.emplace_back();
+      slot = &ds->ll_cache.back();
+      void* p = nullptr;
+      PMX_HIP(hipMalloc(&p, static_cast<size_t>(hp.n_obs > 0 ? hp.n_obs : 1) * 4 * sizeof(double)));
+      ds->allocs.push_back(p);
+      slot->d_obs = static_cast<double*>(p);
+      if (ds->cobs_size > 0) {
+        PMX_HIP(hipMalloc(&p, static_cast<size_t>(ds->cobs_size) * sizeof(double)));
+        ds->allocs.push_back(p);
+        slot->d_cobs = static_cast<double*>(p);
       }
+      PMX_HIP(hipMalloc(&p, sizeof(int32_t)));
+      ds->allocs.push_back(p);
+      slot->d_err = static_cast<int32_t*>(p);
+      PMX_HIP(hipEventCreateWithFlags(&slot->ev, hipEventDisableTiming));
+      PMX_HIP(hipEventRecord(slot->ev, st));
     }
-    // zero the padding members (they alias row 0)
-    {
-      const std::vector<int32_t>& n_live = ds->h_chunk_n;
-      for (int64_t ch = 0; ch < ds->cls.n_chunks; ++ch)
-        for (int j = n_live[static_cast<size_t>(ch)]; j < G; ++j)
-          for (int32_t k = 0; k < ds->h_chunk_nobs[static_cast<size_t>(ch)]; ++k)
-            for (int f = 0; f < 3; ++f) cobs[static_cast<size_t>(off[static_cast<size_t>(ch)]) + (static_cast<size_t>(k) * 3 + f) * G + j] = 0.0;
-    }
-    if ((rc = upload(cobs, &c.d_cobs, &ds->allocs)) != PMX_OK) return rc;
-    if ((rc = upload(off, &c.d_chunk_obs_off, &ds->allocs)) != PMX_OK) return rc;
   }
-  ds->ll_cache.push_back(std::move(c));
-  *out = &ds->ll_cache.back();
+  PMX_HIP(hipStreamWaitEvent(st, slot->ev, 0));  // after the slot's last fill / read, whatever stream that was on
+  if (!hit) {
+    slot->em.assign(em, em + nout);
+    pmx::LLPrepareArgs a{};
+    a.obs_y = pop->d_obs_y;
+    a.obs_outeq = pop->d_obs_outeq;
+    a.obs_poly = pop->d_obs_poly;
+    a.obs_cens = pop->d_obs_cens;
+    for (int q = 0; q < PMX_MAX_OUT; ++q) a.em[q] = q < nout ? em[q] : pmx_error_model{};
+    a.n_obs = hp.n_obs;
+    a.obs4 = slot->d_obs;
+    a.err = slot->d_err;
+    a.chunk_row = ds->cls.chunk_row;
+    a.chunk_n = ds->cls.chunk_n;
+    a.chunk_nobs = ds->d_chunk_nobs;
+    a.chunk_obs_off = ds->d_chunk_obs_off;
+    a.n_chunks = ds->cobs_size > 0 ? ds->cls.n_chunks : 0;
+    a.G = ds->cls.G;
+    a.cobs = slot->d_cobs;
+    a.stream = stream;
+    PMX_HIP(hipMemsetAsync(slot->d_err, 0, sizeof(int32_t), st));
+    PMX_HIP(pmx::launch_ll_prepare(a));
+  }
+  slot->stamp = ++ds->ll_stamp;
+  slot->host_users++;
+  *out = slot;
   return PMX_OK;
+}
+
+void release_ll_slot(pmx_population* pop, DeviceStream::LLCache* slot, void* stream) {
+  std::lock_guard<std::mutex> lock(pop->mu);
+  (void)hipEventRecord(slot->ev, static_cast<hipStream_t>(stream));
+  slot->host_users--;
 }
 
 struct LLRequest {
   const pmx_error_model* em = nullptr;
   double* d_ll = nullptr;
   int64_t ld = 0;
+  const int32_t** d_sigma_err = nullptr;  // out (host form): the slot's invalid-sigma counter
 };
 
 int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_theta, int64_t P, int batch,
@@ -629,16 +677,25 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
   a.stream = stream;
   a.cls = ds->cls;
   a.use_classes = ds->cls.n_chunks > 0 ? 1 : 0;
+  DeviceStream::LLCache* slot = nullptr;
+  struct SlotGuard {  // the slot is released (event recorded on the stream) however this function leaves
+    pmx_population* pop;
+    DeviceStream::LLCache** slot;
+    void* stream;
+    ~SlotGuard() {
+      if (*slot) release_ll_slot(pop, *slot, stream);
+    }
+  } slot_guard{pop, &slot, stream};
   if (llreq != nullptr) {
-    const DeviceStream::LLCache* lc = nullptr;
-    rc = get_ll_cache(model, pop, ds, llreq->em, &lc);
+    rc = acquire_ll_slot(model, pop, ds, llreq->em, stream, &slot);
     if (rc != PMX_OK) return rc;
-    a.ops.ll_obs = lc->d_obs;
+    a.ops.ll_obs = slot->d_obs;
     a.ops.ll_out = llreq->d_ll;
     a.ops.ll_ld = llreq->ld;
-    a.cls.cobs = lc->d_cobs;
-    a.cls.chunk_obs_off = lc->d_chunk_obs_off;
-    if (lc->any_censored) a.use_classes = 0;  // the classed blocks carry {value, const, weight} only: censored rows take the generic walk
+    a.cls.cobs = slot->d_cobs;
+    a.cls.chunk_obs_off = ds->d_chunk_obs_off;
+    if (llreq->d_sigma_err) *llreq->d_sigma_err = slot->d_err;
+    if (pop->any_censored) a.use_classes = 0;  // the classed blocks carry {value, const, weight} only: censored rows take the generic walk
   }
   // GRID (lane = support point, wave-uniform op stream) vs PAIR (lane = pair, divergent streams): measured crossovers
   // (tools/pairgrid_sweep.sh) are 8 support points when the classed kernel serves most subjects, ~48 when every
@@ -888,10 +945,17 @@ int32_t pmx_loglik(const pmx_model* model, const pmx_population* cpop, const pmx
   PMX_HIP(hipMalloc(reinterpret_cast<void**>(&d_status), st_bytes > 0 ? st_bytes : 8));
   PMX_HIP(hipMemcpy(d_theta, theta, theta_bytes, hipMemcpyHostToDevice));
   PMX_HIP(hipMemcpy(d_ll, ll, ll_bytes, hipMemcpyHostToDevice));  // keeps the caller's padding columns
-  LLRequest req{em, d_ll, ld_ll};
+  const int32_t* d_sigma_err = nullptr;
+  LLRequest req{em, d_ll, ld_ll, &d_sigma_err};
   int32_t rc = enqueue(model, pop, d_theta, n_support, 0, d_ll, ld_ll, d_status, nullptr, &req);
   if (rc != PMX_OK) return rc;
   PMX_HIP(hipDeviceSynchronize());
+  if (d_sigma_err) {  // ErrorModelError::NegativeSigma / NonFiniteSigma (error_model.rs:1073-1077), found on the device
+    int32_t n_bad = 0;
+    PMX_HIP(hipMemcpy(&n_bad, d_sigma_err, sizeof n_bad, hipMemcpyDeviceToHost));
+    if (n_bad > 0)
+      return fail(PMX_ERR_ERROR_MODEL, "NegativeSigma / NonFiniteSigma for " + std::to_string(n_bad) + " observation(s)");
+  }
   PMX_HIP(hipMemcpy(ll, d_ll, ll_bytes, hipMemcpyDeviceToHost));
   std::vector<uint8_t> hst(st_bytes);
   PMX_HIP(hipMemcpy(hst.data(), d_status, st_bytes, hipMemcpyDeviceToHost));

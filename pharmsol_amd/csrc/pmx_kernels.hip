@@ -879,6 +879,77 @@ hipError_t launch_analytical_k(const LaunchArgs& a, const char** name) {
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------
+// log-likelihood tables (one thread per observation / per chunk slot)
+// ------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void pmx_ll_prepare_obs(LLPrepareArgs a) {
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (r >= a.n_obs) return;
+  double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+  const double y = a.obs_y[r];
+  if (y == y) {  // a valued observation (missing ones keep weight 0)
+    const int q = a.obs_outeq[r];
+    const pmx_error_model& e = a.em[q < PMX_MAX_OUT ? q : 0];
+    double c0 = e.c[0], c1 = e.c[1], c2 = e.c[2], c3 = e.c[3];
+    if (a.obs_poly != nullptr) {  // the observation's own polynomial wins (error_model.rs:1051-1054)
+      const double p0 = a.obs_poly[r * 4];
+      if (p0 == p0) {
+        c0 = p0;
+        c1 = a.obs_poly[r * 4 + 1];
+        c2 = a.obs_poly[r * 4 + 2];
+        c3 = a.obs_poly[r * 4 + 3];
+      }
+    }
+    const double alpha = c0 + c1 * y + c2 * (y * y) + c3 * (y * y * y);
+    const double sigma = (e.kind == PMX_EM_ADDITIVE) ? sqrt(alpha * alpha + e.scalar * e.scalar) : e.scalar * alpha;
+    const int cz = a.obs_cens != nullptr ? a.obs_cens[r] : 0;
+    const bool bad = !(sigma >= 0.0) || !isfinite(sigma) || (cz != 0 && !(sigma > 0.0));
+    q0 = y;
+    q1 = -0.5 * 1.8378770664093453 - log(sigma);
+    q2 = 1.0 / (2.0 * sigma * sigma);
+    q3 = (cz == 0) ? 0.0 : ((cz > 0 ? 1.0 : -1.0) / (sigma * 1.4142135623730951));
+    if (bad) {  // NegativeSigma / NonFiniteSigma: the row (and so the subject's sum) becomes NaN
+      q1 = __longlong_as_double(0x7ff8000000000000LL);
+      q2 = 1.0;
+      atomicAdd(a.err, 1);
+    }
+  }
+  a.obs4[r * 4 + 0] = q0;
+  a.obs4[r * 4 + 1] = q1;
+  a.obs4[r * 4 + 2] = q2;
+  a.obs4[r * 4 + 3] = q3;
+}
+
+// cobs[chunk][k][f][j] = obs4[chunk_row[chunk][j] + k][f] for live members, 0 for padding
+__global__ __launch_bounds__(256) void pmx_ll_prepare_chunks(LLPrepareArgs a) {
+  const int64_t ch = blockIdx.x;
+  if (ch >= a.n_chunks) return;
+  const int32_t nobs = a.chunk_nobs[ch], n_live = a.chunk_n[ch];
+  const int64_t base = a.chunk_obs_off[ch];
+  const int32_t total = nobs * 3 * a.G;
+  for (int32_t i = threadIdx.x; i < total; i += 256) {
+    const int32_t j = i % a.G, f = (i / a.G) % 3, k = i / (3 * a.G);
+    double v = 0.0;
+    if (j < n_live) v = a.obs4[(a.chunk_row[ch * a.G + j] + k) * 4 + f];
+    a.cobs[base + i] = v;
+  }
+}
+}  // namespace
+
+hipError_t launch_ll_prepare(const LLPrepareArgs& a) {
+  hipStream_t st = static_cast<hipStream_t>(a.stream);
+  if (a.n_obs > 0) {
+    hipLaunchKernelGGL(pmx_ll_prepare_obs, dim3(static_cast<uint32_t>((a.n_obs + 255) / 256)), dim3(256), 0, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  if (a.n_chunks > 0) {
+    hipLaunchKernelGGL(pmx_ll_prepare_chunks, dim3(static_cast<uint32_t>(a.n_chunks)), dim3(256), 0, st, a);
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_predict(const LaunchArgs& a, const char** name) {
   if (a.S <= 0 || (a.P <= 0 && !a.batch)) return hipSuccess;
   if (a.m.eq_kind == PMX_EQ_ANALYTICAL) {

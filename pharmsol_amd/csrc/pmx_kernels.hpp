@@ -53,6 +53,32 @@ struct LaunchArgs {
   void* stream;
 };
 
+// Sigma terms of every observation for one set of error models, computed on the device (AssayErrorModel::sigma,
+// error_model.rs:1045-1080; the sigma-only parts of lognormpdf / lognormcdf, distributions.rs:31-103): fills
+// obs4[n_obs][4] = {y, -0.5 ln(2 pi) - ln sigma, 1/(2 sigma^2), +-1/(sigma sqrt 2) | 0} and, for a class plan,
+// the per-chunk [observation k][value | const | weight][G] blocks.  An invalid sigma (negative, non-finite, or not
+// positive on a censored row) poisons that row with NaN and bumps *err.
+struct LLPrepareArgs {
+  const double* obs_y;        // [n_obs] observed value, NaN = missing
+  const int32_t* obs_outeq;   // [n_obs]
+  const double* obs_poly;     // [n_obs*4] or nullptr: the observation's own ErrorPoly (c0 NaN = none)
+  const int8_t* obs_cens;     // [n_obs] or nullptr
+  pmx_error_model em[PMX_MAX_OUT];
+  int64_t n_obs;
+  double* obs4;
+  int32_t* err;
+  // classed blocks (n_chunks == 0: none)
+  const int64_t* chunk_row;
+  const int32_t* chunk_n;
+  const int32_t* chunk_nobs;
+  const int64_t* chunk_obs_off;
+  int64_t n_chunks;
+  int32_t G;
+  double* cobs;
+  void* stream;
+};
+hipError_t launch_ll_prepare(const LLPrepareArgs& a);
+
 // Enqueue the prediction kernel; *name receives a static string naming the kernel family.
 hipError_t launch_predict(const LaunchArgs& a, const char** name);
 

@@ -195,3 +195,32 @@ def test_censored_tail_far_from_the_prediction():
     assert (st[2] == _abi.PMX_PAIR_NONFINITE).all() and (st[:2] == 0).all()
     np.testing.assert_allclose(got[:2], want[:2], rtol=1e-12)
     assert np.isnan(got[2]).all()
+
+
+def test_error_models_changing_between_calls_and_invalid_sigma():
+    """The sigma tables are rebuilt on the device whenever the error models change (an optimiser moving gamma / lambda
+    every call): more distinct models than cache slots, revisits, and a model whose sigma goes negative."""
+    rng = np.random.default_rng(21)
+    m, flat, theta = synth.config_c3(100, 64)
+    flat = with_observed_values(m, flat, theta[:1], rng)
+    import torch
+
+    pop = runtime.DevicePopulation(flat, 0)
+    ems = [AssayErrorModels.empty().add(0, AssayErrorModel.additive(ErrorPoly(0.05, 0.1, 0.0, 0.0), lam))
+           for lam in (0.05, 0.1, 0.2, 0.4, 0.8, 1.6)]
+    ems += [AssayErrorModels.empty().add(0, AssayErrorModel.proportional(ErrorPoly(0.02, 0.15, 0.0, 0.0), g)) for g in (0.7, 1.3)]
+    wants = [oracle.loglik(m, flat, em, theta)[0] for em in ems]
+    for order in (range(len(ems)), reversed(range(len(ems))), [0, 5, 0, 7, 2, 2, 6, 1]):
+        for i in order:
+            ll, st = runtime.loglik(m, pop, ems[i], theta)
+            torch.cuda.synchronize()
+            got = ll.cpu().numpy()
+            assert (np.abs(got - wants[i]) / np.maximum(np.abs(wants[i]), 1.0)).max() < TOL_LL, i
+    # gamma < 0 makes sigma = gamma * alpha negative: ErrorModelError::NegativeSigma
+    bad = AssayErrorModels.empty().add(0, AssayErrorModel.proportional(ErrorPoly(0.02, 0.15, 0.0, 0.0), -1.0))
+    with pytest.raises(_abi.PmxError) as e:
+        runtime.loglik_host(m, flat, bad, theta)
+    assert e.value.status == _abi.PMX_ERR_ERROR_MODEL and "NegativeSigma" in str(e.value)
+    ll, st = runtime.loglik(m, pop, bad, theta)  # device form: flagged rows instead of a call-level error
+    torch.cuda.synchronize()
+    assert np.isnan(ll.cpu().numpy()).all() and (st.cpu().numpy() == _abi.PMX_PAIR_NONFINITE).all()
