@@ -54,7 +54,8 @@ struct DevOps {
   const double* lagb_time;
   const double* lagb_amount;
   // fused log-likelihood (pmx_loglik): nullptr = prediction mode
-  const double* ll_obs;         // [n_observations][4] = {observed value, -0.5 ln(2pi) - ln(sigma), 1/(2 sigma^2), 0};
+  const double* ll_obs;         // [n_observations][4] = {observed value, -0.5 ln(2pi) - ln(sigma), 1/(2 sigma^2),
+                                //   censor scale: 0 | +1/(sigma sqrt 2) BLOQ | -1/(sigma sqrt 2) ALOQ};
                                 //   weight 0 marks a missing observation (contributes nothing)
   double* ll_out;               // [n_subjects x ll_ld]
   int64_t ll_ld;
