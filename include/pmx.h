@@ -278,6 +278,14 @@ int32_t pmx_predict(const pmx_model* model, const pmx_population* pop, const dou
 int32_t pmx_predict_device(const pmx_model* model, const pmx_population* pop, const double* d_theta,
                            int64_t n_support, double* d_pred, int64_t ld_pred, uint8_t* d_status, void* stream);
 
+/* Prediction::state (likelihood/prediction.rs:18-27, a19): the reference records the full state vector beside every
+ * prediction.  This entry point writes the amount in model state `state` at every observation time, for every
+ * support point, in the layout of pmx_predict_device (one call per state of interest; same kernels, the output
+ * equations replaced by y = x[state]). */
+int32_t pmx_predict_state_device(const pmx_model* model, const pmx_population* pop, const double* d_theta,
+                                 int64_t n_support, int32_t state, double* d_out, int64_t ld_out, uint8_t* d_status,
+                                 void* stream);
+
 /* "Batch" form (log_likelihood_batch shape, likelihood/mod.rs:119-177): subject s
  * is simulated with its own row theta[s] only.  pred is [n_observations] (ld 1),
  * status [n_subjects]. */

@@ -618,7 +618,8 @@ struct LLRequest {
 };
 
 int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_theta, int64_t P, int batch,
-                double* d_pred, int64_t ld, uint8_t* d_status, void* stream, const LLRequest* llreq = nullptr) {
+                double* d_pred, int64_t ld, uint8_t* d_status, void* stream, const LLRequest* llreq = nullptr,
+                int state_override = -1) {
   const pmx_model_desc& d = model->d;
   if (d.n_covariates != pop->hp.n_cov)
     return fail(PMX_ERR_INVALID_ARGUMENT, "model declares " + std::to_string(d.n_covariates) +
@@ -652,6 +653,8 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
   std::memcpy(a.m.derived, d.derived, sizeof(d.derived));
   std::memcpy(a.m.bind, d.bind, sizeof(d.bind));
   std::memcpy(a.m.out, d.out, sizeof(d.out));
+  if (state_override >= 0)  // Prediction::state: every output equation reads the raw amount of one state
+    for (int o = 0; o < PMX_MAX_OUT; ++o) a.m.out[o] = pmx_out{state_override, PMX_SRC_NONE, 0};
   std::memcpy(a.m.init_param, d.init_param, sizeof(d.init_param));
   std::memcpy(a.m.bolus_dest, d.bolus_dest, sizeof(d.bolus_dest));
   std::memcpy(a.m.infusion_dest, d.infusion_dest, sizeof(d.infusion_dest));
@@ -837,6 +840,20 @@ int32_t pmx_predict_device(const pmx_model* model, const pmx_population* cpop, c
   DeviceGuard g;
   PMX_HIP(g.enter(pop->device));
   return enqueue(model, pop, d_theta, n_support, 0, d_pred, ld_pred, d_status, stream);
+}
+
+int32_t pmx_predict_state_device(const pmx_model* model, const pmx_population* cpop, const double* d_theta,
+                                 int64_t n_support, int32_t state, double* d_out, int64_t ld_out, uint8_t* d_status,
+                                 void* stream) {
+  g_err.clear();
+  if (!model || !cpop || !d_theta || !d_out) return fail(PMX_ERR_INVALID_ARGUMENT, "null argument");
+  if (n_support <= 0 || ld_out < n_support) return fail(PMX_ERR_INVALID_ARGUMENT, "n_support must be > 0 and ld_out >= n_support");
+  if (state < 0 || state >= model->d.nstates) return fail(PMX_ERR_INVALID_ARGUMENT, "state out of range");
+  if (model->custom) return fail(PMX_ERR_UNSUPPORTED, "state read-out of a custom model: add an output equation for the state");
+  pmx_population* pop = const_cast<pmx_population*>(cpop);
+  DeviceGuard g;
+  PMX_HIP(g.enter(pop->device));
+  return enqueue(model, pop, d_theta, n_support, 0, d_out, ld_out, d_status, stream, nullptr, state);
 }
 
 int32_t pmx_predict_batch_device(const pmx_model* model, const pmx_population* cpop, const double* d_theta,

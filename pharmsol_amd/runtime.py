@@ -72,6 +72,28 @@ class DevicePopulation:
             self.handle = None
 
 
+def predict_states(model, pop: DevicePopulation, theta, states=None):
+    """``Prediction::state`` (likelihood/prediction.rs:18-27) for every observation: a CUDA tensor
+    ``[n_observations, len(states), n_support]`` (default: all model states), one ``pmx_predict_state_device`` call
+    per state on torch's current stream."""
+    import torch
+
+    L = _ffi.lib()
+    dm = _as_model(model)
+    dev = torch.device("cuda", pop.device)
+    if not (isinstance(theta, torch.Tensor) and theta.is_cuda):
+        theta = torch.as_tensor(np.ascontiguousarray(theta, dtype=np.float64), device=dev)
+    theta = theta.contiguous()
+    P = int(theta.shape[0])
+    states = list(range(dm.desc.nstates)) if states is None else [int(s) for s in states]
+    out = torch.empty((len(states), pop.n_observations, P), dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    for k, st in enumerate(states):
+        _ffi.check(L.pmx_predict_state_device(dm.handle, pop.handle, theta.data_ptr(), P, st, out[k].data_ptr(), P, None,
+                                              stream))
+    return out.permute(1, 0, 2)
+
+
 def jit_translation_unit(model) -> str:
     """The source text the library hands to hiprtc for a custom ODE model (``pmx_debug_jit_source``)."""
     L = _ffi.lib()

@@ -556,3 +556,28 @@ PMX_DEVICE void pmx_outputs(double t, const double* x, const double* p, const do
         assert rel_err(results[i][0], want).max() < TOL_ANALYTICAL
         assert (np.abs(results[i][1] - wll) / np.maximum(np.abs(wll), 1.0)).max() < 1e-9
         assert rel_err(results[i][2], want).max() < 1e-4  # the same two-compartment system through RK4 (h <= 0.05)
+
+
+def test_state_vectors_at_the_observation_times():
+    """Prediction::state (a19): the amounts in every model state at each observation, through the same kernels with
+    the output equations replaced by y = x[state]; checked against the oracle run with exactly such outputs."""
+    import torch
+
+    rng = np.random.default_rng(111)
+    cases = [(models.handwritten_analytical("two_compartments_with_absorption", 1, 5).with_ndrugs(1), 3,
+              np.concatenate([synth.theta_c3(40)[:, :1], rng.uniform(0.8, 3.0, (40, 1)), synth.theta_c3(40)[:, 1:]], axis=1)),
+             (models.handwritten_ode("two_cmt_iv", 0, 4, h_max=0.02).with_ndrugs(1), 2, synth.theta_c3(40))]
+    subs = [models.random_subject(rng, multi_occasion=True) for _ in range(30)]
+    for m, ns, theta in cases:
+        flat = m.flatten(Data(subs))
+        pop = runtime.DevicePopulation(flat, 0)
+        got = runtime.predict_states(m, pop, theta)
+        torch.cuda.synchronize()
+        got = got.cpu().numpy()
+        assert got.shape == (flat.n_observations, ns, 40)
+        for st in range(ns):
+            d = m.desc()
+            for o in range(_abi.PMX_MAX_OUT):
+                d.out[o].state, d.out[o].vol_src, d.out[o].vol_index = st, _abi.PMX_SRC_NONE, 0
+            want, _ = oracle.predict(d, flat, theta)
+            assert rel_err(got[:, st, :], want).max() < (TOL_ODE if "ode" in m.kernel_name or m.eq_kind == _abi.PMX_EQ_ODE else TOL_ANALYTICAL)
