@@ -369,7 +369,9 @@ __device__ __forceinline__ void classed_emit(const double (&x)[G][NS], double in
         dbl2 vv;
         vv.x = v.x;
         vv.y = v.y;
-        __builtin_nontemporal_store(vv, reinterpret_cast<dbl2*>(dst));
+        // streaming store, cache policy `sc1 nt` (tools/store_pattern_probe.hip: plain 1.23 ms, nt 1.12, sc1 nt 1.07
+        // for this address map); no builtin carries sc1, hence the asm
+        asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(dst), "v"(vv) : "memory");
       }
       if (any_half) {  // wave-uniform: only the wave holding the last slot of an odd-length row
         if (row_live && pair_half) *dst = v.x;

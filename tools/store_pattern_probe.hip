@@ -33,6 +33,44 @@ __device__ __forceinline__ void st16(double* p, double a, double b) {
     *reinterpret_cast<dbl2*>(p) = v;
 }
 
+// the classed map with explicit cache-policy bits on the store (inline asm): 0 plain, 1 nt, 2 sc1, 3 sc0 sc1, 4 sc1 nt,
+// 5 sc0 sc1 nt, 6 sc0
+template <int POLICY>
+__device__ __forceinline__ void st16_policy(double* p, double a, double b) {
+  dbl2 v;
+  v.x = a;
+  v.y = b;
+  if constexpr (POLICY == 0) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+  if constexpr (POLICY == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+  if constexpr (POLICY == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+  if constexpr (POLICY == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+  if constexpr (POLICY == 4) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+  if constexpr (POLICY == 5) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
+  if constexpr (POLICY == 6) asm volatile("global_store_dwordx4 %0, %1, off sc0" ::"v"(p), "v"(v) : "memory");
+}
+template <int POLICY>
+__global__ __launch_bounds__(256) void k_classed_policy(double* out, int64_t n_chunks, int cpb, int n_ptiles) {
+  const int64_t b = blockIdx.x;
+  const int64_t group = b / (8 * n_ptiles);
+  const int local = static_cast<int>(b % (8 * n_ptiles));
+  const int ptile = local / 8;
+  const int64_t cblock = group * 8 + (local % 8);
+  const unsigned lane = threadIdx.x & 63u;
+  const bool upper = lane >= 32u;
+  const int64_t p_even = static_cast<int64_t>(ptile) * 256 + (threadIdx.x & ~63u) + 2u * (lane & 31u);
+  const bool ok = p_even + 1 < P;
+  for (int64_t c = cblock * cpb; c < (cblock + 1) * cpb && c < n_chunks; ++c) {
+    for (int k = 0; k < O; ++k) {
+#pragma unroll
+      for (int h = 0; h < G / 2; ++h) {
+        const int64_t subj = c * G + 2 * h + (upper ? 1 : 0);
+        const int64_t row = subj * O + k;
+        if (ok) st16_policy<POLICY>(out + row * P + p_even, 1.0, 2.0);
+      }
+    }
+  }
+}
+
 // A: linear fill, 16 B per lane, grid-stride
 template <bool NT>
 __global__ __launch_bounds__(256) void k_linear(double* out, int64_t n2) {
@@ -211,6 +249,15 @@ int main() {
       run(nm, [&] { hipLaunchKernelGGL((k_classed<true, false, 256>), dim3(cb * 4), dim3(256), 0, 0, out, n_chunks, cpb, 4, 0); });
       std::snprintf(nm, sizeof nm, "B classed map nt +delay64 cpb=%d", cpb);
       run(nm, [&] { hipLaunchKernelGGL((k_classed<true, false, 256>), dim3(cb * 4), dim3(256), 0, 0, out, n_chunks, cpb, 4, 64); });
+      if (cpb == 6) {
+        run("P classed map, store policy plain", [&] { hipLaunchKernelGGL((k_classed_policy<0>), dim3(cb * 4), dim3(256), 0, 0, out, n_chunks, cpb, 4); });
+        run("P classed map, store policy nt", [&] { hipLaunchKernelGGL((k_classed_policy<1>), dim3(cb * 4), dim3(256), 0, 0, out, n_chunks, cpb, 4); });
+        run("P classed map, store policy sc1", [&] { hipLaunchKernelGGL((k_classed_policy<2>), dim3(cb * 4), dim3(256), 0, 0, out, n_chunks, cpb, 4); });
+        run("P classed map, store policy sc0 sc1", [&] { hipLaunchKernelGGL((k_classed_policy<3>), dim3(cb * 4), dim3(256), 0, 0, out, n_chunks, cpb, 4); });
+        run("P classed map, store policy sc1 nt", [&] { hipLaunchKernelGGL((k_classed_policy<4>), dim3(cb * 4), dim3(256), 0, 0, out, n_chunks, cpb, 4); });
+        run("P classed map, store policy sc0 sc1 nt", [&] { hipLaunchKernelGGL((k_classed_policy<5>), dim3(cb * 4), dim3(256), 0, 0, out, n_chunks, cpb, 4); });
+        run("P classed map, store policy sc0", [&] { hipLaunchKernelGGL((k_classed_policy<6>), dim3(cb * 4), dim3(256), 0, 0, out, n_chunks, cpb, 4); });
+      }
       std::snprintf(nm, sizeof nm, "C full-row blocks (1024 thr) nt cpb=%d", cpb);
       run(nm, [&] { hipLaunchKernelGGL((k_classed<true, false, 1024>), dim3(cb), dim3(1024), 0, 0, out, n_chunks, cpb, 1, 0); });
       std::snprintf(nm, sizeof nm, "D obs-major rows nt cpb=%d", cpb);
