@@ -472,7 +472,9 @@ int32_t get_stream(pmx_population* pop, const pmx::CompileKey& key, DeviceStream
     pmx::ClassPlan cp;
     int32_t min_class = key.class_g / 2;
     if (const char* e = std::getenv("PMX_TUNE_MIN_CLASS")) min_class = std::atoi(e) > 0 ? std::atoi(e) : min_class;  // tuning experiments
-    pmx::build_class_plan(pop->hp, os, key.class_g, min_class, &cp, key.ladder);
+    bool spread = true;  // (0.94-0.97 vs 1.05-1.11 ms on C3 in most allocations, never slower: tools/alloc_tune.py)
+    if (const char* e = std::getenv("PMX_TUNE_SPREAD")) spread = e[0] && e[0] != '0';  // tuning experiments
+    pmx::build_class_plan(pop->hp, os, key.class_g, min_class, &cp, key.ladder, spread);
     if (cp.n_chunks > 0) {
       if ((rc = upload(cp.prog_meta, &ds->cls.prog_meta, &ds->allocs)) != PMX_OK) return rc;
       if ((rc = upload(cp.prog_dt, &ds->cls.prog_dt, &ds->allocs)) != PMX_OK) return rc;

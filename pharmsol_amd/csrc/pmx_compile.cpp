@@ -483,7 +483,7 @@ uint32_t ladder_code(double dt, double* prev, double* span) {
 }
 
 void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, int32_t min_class_size, ClassPlan* cp,
-                      bool ladder) {
+                      bool ladder, bool spread) {
   *cp = ClassPlan{};
   cp->G = G;
   const int64_t S = hp.n_subjects;
@@ -574,19 +574,29 @@ void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, i
       cp->prog_dt.push_back(step_dt[static_cast<size_t>(i)]);
     }
     cp->cls_prog_off.push_back(static_cast<int64_t>(cp->prog_meta.size()));
-    for (size_t m0 = 0; m0 < mem.size(); m0 += G) {
-      const int32_t n = static_cast<int32_t>(std::min<size_t>(G, mem.size() - m0));
+    // Which members share a chunk is free (any G subjects of the class may share a propagator).  `spread`: member j of
+    // chunk c is the (c + j * n_chunks)-th subject of the class, so the G rows a block writes at one step are far
+    // apart while neighbouring blocks write neighbouring subjects: G slowly advancing write fronts instead of every
+    // block covering its own 8-subject region (tools/store_pattern_probe.hip, rows B vs H).
+    const size_t n_chunks_cls = (mem.size() + static_cast<size_t>(G) - 1) / static_cast<size_t>(G);
+    std::vector<int32_t> pick(static_cast<size_t>(G));
+    for (size_t c = 0; c < n_chunks_cls; ++c) {
+      int32_t n = 0;
+      for (int32_t j = 0; j < G; ++j) {
+        const size_t idx = spread ? (c + static_cast<size_t>(j) * n_chunks_cls) : (c * static_cast<size_t>(G) + static_cast<size_t>(j));
+        if (idx < mem.size()) pick[static_cast<size_t>(n++)] = mem[idx];
+      }
       cp->chunk_cls.push_back(out_cls);
       cp->chunk_n.push_back(n);
       cp->chunk_val_off.push_back(static_cast<int64_t>(cp->val.size()));
       for (int32_t j = 0; j < G; ++j) {
-        cp->chunk_subj.push_back(j < n ? mem[m0 + j] : -1);
-        cp->chunk_row.push_back(j < n ? hp.subj_obs_off[mem[m0 + j]] : 0);
+        cp->chunk_subj.push_back(j < n ? pick[static_cast<size_t>(j)] : -1);
+        cp->chunk_row.push_back(j < n ? hp.subj_obs_off[pick[static_cast<size_t>(j)]] : 0);
       }
       const size_t base = cp->val.size();
       cp->val.resize(base + static_cast<size_t>(L) * G, 0.0);
       for (int32_t j = 0; j < n; ++j) {
-        const int64_t s0 = os.subj_op_off[mem[m0 + j]];
+        const int64_t s0 = os.subj_op_off[pick[static_cast<size_t>(j)]];
         for (int64_t i = 0; i < r1 - r0; ++i) {
           const int32_t st = step_of_op[static_cast<size_t>(i)];
           if (st < 0) continue;

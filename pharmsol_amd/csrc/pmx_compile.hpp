@@ -140,7 +140,7 @@ struct ClassPlan {
 uint32_t ladder_code(double dt, double* prev, double* span);
 
 void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, int32_t min_class_size, ClassPlan* out,
-                      bool ladder = true);
+                      bool ladder = true, bool spread = false);
 
 // Validate + copy + sort (Occasion::sort, structs.rs:669-671) + build covariate segments.
 // Returns PMX_OK or an error with `err` filled.

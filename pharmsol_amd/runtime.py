@@ -72,6 +72,44 @@ class DevicePopulation:
             self.handle = None
 
 
+def alloc_predictions(model, pop: DevicePopulation, theta, tries: int = 4, reps: int = 3):
+    """A prediction matrix ``[n_observations, n_support]`` placed where the kernel writes fastest.
+
+    The prediction stream is a row-strided scatter; on MI355X its rate depends on WHICH allocation it lands in
+    (tools/store_pattern_probe.hip ``alloc``, tools/alloc_tune.py: the same kernel takes 0.94-0.97 ms in most 5.6 GB
+    allocations and 1.10-1.12 ms in others, stable for the life of the allocation).  This helper allocates up to
+    ``tries`` candidates (all alive at once, so that each sits on different memory), times ``reps`` passes of the real
+    kernel into each, keeps the fastest and frees the rest.  A caller reuses the returned buffer across passes."""
+    import torch
+
+    dev = torch.device("cuda", pop.device)
+    if not (isinstance(theta, torch.Tensor) and theta.is_cuda):
+        theta = torch.as_tensor(np.ascontiguousarray(theta, dtype=np.float64), device=dev)
+    theta = theta.contiguous()
+    P = int(theta.shape[0])
+    best, best_ms, held = None, float("inf"), []
+    for _ in range(max(1, tries)):
+        try:
+            cand = torch.empty((pop.n_observations, P), dtype=torch.float64, device=dev)
+        except RuntimeError:  # out of memory: keep what we have
+            break
+        held.append(cand)
+        predict(model, pop, theta, pred=cand, want_status=False)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            predict(model, pop, theta, pred=cand, want_status=False)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1) / reps
+        if ms < best_ms:
+            best, best_ms = cand, ms
+    held.clear()
+    torch.cuda.empty_cache()
+    return best
+
+
 def predict_states(model, pop: DevicePopulation, theta, states=None):
     """``Prediction::state`` (likelihood/prediction.rs:18-27) for every observation: a CUDA tensor
     ``[n_observations, len(states), n_support]`` (default: all model states), one ``pmx_predict_state_device`` call

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 
 #define CK(x)                                                                  \
   do {                                                                         \
@@ -27,8 +28,8 @@ __device__ __forceinline__ void st16(double* p, double a, double b) {
   dbl2 v;
   v.x = a;
   v.y = b;
-  if (NT)
-    __builtin_nontemporal_store(v, reinterpret_cast<dbl2*>(p));
+  if (NT)  // "nt" rows below = cache policy sc1 nt (what the library's kernel uses; plain nt is in the P rows)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
   else
     *reinterpret_cast<dbl2*>(p) = v;
 }
@@ -224,7 +225,76 @@ static void run(const char* name, F launch) {
   std::fflush(stdout);
 }
 
-int main() {
+// Does the rate of a scattered pattern depend on WHICH allocation it writes?  (argv[1] = "alloc")
+static int alloc_study() {
+  const int64_t n_chunks = S / G;
+  const int cpb = 6;
+  const int64_t cb = ((n_chunks + cpb - 1) / cpb + 7) / 8 * 8;
+  void* pad[8] = {};
+  for (int trial = 0; trial < 8; ++trial) {
+    if (trial % 2 == 1) CK(hipMalloc(&pad[trial], (64ull + 37ull * trial) << 20));  // perturb the allocator between trials
+    double* out = nullptr;
+    CK(hipMalloc(&out, ROWS * P * 8));
+    CK(hipMemset(out, 0, ROWS * P * 8));
+    std::printf("allocation %d at %p\n", trial, static_cast<void*>(out));
+    run("  B classed map (sc1 nt)", [&] { hipLaunchKernelGGL((k_classed<true, false, 256>), dim3(cb * 4), dim3(256), 0, 0, out, n_chunks, cpb, 4, 0); });
+    run("  H members spread (sc1 nt)", [&] { hipLaunchKernelGGL((k_classed_spread<true>), dim3(cb * 4), dim3(256), 0, 0, out, n_chunks, cpb, 4); });
+    run("  D obs-major (sc1 nt)", [&] { hipLaunchKernelGGL((k_classed<true, true, 256>), dim3(cb * 4), dim3(256), 0, 0, out, n_chunks, cpb, 4, 0); });
+    CK(hipFree(out));
+  }
+  for (void* p : pad)
+    if (p) CK(hipFree(p));
+  return 0;
+}
+
+static int alloc2_study() {
+  const int64_t n_chunks = S / G;
+  const int cpb = 6;
+  const int64_t cb = ((n_chunks + cpb - 1) / cpb + 7) / 8 * 8;
+  auto measure = [&](const char* what, double* out) {
+    CK(hipMemset(out, 0, ROWS * P * 8));
+    run(what, [&] { hipLaunchKernelGGL((k_classed<true, false, 256>), dim3(cb * 4), dim3(256), 0, 0, out, n_chunks, cpb, 4, 0); });
+  };
+  const size_t big = ROWS * P * 8;
+  for (int rep = 0; rep < 2; ++rep) {
+    double *a = nullptr, *b = nullptr;
+    void* pad = nullptr;
+    CK(hipMalloc(&a, big)); measure("v0 nothing before", a); CK(hipFree(a));
+    CK(hipMalloc(&pad, 4096)); CK(hipMalloc(&a, big)); measure("v1 4 KB pad before", a); CK(hipFree(a)); CK(hipFree(pad));
+    CK(hipMalloc(&pad, 2u << 20)); CK(hipMalloc(&a, big)); measure("v2 2 MB pad before", a); CK(hipFree(a)); CK(hipFree(pad));
+    CK(hipMalloc(&pad, 64u << 20)); CK(hipMalloc(&a, big)); measure("v3 64 MB pad before", a); CK(hipFree(a)); CK(hipFree(pad));
+    CK(hipMalloc(&pad, 64u << 20)); CK(hipFree(pad)); CK(hipMalloc(&a, big)); measure("v4 64 MB pad allocated+freed before", a); CK(hipFree(a));
+    CK(hipMalloc(&a, big)); CK(hipMalloc(&b, big)); measure("v5 first of two", a); measure("v5 second of two", b); CK(hipFree(a)); CK(hipFree(b));
+    CK(hipMalloc(&a, big + (64u << 20))); measure("v6 one allocation 64 MB larger", a); CK(hipFree(a));
+    CK(hipMalloc(&a, big + 4096)); measure("v7 one allocation 4 KB larger", a); CK(hipFree(a));
+  }
+  return 0;
+}
+
+// ... or on where inside one allocation the matrix starts?  (argv[1] = "offset")
+static int offset_study() {
+  const int64_t n_chunks = S / G;
+  const int cpb = 6;
+  const int64_t cb = ((n_chunks + cpb - 1) / cpb + 7) / 8 * 8;
+  char* base = nullptr;
+  const size_t extra = 1ull << 30;
+  CK(hipMalloc(&base, ROWS * P * 8 + extra));
+  CK(hipMemset(base, 0, ROWS * P * 8 + extra));
+  const size_t offs[] = {0, 4096, 1ull << 20, 2ull << 20, 37ull << 20, 64ull << 20, 101ull << 20, 128ull << 20, 256ull << 20, 512ull << 20, (512ull << 20) + 8000};
+  for (size_t off : offs) {
+    double* out = reinterpret_cast<double*>(base + off);
+    std::printf("offset %zu MiB (+%zu B)\n", off >> 20, off & ((1u << 20) - 1));
+    run("  B classed map (sc1 nt)", [&] { hipLaunchKernelGGL((k_classed<true, false, 256>), dim3(cb * 4), dim3(256), 0, 0, out, n_chunks, cpb, 4, 0); });
+    run("  H members spread (sc1 nt)", [&] { hipLaunchKernelGGL((k_classed_spread<true>), dim3(cb * 4), dim3(256), 0, 0, out, n_chunks, cpb, 4); });
+  }
+  CK(hipFree(base));
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc > 1 && std::string(argv[1]) == "alloc") return alloc_study();
+  if (argc > 1 && std::string(argv[1]) == "offset") return offset_study();
+  if (argc > 1 && std::string(argv[1]) == "alloc2") return alloc2_study();
   double* out = nullptr;
   CK(hipMalloc(&out, ROWS * P * 8));
   CK(hipMemset(out, 0, ROWS * P * 8));
