@@ -417,7 +417,10 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
   const int32_t local = static_cast<int32_t>(b % (8 * n_ptiles));
   const int32_t ptile = local / 8;
   const int64_t cblock = group * 8 + (local % 8);
-  if (cblock * chunks_per_block >= cp.n_chunks) return;
+  // chunk-blocks take chunks cblock, cblock + n_cblocks, ... (grid stride): the blocks resident at one moment then
+  // work on neighbouring chunks, which keeps each of the G write fronts compact (see build_class_plan `spread`)
+  const int64_t n_cblocks = static_cast<int64_t>(gridDim.x) / n_ptiles;
+  if (cblock >= cp.n_chunks) return;
   const uint32_t lane = threadIdx.x & 63u;
   const bool upper = lane >= 32u;
   const int64_t p_even = static_cast<int64_t>(ptile) * kBlock + (threadIdx.x & ~63u) + 2u * (lane & 31u);
@@ -451,9 +454,8 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
   const auto val = as_const(cp.val);
   const double* __restrict__ th = theta + pc * m.nparams;
 
-  const int64_t c_begin = cblock * chunks_per_block;
-  const int64_t c_end = (c_begin + chunks_per_block < cp.n_chunks) ? (c_begin + chunks_per_block) : cp.n_chunks;
-  for (int64_t c = c_begin; c < c_end; ++c) {
+  (void)chunks_per_block;
+  for (int64_t c = cblock; c < cp.n_chunks; c += n_cblocks) {
     const int32_t cls = chunk_cls[c];
     const int32_t n_live = chunk_n[c];
     int64_t voff = chunk_val_off[c];

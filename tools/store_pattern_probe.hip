@@ -184,6 +184,32 @@ __global__ __launch_bounds__(256) void k_classed_spread(double* out, int64_t n_c
   }
 }
 
+// S: member stride study.  Chunk c of a group of (stride*G) subjects: member j = base + j*stride
+// (stride 1 = B consecutive members, stride n_chunks = H).
+template <bool NT>
+__global__ __launch_bounds__(256) void k_classed_stride(double* out, int64_t n_chunks, int cpb, int n_ptiles, int64_t stride) {
+  const int64_t b = blockIdx.x;
+  const int64_t group = b / (8 * n_ptiles);
+  const int local = static_cast<int>(b % (8 * n_ptiles));
+  const int ptile = local / 8;
+  const int64_t cblock = group * 8 + (local % 8);
+  const unsigned lane = threadIdx.x & 63u;
+  const bool upper = lane >= 32u;
+  const int64_t p_even = static_cast<int64_t>(ptile) * 256 + (threadIdx.x & ~63u) + 2u * (lane & 31u);
+  const bool ok = p_even + 1 < P;
+  for (int64_t c = cblock * cpb; c < (cblock + 1) * cpb && c < n_chunks; ++c) {
+    const int64_t base = (c / stride) * (stride * G) + (c % stride);
+    for (int k = 0; k < O; ++k) {
+#pragma unroll
+      for (int h = 0; h < G / 2; ++h) {
+        const int64_t subj = base + (2 * h + (upper ? 1 : 0)) * stride;
+        const int64_t row = subj * O + k;
+        if (ok && subj < S) st16<NT>(out + row * P + p_even, 1.0, 2.0);
+      }
+    }
+  }
+}
+
 // E: one wave-store = 1 KB of ONE row (64 lanes x 16 B = 128 adjacent p): what an LDS transpose would allow.
 // block of 256 threads covers 512 p of a row -> 2 ptiles for P=1000; members are walked one row at a time.
 template <bool NT>
@@ -247,6 +273,30 @@ static int alloc_study() {
   return 0;
 }
 
+static int stride_study() {
+  const int64_t n_chunks = S / G;
+  void* pad = nullptr;
+  double* out = nullptr;
+  for (int trial = 0; trial < 3; ++trial) {  // a few allocations: the effect is allocation dependent
+    if (trial) CK(hipMalloc(&pad, 97u << 20));
+    CK(hipMalloc(&out, ROWS * P * 8));
+    CK(hipMemset(out, 0, ROWS * P * 8));
+    std::printf("allocation %d\n", trial);
+    for (int cpb : {1, 6}) {
+      const int64_t cb = ((n_chunks + cpb - 1) / cpb + 7) / 8 * 8;
+      for (int64_t stride : {1ll, 2ll, 5ll, 20ll, 100ll, 500ll, 2500ll, 12500ll}) {
+        char nm[96];
+        std::snprintf(nm, sizeof nm, "  member stride %lld cpb=%d", static_cast<long long>(stride), cpb);
+        run(nm, [&] { hipLaunchKernelGGL((k_classed_stride<true>), dim3(cb * 4), dim3(256), 0, 0, out, n_chunks, cpb, 4, stride); });
+      }
+    }
+    CK(hipFree(out));
+    if (pad) CK(hipFree(pad));
+    pad = nullptr;
+  }
+  return 0;
+}
+
 static int alloc2_study() {
   const int64_t n_chunks = S / G;
   const int cpb = 6;
@@ -295,6 +345,7 @@ int main(int argc, char** argv) {
   if (argc > 1 && std::string(argv[1]) == "alloc") return alloc_study();
   if (argc > 1 && std::string(argv[1]) == "offset") return offset_study();
   if (argc > 1 && std::string(argv[1]) == "alloc2") return alloc2_study();
+  if (argc > 1 && std::string(argv[1]) == "stride") return stride_study();
   double* out = nullptr;
   CK(hipMalloc(&out, ROWS * P * 8));
   CK(hipMemset(out, 0, ROWS * P * 8));
