@@ -53,7 +53,7 @@ def main():
     ap.add_argument("--no-status", action="store_true", help="do not write the per-pair status bytes")
     ap.add_argument("--loglik", action="store_true",
                     help="time the fused log-likelihood entry (pmx_loglik_device) instead of predictions: output S x P")
-    ap.add_argument("--alloc-tries", type=int, default=4,
+    ap.add_argument("--alloc-tries", type=int, default=6,
                     help="candidate allocations for the prediction matrix; the fastest is kept (runtime.alloc_predictions; "
                          "1 = take the first)")
     ap.add_argument("--ragged", action="store_true",

@@ -297,6 +297,36 @@ static int stride_study() {
   return 0;
 }
 
+// Which kind of allocation does the spread pattern like?  (argv[1] = "alloc3")
+static int alloc3_study() {
+  const int64_t n_chunks = S / G;
+  const size_t big = ROWS * P * 8;
+  const int64_t cb = (n_chunks + 7) / 8 * 8;
+  auto measure = [&](const char* what, double* out) {
+    CK(hipMemset(out, 0, big));
+    run(what, [&] { hipLaunchKernelGGL((k_classed_stride<true>), dim3(cb * 4), dim3(256), 0, 0, out, n_chunks, 1, 4, n_chunks); });
+  };
+  for (int rep = 0; rep < 4; ++rep) {
+    double* a = nullptr;
+    void* pad = nullptr;
+    if (rep % 2) CK(hipMalloc(&pad, 97u << 20));
+    CK(hipMalloc(&a, big)); measure("hipMalloc", a); CK(hipFree(a));
+    CK(hipMalloc(&a, 6ull << 30)); measure("hipMalloc 6 GiB", a); CK(hipFree(a));
+    CK(hipMalloc(&a, 8ull << 30)); measure("hipMalloc 8 GiB", a); CK(hipFree(a));
+    if (hipExtMallocWithFlags(reinterpret_cast<void**>(&a), big, hipDeviceMallocUncached) == hipSuccess) { measure("hipExtMallocWithFlags uncached", a); CK(hipFree(a)); }
+    if (hipExtMallocWithFlags(reinterpret_cast<void**>(&a), big, hipDeviceMallocFinegrained) == hipSuccess) { measure("hipExtMallocWithFlags finegrained", a); CK(hipFree(a)); }
+    {
+      hipMemPool_t pool; hipStream_t st; CK(hipStreamCreate(&st));
+      CK(hipDeviceGetDefaultMemPool(&pool, 0));
+      if (hipMallocAsync(reinterpret_cast<void**>(&a), big, st) == hipSuccess) { CK(hipStreamSynchronize(st)); measure("hipMallocAsync (pool)", a); CK(hipFreeAsync(a, st)); CK(hipStreamSynchronize(st)); }
+      CK(hipStreamDestroy(st));
+    }
+    if (pad) CK(hipFree(pad));
+    std::printf("--\n");
+  }
+  return 0;
+}
+
 static int alloc2_study() {
   const int64_t n_chunks = S / G;
   const int cpb = 6;
@@ -346,6 +376,7 @@ int main(int argc, char** argv) {
   if (argc > 1 && std::string(argv[1]) == "offset") return offset_study();
   if (argc > 1 && std::string(argv[1]) == "alloc2") return alloc2_study();
   if (argc > 1 && std::string(argv[1]) == "stride") return stride_study();
+  if (argc > 1 && std::string(argv[1]) == "alloc3") return alloc3_study();
   double* out = nullptr;
   CK(hipMalloc(&out, ROWS * P * 8));
   CK(hipMemset(out, 0, ROWS * P * 8));
