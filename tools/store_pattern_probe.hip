@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <vector>
 
 #define CK(x)                                                                  \
   do {                                                                         \
@@ -327,6 +328,58 @@ static int alloc3_study() {
   return 0;
 }
 
+// Virtual-memory API: the matrix mapped from physical handles of a chosen size (argv[1] = "vmm")
+static int vmm_study() {
+  const int64_t n_chunks = S / G;
+  const size_t big = ROWS * P * 8;
+  const int64_t cb = (n_chunks + 7) / 8 * 8;
+  hipMemAllocationProp prop{};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = 0;
+  size_t gran = 0;
+  CK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+  std::printf("recommended granularity %zu\n", gran);
+  for (int rep = 0; rep < 3; ++rep) {
+    for (size_t chunk : {size_t(2) << 20, size_t(64) << 20, size_t(1) << 30, size_t(6) << 30}) {
+      const size_t total = (big + chunk - 1) / chunk * chunk;
+      void* va = nullptr;
+      if (hipMemAddressReserve(&va, total, chunk < (size_t(1) << 30) ? 0 : 0, nullptr, 0) != hipSuccess) { std::printf("reserve failed\n"); continue; }
+      std::vector<hipMemGenericAllocationHandle_t> hs;
+      bool ok = true;
+      for (size_t off = 0; off < total && ok; off += chunk) {
+        hipMemGenericAllocationHandle_t h;
+        if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) { ok = false; break; }
+        hs.push_back(h);
+        if (hipMemMap(static_cast<char*>(va) + off, chunk, 0, h, 0) != hipSuccess) ok = false;
+      }
+      hipMemAccessDesc acc{};
+      acc.location = prop.location;
+      acc.flags = hipMemAccessFlagsProtReadWrite;
+      if (ok && hipMemSetAccess(va, total, &acc, 1) != hipSuccess) ok = false;
+      if (ok) {
+        double* out = static_cast<double*>(va);
+        CK(hipMemset(out, 0, big));
+        char nm[96];
+        std::snprintf(nm, sizeof nm, "VMM, %zu MiB physical handles", chunk >> 20);
+        run(nm, [&] { hipLaunchKernelGGL((k_classed_stride<true>), dim3(cb * 4), dim3(256), 0, 0, out, n_chunks, 1, 4, n_chunks); });
+      } else {
+        std::printf("VMM with %zu MiB handles: failed\n", chunk >> 20);
+      }
+      (void)hipMemUnmap(va, total);
+      for (auto h : hs) (void)hipMemRelease(h);
+      (void)hipMemAddressFree(va, total);
+    }
+    double* a = nullptr;
+    CK(hipMalloc(&a, big));
+    CK(hipMemset(a, 0, big));
+    run("hipMalloc", [&] { hipLaunchKernelGGL((k_classed_stride<true>), dim3(cb * 4), dim3(256), 0, 0, a, n_chunks, 1, 4, n_chunks); });
+    CK(hipFree(a));
+    std::printf("--\n");
+  }
+  return 0;
+}
+
 static int alloc2_study() {
   const int64_t n_chunks = S / G;
   const int cpb = 6;
@@ -377,6 +430,7 @@ int main(int argc, char** argv) {
   if (argc > 1 && std::string(argv[1]) == "alloc2") return alloc2_study();
   if (argc > 1 && std::string(argv[1]) == "stride") return stride_study();
   if (argc > 1 && std::string(argv[1]) == "alloc3") return alloc3_study();
+  if (argc > 1 && std::string(argv[1]) == "vmm") return vmm_study();
   double* out = nullptr;
   CK(hipMalloc(&out, ROWS * P * 8));
   CK(hipMemset(out, 0, ROWS * P * 8));
