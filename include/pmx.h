@@ -278,6 +278,14 @@ int32_t pmx_predict(const pmx_model* model, const pmx_population* pop, const dou
 int32_t pmx_predict_device(const pmx_model* model, const pmx_population* pop, const double* d_theta,
                            int64_t n_support, double* d_pred, int64_t ld_pred, uint8_t* d_status, void* stream);
 
+/* Average device time (ms, HIP events on `stream`) of `reps` prediction passes into `d_pred`, after one untimed pass;
+ * synchronises `stream`.  For choosing among candidate output buffers: on MI355X the row-strided write stream runs at one
+ * of two speeds depending on the allocation it lands in (DESIGN.md §5 "Where the matrix lives"); a caller that reuses
+ * one buffer across passes allocates a few, times each with this call and keeps the fastest. */
+int32_t pmx_time_predict_device(const pmx_model* model, const pmx_population* pop, const double* d_theta,
+                                int64_t n_support, double* d_pred, int64_t ld_pred, int32_t reps, void* stream,
+                                double* ms_per_pass);
+
 /* Prediction::state (likelihood/prediction.rs:18-27, a19): the reference records the full state vector beside every
  * prediction.  This entry point writes the amount in model state `state` at every observation time, for every
  * support point, in the layout of pmx_predict_device (one call per state of interest; same kernels, the output

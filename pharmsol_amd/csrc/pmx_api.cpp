@@ -844,6 +844,36 @@ int32_t pmx_predict_device(const pmx_model* model, const pmx_population* cpop, c
   return enqueue(model, pop, d_theta, n_support, 0, d_pred, ld_pred, d_status, stream);
 }
 
+int32_t pmx_time_predict_device(const pmx_model* model, const pmx_population* cpop, const double* d_theta,
+                                int64_t n_support, double* d_pred, int64_t ld_pred, int32_t reps, void* stream,
+                                double* ms_per_pass) {
+  g_err.clear();
+  if (!model || !cpop || !d_theta || !d_pred || !ms_per_pass) return fail(PMX_ERR_INVALID_ARGUMENT, "null argument");
+  if (n_support <= 0 || ld_pred < n_support || reps < 1) return fail(PMX_ERR_INVALID_ARGUMENT, "n_support, ld_pred or reps out of range");
+  pmx_population* pop = const_cast<pmx_population*>(cpop);
+  DeviceGuard g;
+  PMX_HIP(g.enter(pop->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int32_t rc = enqueue(model, pop, d_theta, n_support, 0, d_pred, ld_pred, nullptr, stream);
+  if (rc != PMX_OK) return rc;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  PMX_HIP(hipEventCreate(&e0));
+  PMX_HIP(hipEventCreate(&e1));
+  PMX_HIP(hipEventRecord(e0, st));
+  for (int32_t i = 0; i < reps && rc == PMX_OK; ++i) rc = enqueue(model, pop, d_theta, n_support, 0, d_pred, ld_pred, nullptr, stream);
+  if (rc == PMX_OK) {
+    float ms = 0.0f;
+    hipError_t e = hipEventRecord(e1, st);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e != hipSuccess) rc = fail(PMX_ERR_HIP, hipGetErrorString(e));
+    *ms_per_pass = static_cast<double>(ms) / reps;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return rc;
+}
+
 int32_t pmx_predict_state_device(const pmx_model* model, const pmx_population* cpop, const double* d_theta,
                                  int64_t n_support, int32_t state, double* d_out, int64_t ld_out, uint8_t* d_status,
                                  void* stream) {

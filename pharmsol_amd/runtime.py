@@ -94,15 +94,10 @@ def alloc_predictions(model, pop: DevicePopulation, theta, tries: int = 4, reps:
         except RuntimeError:  # out of memory: keep what we have
             break
         held.append(cand)
-        predict(model, pop, theta, pred=cand, want_status=False)
-        torch.cuda.synchronize(dev)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            predict(model, pop, theta, pred=cand, want_status=False)
-        e1.record()
-        torch.cuda.synchronize(dev)
-        ms = e0.elapsed_time(e1) / reps
+        ms_c = C.c_double()
+        _ffi.check(_ffi.lib().pmx_time_predict_device(_as_model(model).handle, pop.handle, theta.data_ptr(), P, cand.data_ptr(),
+                                                      P, reps, torch.cuda.current_stream(dev).cuda_stream, C.byref(ms_c)))
+        ms = ms_c.value
         if ms < best_ms:
             best, best_ms = cand, ms
     held.clear()
