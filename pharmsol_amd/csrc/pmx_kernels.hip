@@ -796,7 +796,8 @@ hipError_t launch_analytical(const LaunchArgs& a, const char** name) {
       if (a.use_classes && a.cls.n_chunks > 0) {
         *name = "pmx_analytical_classed";
         // enough blocks to fill the chip several times over, few enough that lane_setup stays amortised
-        int64_t cpb = (a.cls.n_chunks * a.n_ptiles) / 8192;
+        // (chunks are taken in grid-stride order; one chunk per block up to 32k blocks measured best: tools/cpb_on_one_allocation.py)
+        int64_t cpb = (a.cls.n_chunks * a.n_ptiles) / 32768;
         if (cpb < 1) cpb = 1;
         if (cpb > 8) cpb = 8;
         if (const char* e = std::getenv("PMX_TUNE_CPB")) cpb = std::atoi(e) > 0 ? std::atoi(e) : cpb;  // tuning experiments
