@@ -797,7 +797,8 @@ hipError_t launch_analytical(const LaunchArgs& a, const char** name) {
         *name = "pmx_analytical_classed";
         // enough blocks to fill the chip several times over, few enough that lane_setup stays amortised
         // (chunks are taken in grid-stride order; one chunk per block up to 32k blocks measured best: tools/cpb_on_one_allocation.py)
-        int64_t cpb = (a.cls.n_chunks * a.n_ptiles) / 32768;
+        // (the log-likelihood variant writes almost nothing: it prefers fewer, longer blocks that amortise the lane setup)
+        int64_t cpb = (a.cls.n_chunks * a.n_ptiles) / (a.ops.ll_obs != nullptr ? 8192 : 32768);
         if (cpb < 1) cpb = 1;
         if (cpb > 8) cpb = 8;
         if (const char* e = std::getenv("PMX_TUNE_CPB")) cpb = std::atoi(e) > 0 ? std::atoi(e) : cpb;  // tuning experiments
