@@ -726,7 +726,13 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
   const int64_t blocks = a.mode == pmx::MODE_GRID ? ((a.S + a.s_chunk - 1) / a.s_chunk) * a.n_ptiles
                                                   : ((batch ? a.S : a.S * a.P) + 255) / 256;
   if (blocks > 0x7fffffffLL) return fail(PMX_ERR_INVALID_ARGUMENT, "grid too large for one launch");
-  if (d_status != nullptr) {
+  // the classed kernel can clear its own status bytes (no memset between passes) when it serves every subject
+  a.cls.zero_status = (d_status != nullptr && a.mode == pmx::MODE_GRID && a.use_classes && ds->cls.n_generic == 0 &&
+                       ds->n_classed_subjects == a.S /* no empty subject either */ && ds->cls.G <= 8 && P % 8 == 0 && !model->custom &&
+                       d.eq_kind == PMX_EQ_ANALYTICAL)
+                          ? 1
+                          : 0;
+  if (d_status != nullptr && !a.cls.zero_status) {
     // PMX_PAIR_OK == 0: the kernels only write the bytes of failed pairs
     const int64_t n_status = batch ? a.S : a.S * P;
     hipError_t me = hipMemsetAsync(d_status, 0, static_cast<size_t>(n_status), static_cast<hipStream_t>(stream));

@@ -462,6 +462,20 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
     const int64_t pb = cls_prog_off[cls];
     const int64_t pe = cls_prog_off[cls + 1];
     int64_t kld = 0;   // (observations emitted so far) * ld
+    if (cp.zero_status && status != nullptr) {
+      // The wave clears the status bytes it owns (G members x its 64 support points) with ONE 8-byte store per lane:
+      // lane = 8 * member + piece.  A separate memset between two passes cost ~70 us of serialisation per pass, this
+      // costs one store per chunk.  (Launcher guarantees n_support % 8 == 0 and G <= 8 when the flag is set.)
+      const int zj = static_cast<int>(lane >> 3);
+      int64_t zsid = -1;
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const int64_t sj = chunk_subj[c * G + j];
+        zsid = (zj == j && j < n_live) ? sj : zsid;
+      }
+      const int64_t zp = static_cast<int64_t>(ptile) * kBlock + (threadIdx.x & ~63u) + 8 * (lane & 7u);
+      if (zsid >= 0 && zp < P) *reinterpret_cast<uint64_t*>(status + zsid * P + zp) = 0ull;
+    }
     double* slot[G / 2];  // this lane's 16-byte slot in the first prediction row of each member pair
     double ll_acc[G];     // log-likelihood mode: running sum of each member
     int64_t cobs_off = 0;  // log-likelihood mode: the chunk's {value, const, weight} block, advanced per observation
@@ -575,6 +589,7 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
     // status bytes: the library zeroes the array before the launch (PMX_PAIR_OK == 0); only failures are
     // written here, so the healthy case issues no byte stores at all
     if (status != nullptr && __any(((bad != 0u || !lane_good) && lane_ok) ? 1 : 0)) {
+      if (cp.zero_status) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clearing store above lands first
 #pragma unroll
       for (int j = 0; j < G; ++j) {
         if (j < n_live) {

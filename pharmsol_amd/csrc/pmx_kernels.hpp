@@ -27,7 +27,7 @@ struct DevClassPlan {
   int64_t n_chunks;
   int64_t n_generic;
   int32_t G;
-  int32_t pad_;
+  int32_t zero_status;  // 1: the classed kernel clears its own status bytes (no memset before the launch)
 };
 
 enum LaneMode : int32_t { MODE_GRID = 0, MODE_PAIR = 1 };

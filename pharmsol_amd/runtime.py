@@ -72,7 +72,7 @@ class DevicePopulation:
             self.handle = None
 
 
-def alloc_predictions(model, pop: DevicePopulation, theta, tries: int = 4, reps: int = 3):
+def alloc_predictions(model, pop: DevicePopulation, theta, tries: int = 4, reps: int = 5, log=None):
     """A prediction matrix ``[n_observations, n_support]`` placed where the kernel writes fastest.
 
     The prediction stream is a row-strided scatter; on MI355X its rate depends on WHICH allocation it lands in
@@ -98,6 +98,8 @@ def alloc_predictions(model, pop: DevicePopulation, theta, tries: int = 4, reps:
         _ffi.check(_ffi.lib().pmx_time_predict_device(_as_model(model).handle, pop.handle, theta.data_ptr(), P, cand.data_ptr(),
                                                       P, reps, torch.cuda.current_stream(dev).cuda_stream, C.byref(ms_c)))
         ms = ms_c.value
+        if log is not None:
+            log.append((int(cand.data_ptr()), ms))
         if ms < best_ms:
             best, best_ms = cand, ms
     held.clear()

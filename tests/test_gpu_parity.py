@@ -581,3 +581,35 @@ def test_state_vectors_at_the_observation_times():
                 d.out[o].state, d.out[o].vol_src, d.out[o].vol_index = st, _abi.PMX_SRC_NONE, 0
             want, _ = oracle.predict(d, flat, theta)
             assert rel_err(got[:, st, :], want).max() < (TOL_ODE if "ode" in m.kernel_name or m.eq_kind == _abi.PMX_EQ_ODE else TOL_ANALYTICAL)
+
+
+def test_status_bytes_cleared_by_the_kernel_itself():
+    """When the classed kernel serves every subject it clears its own status bytes (no memset between passes): a dirty
+    status buffer must come back clean where pairs are healthy and flagged where they are not, pass after pass."""
+    import torch
+
+    m, flat, theta = synth.config_c3(203, 64)  # 203: partial last chunk; 64 % 8 == 0
+    th = theta.copy()
+    th[5, 3] = 0.0   # v = 0 -> non-finite predictions for support point 5
+    th[9, :3] = [1.0, -1.0, 1.0]  # (ke + kcp + kpc)^2 < 4 ke kpc: complex eigenvalues for support point 9
+    pop = runtime.DevicePopulation(flat, 0)
+    status = torch.full((flat.n_subjects, 64), 77, dtype=torch.uint8, device="cuda")  # dirty on purpose
+    for _ in range(2):
+        pred, st = runtime.predict(m, pop, th, status=status)
+        torch.cuda.synchronize()
+        assert runtime.last_kernel_name() == "pmx_analytical_classed"
+        got = st.cpu().numpy()
+        want, wst = oracle.predict(m, flat, th)
+        np.testing.assert_array_equal(got, wst)
+        assert (got[:, 5] == _abi.PMX_PAIR_NONFINITE).all() and (got[:, 9] == _abi.PMX_PAIR_COMPLEX_ROOTS).all()
+        status.fill_(13)  # dirty again before the second pass
+    # a population with an empty subject keeps the memset path (the kernel never visits that subject)
+    subs = [Subject.builder("empty").build()] + [
+        Subject.builder(f"s{i}").infusion(0.0, 500.0, "iv", 0.5).missing_observation(1.0, "cp").missing_observation(2.0, "cp").build()
+        for i in range(16)]
+    flat2 = m.flatten(Data(subs))
+    pop2 = runtime.DevicePopulation(flat2, 0)
+    status2 = torch.full((17, 64), 55, dtype=torch.uint8, device="cuda")
+    _, st2 = runtime.predict(m, pop2, theta, status=status2)
+    torch.cuda.synchronize()
+    assert (st2.cpu().numpy() == 0).all()

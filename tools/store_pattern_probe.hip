@@ -380,6 +380,53 @@ static int vmm_study() {
   return 0;
 }
 
+// How many write fronts?  Spread members, one chunk per block, GG members per chunk (argv[1] = "fronts")
+template <int GG>
+__global__ __launch_bounds__(256) void k_fronts(double* out, int64_t n_chunks, int n_ptiles) {
+  const int64_t b = blockIdx.x;
+  const int64_t group = b / (8 * n_ptiles);
+  const int local = static_cast<int>(b % (8 * n_ptiles));
+  const int ptile = local / 8;
+  const int64_t c = group * 8 + (local % 8);
+  if (c >= n_chunks) return;
+  const unsigned lane = threadIdx.x & 63u;
+  const bool upper = lane >= 32u;
+  const int64_t p_even = static_cast<int64_t>(ptile) * 256 + (threadIdx.x & ~63u) + 2u * (lane & 31u);
+  const bool ok = p_even + 1 < P;
+  for (int k = 0; k < O; ++k) {
+#pragma unroll
+    for (int h = 0; h < (GG + 1) / 2; ++h) {
+      const int j = 2 * h + (upper ? 1 : 0);
+      const int64_t subj = c + static_cast<int64_t>(j) * n_chunks;
+      const int64_t row = subj * O + k;
+      if (ok && j < GG && subj < S) st16<true>(out + row * P + p_even, 1.0, 2.0);
+    }
+  }
+}
+
+static int fronts_study() {
+  const size_t big = ROWS * P * 8;
+  void* pad = nullptr;
+  for (int trial = 0; trial < 4; ++trial) {
+    if (trial % 2) CK(hipMalloc(&pad, 97u << 20));
+    double* out = nullptr;
+    CK(hipMalloc(&out, big));
+    CK(hipMemset(out, 0, big));
+    std::printf("allocation %d\n", trial);
+#define FRONTS(GG)                                                                                              \
+    {                                                                                                            \
+      const int64_t nc = (S + GG - 1) / GG;                                                                      \
+      const int64_t cb = (nc + 7) / 8 * 8;                                                                       \
+      run("  " #GG " fronts", [&] { hipLaunchKernelGGL((k_fronts<GG>), dim3(cb * 4), dim3(256), 0, 0, out, nc, 4); }); \
+    }
+    FRONTS(1) FRONTS(2) FRONTS(4) FRONTS(8) FRONTS(16) FRONTS(32)
+    CK(hipFree(out));
+    if (pad) CK(hipFree(pad));
+    pad = nullptr;
+  }
+  return 0;
+}
+
 static int alloc2_study() {
   const int64_t n_chunks = S / G;
   const int cpb = 6;
@@ -431,6 +478,7 @@ int main(int argc, char** argv) {
   if (argc > 1 && std::string(argv[1]) == "stride") return stride_study();
   if (argc > 1 && std::string(argv[1]) == "alloc3") return alloc3_study();
   if (argc > 1 && std::string(argv[1]) == "vmm") return vmm_study();
+  if (argc > 1 && std::string(argv[1]) == "fronts") return fronts_study();
   double* out = nullptr;
   CK(hipMalloc(&out, ROWS * P * 8));
   CK(hipMemset(out, 0, ROWS * P * 8));
