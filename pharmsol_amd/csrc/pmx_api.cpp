@@ -728,7 +728,8 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
   if (blocks > 0x7fffffffLL) return fail(PMX_ERR_INVALID_ARGUMENT, "grid too large for one launch");
   // the classed kernel can clear its own status bytes (no memset between passes) when it serves every subject
   a.cls.zero_status = (d_status != nullptr && a.mode == pmx::MODE_GRID && a.use_classes && ds->cls.n_generic == 0 &&
-                       ds->n_classed_subjects == a.S /* no empty subject either */ && ds->cls.G <= 8 && P % 8 == 0 && !model->custom &&
+                       ds->n_classed_subjects == a.S /* no empty subject either */ && ds->cls.G <= 8 && P % 8 == 0 &&
+                       reinterpret_cast<uintptr_t>(d_status) % 8 == 0 && !model->custom &&
                        d.eq_kind == PMX_EQ_ANALYTICAL)
                           ? 1
                           : 0;
