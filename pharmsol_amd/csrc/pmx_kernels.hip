@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kBlock, (!LAG && LaneModel<KID>::NS <= 2) ? 4 : ((!
                                                               int64_t P, int64_t S, int32_t s_chunk, int32_t n_ptiles,
                                                               double* __restrict__ pred, int64_t ld,
                                                               uint8_t* __restrict__ status,
-                                                              const int32_t* __restrict__ subj_list) {
+                                                              const int32_t* __restrict__ subj_list, int32_t zero_status) {
   using LM = LaneModel<KID>;
   constexpr int NS = LM::NS;
   const int64_t b = blockIdx.x;
@@ -265,6 +265,11 @@ __global__ __launch_bounds__(kBlock, (!LAG && LaneModel<KID>::NS <= 2) ? 4 : ((!
     double xpad = 0.0;
     double ll_acc = 0.0;
     uint8_t st = st_lane;
+    if (zero_status && status != nullptr) {  // the wave clears this subject's status bytes for its 64 support points
+      const uint32_t zl = threadIdx.x & 63u;  // (8 lanes x 8 bytes; launcher guarantees n_support % 8 == 0)
+      const int64_t zp = static_cast<int64_t>(ptile) * kBlock + (threadIdx.x & ~63u) + 8 * zl;
+      if (zl < 8u && zp < P) *reinterpret_cast<uint64_t*>(status + s * P + zp) = 0ull;
+    }
     for (int64_t o = o0; o < o1; ++o) {
       const uint32_t meta = c_op_meta[o];
       const uint32_t kind = meta & 0xffu;
@@ -319,7 +324,10 @@ __global__ __launch_bounds__(kBlock, (!LAG && LaneModel<KID>::NS <= 2) ? 4 : ((!
       if (st == PMX_PAIR_OK && !isfinite(ll_acc)) st = PMX_PAIR_NONFINITE;  // NonFiniteLikelihood (prediction.rs:119-124)
       if (lane_ok) ops.ll_out[s * ops.ll_ld + p] = (st == PMX_PAIR_OK || st == PMX_PAIR_NONFINITE) ? ll_acc : nanv;
     }
-    if (status != nullptr && lane_ok && st != PMX_PAIR_OK) status[s * P + p] = st;  // array pre-zeroed by the library
+    if (status != nullptr && lane_ok && st != PMX_PAIR_OK) {
+      if (zero_status) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clearing store above lands first
+      status[s * P + p] = st;  // (array pre-zeroed by the library or by this wave)
+    }
   }
 }
 
@@ -844,10 +852,10 @@ hipError_t launch_analytical(const LaunchArgs& a, const char** name) {
     const int64_t blocks = n_chunks * a.n_ptiles;
     if (a.ops.ll_obs != nullptr)
       hipLaunchKernelGGL((pmx_analytical_grid<KID, DYN, LAG, true>), dim3(static_cast<uint32_t>(blocks)), dim3(grid_threads(a.P)), 0, st,
-                         a.m, a.ops, a.theta, a.P, n_walk, s_chunk, a.n_ptiles, a.pred, a.ld, a.status, list);
+                         a.m, a.ops, a.theta, a.P, n_walk, s_chunk, a.n_ptiles, a.pred, a.ld, a.status, list, a.cls.zero_status);
     else
       hipLaunchKernelGGL((pmx_analytical_grid<KID, DYN, LAG, false>), dim3(static_cast<uint32_t>(blocks)), dim3(grid_threads(a.P)), 0, st,
-                         a.m, a.ops, a.theta, a.P, n_walk, s_chunk, a.n_ptiles, a.pred, a.ld, a.status, list);
+                         a.m, a.ops, a.theta, a.P, n_walk, s_chunk, a.n_ptiles, a.pred, a.ld, a.status, list, a.cls.zero_status);
   } else {
     *name = kNamePair;
     const int64_t n_pairs = a.batch ? a.S : a.S * a.P;
