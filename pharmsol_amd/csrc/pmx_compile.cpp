@@ -509,7 +509,10 @@ void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, i
   std::vector<std::vector<int32_t>> members;
   for (int64_t s = 0; s < S; ++s) {
     const int64_t o0 = os.subj_op_off[s], o1 = os.subj_op_off[s + 1];
-    if (o1 == o0) continue;  // nothing to do for an empty subject
+    if (o1 == o0) {  // an empty subject: nothing to compute, but the generic walker still owns its status bytes
+      cp->generic_subjects.push_back(static_cast<int32_t>(s));
+      continue;
+    }
     uint64_t h = static_cast<uint64_t>(o1 - o0);
     for (int64_t o = o0; o < o1; ++o) h = mix64(h, sig_key(o));
     auto& ids = buckets[h];

@@ -265,8 +265,10 @@ __global__ __launch_bounds__(kBlock, (!LAG && LaneModel<KID>::NS <= 2) ? 4 : ((!
     double xpad = 0.0;
     double ll_acc = 0.0;
     uint8_t st = st_lane;
-    if (zero_status && status != nullptr) {  // the wave clears this subject's status bytes for its 64 support points
-      const uint32_t zl = threadIdx.x & 63u;  // (8 lanes x 8 bytes; launcher guarantees n_support % 8 == 0)
+    // status bytes: no memset precedes the launch.  mode 1 (n_support % 8 == 0, aligned array): the wave clears this
+    // subject's 64 bytes with 8 lanes x 8 bytes and only failures are written later; mode 2: every pair's byte is written.
+    if (zero_status == 1 && status != nullptr) {
+      const uint32_t zl = threadIdx.x & 63u;
       const int64_t zp = static_cast<int64_t>(ptile) * kBlock + (threadIdx.x & ~63u) + 8 * zl;
       if (zl < 8u && zp < P) *reinterpret_cast<uint64_t*>(status + s * P + zp) = 0ull;
     }
@@ -324,9 +326,9 @@ __global__ __launch_bounds__(kBlock, (!LAG && LaneModel<KID>::NS <= 2) ? 4 : ((!
       if (st == PMX_PAIR_OK && !isfinite(ll_acc)) st = PMX_PAIR_NONFINITE;  // NonFiniteLikelihood (prediction.rs:119-124)
       if (lane_ok) ops.ll_out[s * ops.ll_ld + p] = (st == PMX_PAIR_OK || st == PMX_PAIR_NONFINITE) ? ll_acc : nanv;
     }
-    if (status != nullptr && lane_ok && st != PMX_PAIR_OK) {
-      if (zero_status) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clearing store above lands first
-      status[s * P + p] = st;  // (array pre-zeroed by the library or by this wave)
+    if (status != nullptr && lane_ok && (st != PMX_PAIR_OK || zero_status == 2)) {
+      if (zero_status == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clearing store above lands first
+      status[s * P + p] = st;
     }
   }
 }
@@ -470,7 +472,7 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
     const int64_t pb = cls_prog_off[cls];
     const int64_t pe = cls_prog_off[cls + 1];
     int64_t kld = 0;   // (observations emitted so far) * ld
-    if (cp.zero_status && status != nullptr) {
+    if (cp.zero_status == 1 && status != nullptr) {
       // The wave clears the status bytes it owns (G members x its 64 support points) with ONE 8-byte store per lane:
       // lane = 8 * member + piece.  A separate memset between two passes cost ~70 us of serialisation per pass, this
       // costs one store per chunk.  (Launcher guarantees n_support % 8 == 0 and G <= 8 when the flag is set.)
@@ -596,14 +598,14 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
     }
     // status bytes: the library zeroes the array before the launch (PMX_PAIR_OK == 0); only failures are
     // written here, so the healthy case issues no byte stores at all
-    if (status != nullptr && __any(((bad != 0u || !lane_good) && lane_ok) ? 1 : 0)) {
-      if (cp.zero_status) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clearing store above lands first
+    if (status != nullptr && (cp.zero_status == 2 || __any(((bad != 0u || !lane_good) && lane_ok) ? 1 : 0))) {
+      if (cp.zero_status == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clearing store above lands first
 #pragma unroll
       for (int j = 0; j < G; ++j) {
         if (j < n_live) {
           const int64_t sid = chunk_subj[c * G + j];
           const uint8_t st = !lane_good ? PMX_PAIR_COMPLEX_ROOTS : (((bad >> j) & 1u) ? PMX_PAIR_NONFINITE : PMX_PAIR_OK);
-          if (lane_ok && st != PMX_PAIR_OK) status[sid * P + p] = st;
+          if (lane_ok && (st != PMX_PAIR_OK || cp.zero_status == 2)) status[sid * P + p] = st;
         }
       }
     }
@@ -697,7 +699,7 @@ __global__ __launch_bounds__(kBlock) void pmx_analytical_pair(DevModel m, DevOps
     if (st == PMX_PAIR_OK && !isfinite(ll_acc)) st = PMX_PAIR_NONFINITE;
     if (lane_ok) ops.ll_out[batch ? s : (s * ops.ll_ld + p)] = (st == PMX_PAIR_OK || st == PMX_PAIR_NONFINITE) ? ll_acc : nanv;
   }
-  if (status != nullptr && lane_ok && st != PMX_PAIR_OK) status[batch ? s : (s * P + p)] = st;  // pre-zeroed
+  if (status != nullptr && lane_ok) status[batch ? s : (s * P + p)] = st;  // every pair writes its byte: no memset before the launch
 }
 
 // ------------------------------------------------------------------------------------

@@ -27,7 +27,8 @@ struct DevClassPlan {
   int64_t n_chunks;
   int64_t n_generic;
   int32_t G;
-  int32_t zero_status;  // 1: the classed kernel clears its own status bytes (no memset before the launch)
+  int32_t zero_status;  // how the analytical GRID kernels own their status bytes (no memset precedes a launch):
+                        // 1 = clear with 8-byte stores, then write failures only; 2 = write every pair's byte
 };
 
 enum LaneMode : int32_t { MODE_GRID = 0, MODE_PAIR = 1 };

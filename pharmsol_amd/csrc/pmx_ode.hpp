@@ -433,7 +433,7 @@ __device__ __forceinline__ void ode_grid_body(const DevModel& m, const DevOps& o
       if (st == PMX_PAIR_OK && !isfinite(ll_acc)) st = PMX_PAIR_NONFINITE;
       if (lane_ok) ops.ll_out[s * ops.ll_ld + p] = (st == PMX_PAIR_OK || st == PMX_PAIR_NONFINITE) ? ll_acc : nanv;
     }
-    if (status != nullptr && lane_ok && st != PMX_PAIR_OK) status[s * P + p] = st;  // array pre-zeroed by the library
+    if (status != nullptr && lane_ok) status[s * P + p] = st;  // every pair writes its byte: no memset before the launch
   }
 }
 
@@ -612,7 +612,7 @@ __device__ __forceinline__ void ode_pair_body(const DevModel& m, const DevOps& o
     if (st == PMX_PAIR_OK && !isfinite(ll_acc)) st = PMX_PAIR_NONFINITE;
     if (lane_ok) ops.ll_out[batch ? s : (s * ops.ll_ld + p)] = (st == PMX_PAIR_OK || st == PMX_PAIR_NONFINITE) ? ll_acc : nanv;
   }
-  if (status != nullptr && lane_ok && st != PMX_PAIR_OK) status[batch ? s : (s * P + p)] = st;  // pre-zeroed
+  if (status != nullptr && lane_ok) status[batch ? s : (s * P + p)] = st;  // every pair writes its byte
 }
 
 }  // namespace
