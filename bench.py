@@ -55,7 +55,7 @@ def main():
                     help="time the fused log-likelihood entry (pmx_loglik_device) instead of predictions: output S x P")
     ap.add_argument("--spin-up-ms", type=float, default=80.0,
                     help="untimed back-to-back passes before the warm-up, to bring the device clocks up after set-up")
-    ap.add_argument("--alloc-tries", type=int, default=6,
+    ap.add_argument("--alloc-tries", type=int, default=8,
                     help="candidate allocations for the prediction matrix; the fastest is kept (runtime.alloc_predictions; "
                          "1 = take the first)")
     ap.add_argument("--ragged", action="store_true",

@@ -95,6 +95,10 @@ def alloc_predictions(model, pop: DevicePopulation, theta, tries: int = 4, reps:
             break
         held.append(cand)
         ms_c = C.c_double()
+        if len(held) == 1:  # bring the device clocks up first, or the first candidate is judged on a cold device
+            _ffi.check(_ffi.lib().pmx_time_predict_device(_as_model(model).handle, pop.handle, theta.data_ptr(), P,
+                                                          cand.data_ptr(), P, 40, torch.cuda.current_stream(dev).cuda_stream,
+                                                          C.byref(ms_c)))
         _ffi.check(_ffi.lib().pmx_time_predict_device(_as_model(model).handle, pop.handle, theta.data_ptr(), P, cand.data_ptr(),
                                                       P, reps, torch.cuda.current_stream(dev).cuda_stream, C.byref(ms_c)))
         ms = ms_c.value
