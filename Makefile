@@ -7,7 +7,7 @@ LIB := pharmsol_amd/lib/libpmx_hip.so
 # lines (slope*t + intercept) exactly like the reference; device code keeps FMA contraction.
 HOSTFLAGS := -O2 -std=c++17 -fPIC -Wall -Wextra -ffp-contract=off -Iinclude
 DEVFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-parameter -Iinclude
-OBJ := $(CSRC)/build/pmx_compile.o $(CSRC)/build/pmx_api.o $(CSRC)/build/pmx_kernels.o $(CSRC)/build/pmx_jit.o
+OBJ := $(CSRC)/build/pmx_compile.o $(CSRC)/build/pmx_api.o $(CSRC)/build/pmx_kernels.o $(CSRC)/build/pmx_jit.o $(CSRC)/build/pmx_alloc.o
 DEVHDR := $(CSRC)/pmx_devtypes.hpp $(CSRC)/pmx_device.hpp $(CSRC)/pmx_ode.hpp include/pmx.h
 
 all: $(LIB) oracle
@@ -28,6 +28,10 @@ $(CSRC)/build/pmx_kernels.o: $(CSRC)/pmx_kernels.hip $(CSRC)/pmx_kernels.hpp $(C
 $(CSRC)/build/pmx_jit_headers.inc: $(DEVHDR) tools/embed_headers.py
 	@mkdir -p $(CSRC)/build
 	python3 tools/embed_headers.py $@ include/pmx.h $(CSRC)/pmx_devtypes.hpp $(CSRC)/pmx_device.hpp $(CSRC)/pmx_ode.hpp
+
+$(CSRC)/build/pmx_alloc.o: $(CSRC)/pmx_alloc.cpp include/pmx.h
+	@mkdir -p $(CSRC)/build
+	$(HIPCC) $(DEVFLAGS) -x hip -c $< -o $@
 
 $(CSRC)/build/pmx_jit.o: $(CSRC)/pmx_jit.cpp $(CSRC)/pmx_jit.hpp $(CSRC)/build/pmx_jit_headers.inc
 	$(HIPCC) $(DEVFLAGS) -I$(CSRC)/build -x hip -c $< -o $@

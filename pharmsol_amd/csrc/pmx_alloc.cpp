@@ -1,0 +1,155 @@
+// pmx_alloc.cpp — placing the prediction matrix where the row-strided write stream runs fastest.
+//
+// On MI355X the rate of the prediction stream depends on WHERE in device memory the matrix sits (the same kernel:
+// 0.81-0.90 ms in some 5.6 GB windows, 1.04-1.12 ms in most; linear fills do not care; tools/store_pattern_probe.hip
+// `arena`).  Nothing in the HIP API says which memory is the fast kind, so this helper measures: it maps
+// an arena out of separately allocated physical chunks (HIP virtual-memory API), times the real kernel into windows
+// of the arena, keeps the chunks under the best window and gives every other chunk back.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "pmx.h"
+
+namespace {
+
+struct Arena {
+  void* va = nullptr;
+  size_t total = 0, chunk = 0;
+  std::vector<hipMemGenericAllocationHandle_t> handles;  // one per chunk
+  std::vector<char> mapped;                              // chunk still mapped?
+};
+std::mutex g_mu;
+std::map<void*, Arena> g_arenas;  // by the pointer handed to the caller
+
+void release(Arena& a) {
+  for (size_t i = 0; i < a.handles.size(); ++i) {
+    if (a.mapped[i]) (void)hipMemUnmap(static_cast<char*>(a.va) + i * a.chunk, a.chunk);
+    (void)hipMemRelease(a.handles[i]);
+  }
+  if (a.va) (void)hipMemAddressFree(a.va, a.total);
+  a = Arena{};
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t pmx_prediction_buffer_create(const pmx_model* model, const pmx_population* pop, const double* d_theta,
+                                     int64_t n_support, int64_t search_bytes, void* stream, double** d_pred,
+                                     double* ms_per_pass) {
+  if (!model || !pop || !d_theta || !d_pred || n_support <= 0) return PMX_ERR_INVALID_ARGUMENT;
+  *d_pred = nullptr;
+  const size_t need = static_cast<size_t>(pmx_population_n_observations(pop)) * static_cast<size_t>(n_support) * sizeof(double);
+  if (need == 0) return PMX_ERR_INVALID_ARGUMENT;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return PMX_ERR_NO_DEVICE;
+  hipMemAllocationProp prop{};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = dev;
+  // physical chunks of 1/8 of the matrix (at least 2 MiB, a multiple of 2 MiB): windows start on chunk boundaries
+  size_t chunk = ((need / 8 + (2u << 20) - 1) / (2u << 20)) * (2u << 20);
+  if (chunk < (2u << 20)) chunk = 2u << 20;
+  const size_t win_chunks = (need + chunk - 1) / chunk;
+  size_t n_chunks = search_bytes > 0 ? static_cast<size_t>(search_bytes) / chunk : 0;
+  if (n_chunks < win_chunks) n_chunks = win_chunks;
+  Arena a;
+  a.chunk = chunk;
+  a.total = n_chunks * chunk;
+  if (hipMemAddressReserve(&a.va, a.total, 0, nullptr, 0) != hipSuccess) return PMX_ERR_OUT_OF_MEMORY;
+  for (size_t i = 0; i < n_chunks; ++i) {
+    hipMemGenericAllocationHandle_t h;
+    if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) break;  // as much as the device gives
+    if (hipMemMap(static_cast<char*>(a.va) + i * chunk, chunk, 0, h, 0) != hipSuccess) {
+      (void)hipMemRelease(h);
+      break;
+    }
+    a.handles.push_back(h);
+    a.mapped.push_back(1);
+  }
+  if (a.handles.size() < win_chunks) {
+    release(a);
+    return PMX_ERR_OUT_OF_MEMORY;
+  }
+  hipMemAccessDesc acc{};
+  acc.location = prop.location;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  if (hipMemSetAccess(a.va, a.handles.size() * chunk, &acc, 1) != hipSuccess) {
+    release(a);
+    return PMX_ERR_HIP;
+  }
+  // clocks up, then time the kernel into every window
+  double ms = 0.0;
+  double* w0 = static_cast<double*>(a.va);
+  int32_t rc = pmx_time_predict_device(model, pop, d_theta, n_support, w0, n_support, 30, stream, &ms);
+  std::vector<double> t;
+  for (size_t i = 0; rc == PMX_OK && i + win_chunks <= a.handles.size(); ++i) {
+    double* w = reinterpret_cast<double*>(static_cast<char*>(a.va) + i * chunk);
+    rc = pmx_time_predict_device(model, pop, d_theta, n_support, w, n_support, 4, stream, &ms);
+    if (std::getenv("PMX_DEBUG_PLACEMENT")) std::fprintf(stderr, "[pmx] window at chunk %zu (%.2f GiB): %.4f ms\n", i, i * chunk / 1073741824.0, ms);
+    t.push_back(ms);
+  }
+  // fast memory comes in plateaus several windows wide: take the window whose worse neighbour is best, i.e. one from
+  // the inside of a plateau rather than its edge
+  size_t best = 0;
+  double best_ms = 1e300;
+  for (size_t i = 0; i < t.size(); ++i) {
+    double score = t[i];
+    if (t.size() >= 3) {
+      if (i > 0) score = score > t[i - 1] ? score : t[i - 1];
+      if (i + 1 < t.size()) score = score > t[i + 1] ? score : t[i + 1];
+    }
+    if (score < best_ms) {
+      best_ms = score;
+      best = i;
+    }
+  }
+  if (!t.empty()) best_ms = t[best];
+  if (rc != PMX_OK) {
+    release(a);
+    return rc;
+  }
+  // give back every chunk outside the chosen window
+  for (size_t i = 0; i < a.handles.size(); ++i) {
+    if (i >= best && i < best + win_chunks) continue;
+    (void)hipMemUnmap(static_cast<char*>(a.va) + i * chunk, chunk);
+    a.mapped[i] = 0;
+    (void)hipMemRelease(a.handles[i]);
+  }
+  {  // what stays: the reservation and the window's chunks (released handles are marked unmapped)
+    double* out = reinterpret_cast<double*>(static_cast<char*>(a.va) + best * chunk);
+    std::lock_guard<std::mutex> lock(g_mu);
+    g_arenas[out] = std::move(a);
+    *d_pred = out;
+  }
+  if (ms_per_pass) *ms_per_pass = best_ms;
+  return PMX_OK;
+}
+
+void pmx_prediction_buffer_destroy(double* d_pred) {
+  if (!d_pred) return;
+  Arena a;
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = g_arenas.find(d_pred);
+    if (it == g_arenas.end()) return;
+    a = std::move(it->second);
+    g_arenas.erase(it);
+  }
+  (void)hipDeviceSynchronize();
+  for (size_t i = 0; i < a.handles.size(); ++i) {
+    if (!a.mapped[i]) continue;
+    (void)hipMemUnmap(static_cast<char*>(a.va) + i * a.chunk, a.chunk);
+    (void)hipMemRelease(a.handles[i]);
+  }
+  if (a.va) (void)hipMemAddressFree(a.va, a.total);
+}
+
+}  // extern "C"

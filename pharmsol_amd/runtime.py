@@ -113,6 +113,44 @@ def alloc_predictions(model, pop: DevicePopulation, theta, tries: int = 4, reps:
     return best
 
 
+class _PlacedBuffer:
+    """Device memory owned by ``pmx_prediction_buffer_create``, exposed to torch through ``__cuda_array_interface__``."""
+
+    def __init__(self, ptr: int, shape, ms: float):
+        self.ptr, self.shape, self.ms_per_pass = int(ptr), tuple(int(x) for x in shape), float(ms)
+        self.__cuda_array_interface__ = {"shape": self.shape, "typestr": "<f8", "data": (self.ptr, False), "version": 3,
+                                         "strides": None}
+
+    def __del__(self):
+        if getattr(self, "ptr", 0) and _ffi is not None and _ffi._lib is not None:
+            _ffi._lib.pmx_prediction_buffer_destroy(C.c_void_p(self.ptr))
+            self.ptr = 0
+
+
+def place_predictions(model, pop: DevicePopulation, theta, search_gib: float = 48.0):
+    """A prediction matrix ``[n_observations, n_support]`` in the fastest window of a ``search_gib`` arena
+    (``pmx_prediction_buffer_create``: physical chunks mapped through the HIP virtual-memory API, the real kernel timed
+    into every window, everything outside the best window returned to the device).  Returns a CUDA tensor; the
+    memory lives as long as the tensor (``tensor._pmx_owner``)."""
+    import torch
+
+    dev = torch.device("cuda", pop.device)
+    if not (isinstance(theta, torch.Tensor) and theta.is_cuda):
+        theta = torch.as_tensor(np.ascontiguousarray(theta, dtype=np.float64), device=dev)
+    theta = theta.contiguous()
+    P = int(theta.shape[0])
+    out, ms = C.c_void_p(), C.c_double()
+    with torch.cuda.device(dev):
+        _ffi.check(_ffi.lib().pmx_prediction_buffer_create(_as_model(model).handle, pop.handle, theta.data_ptr(), P,
+                                                           int(search_gib * (1 << 30)),
+                                                           torch.cuda.current_stream(dev).cuda_stream, C.byref(out),
+                                                           C.byref(ms)))
+    owner = _PlacedBuffer(out.value, (pop.n_observations, P), ms.value)
+    t = torch.as_tensor(owner, device=dev)
+    t._pmx_owner = owner
+    return t
+
+
 def predict_states(model, pop: DevicePopulation, theta, states=None):
     """``Prediction::state`` (likelihood/prediction.rs:18-27) for every observation: a CUDA tensor
     ``[n_observations, len(states), n_support]`` (default: all model states), one ``pmx_predict_state_device`` call

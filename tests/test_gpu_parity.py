@@ -613,3 +613,25 @@ def test_status_bytes_cleared_by_the_kernel_itself():
     _, st2 = runtime.predict(m, pop2, theta, status=status2)
     torch.cuda.synchronize()
     assert (st2.cpu().numpy() == 0).all()
+
+
+def test_placed_prediction_buffer():
+    """pmx_prediction_buffer_create: an arena mapped through the HIP virtual-memory API, the kernel timed into every
+    window, the best window kept and everything else returned.  The buffer behaves like any other device buffer."""
+    import gc
+
+    import torch
+
+    m, flat, theta = synth.config_c3(300, 64)
+    pop = runtime.DevicePopulation(flat, 0)
+    free0 = torch.cuda.mem_get_info()[0]
+    pred = runtime.place_predictions(m, pop, theta, search_gib=0.25)  # the matrix is ~1 MB: chunks of 2 MiB, 128 windows
+    assert pred.shape == (flat.n_observations, 64) and pred.is_cuda and pred._pmx_owner.ms_per_pass > 0
+    assert free0 - torch.cuda.mem_get_info()[0] < (64 << 20)  # only the window's chunks stayed allocated
+    out, st = runtime.predict(m, pop, theta, pred=pred)
+    torch.cuda.synchronize()
+    want, _ = oracle.predict(m, flat, theta)
+    assert rel_err(out.cpu().numpy(), want).max() < TOL_ANALYTICAL
+    del pred, out
+    gc.collect()
+    assert free0 - torch.cuda.mem_get_info()[0] < (8 << 20)

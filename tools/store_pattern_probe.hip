@@ -427,6 +427,42 @@ static int fronts_study() {
   return 0;
 }
 
+// One big arena, the matrix placed at successive offsets inside it (argv[1] = "arena")
+static int arena_study() {
+  const int64_t n_chunks = S / G;
+  const size_t big = ROWS * P * 8;
+  const int64_t cb = (n_chunks + 7) / 8 * 8;
+  const int n_slots = 10;
+  char* base = nullptr;
+  CK(hipMalloc(&base, big * n_slots));
+  CK(hipMemset(base, 0, big * n_slots));
+  for (int rep = 0; rep < 2; ++rep)
+    for (int i = 0; i < n_slots; ++i) {
+      double* out = reinterpret_cast<double*>(base + big * i);
+      char nm[64];
+      std::snprintf(nm, sizeof nm, "arena slot %d (spread, 1 chunk/block)", i);
+      run(nm, [&] { hipLaunchKernelGGL((k_classed_stride<true>), dim3(cb * 4), dim3(256), 0, 0, out, n_chunks, 1, 4, n_chunks); });
+    }
+  // finer map: the matrix start moved in quarter-matrix steps through the same arena
+  std::printf("start_GiB  ms\n");
+  for (size_t off = 0; off + big <= big * n_slots; off += big / 4) {
+    double* out = reinterpret_cast<double*>(base + off);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((k_classed_stride<true>), dim3(cb * 4), dim3(256), 0, 0, out, n_chunks, 1, 4, n_chunks);
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((k_classed_stride<true>), dim3(cb * 4), dim3(256), 0, 0, out, n_chunks, 1, 4, n_chunks);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    std::printf("%8.2f  %.4f\n", off / 1073741824.0, ms / 5);
+  }
+  CK(hipFree(base));
+  return 0;
+}
+
 static int alloc2_study() {
   const int64_t n_chunks = S / G;
   const int cpb = 6;
@@ -479,6 +515,7 @@ int main(int argc, char** argv) {
   if (argc > 1 && std::string(argv[1]) == "alloc3") return alloc3_study();
   if (argc > 1 && std::string(argv[1]) == "vmm") return vmm_study();
   if (argc > 1 && std::string(argv[1]) == "fronts") return fronts_study();
+  if (argc > 1 && std::string(argv[1]) == "arena") return arena_study();
   double* out = nullptr;
   CK(hipMalloc(&out, ROWS * P * 8));
   CK(hipMemset(out, 0, ROWS * P * 8));
