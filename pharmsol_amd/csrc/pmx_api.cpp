@@ -449,6 +449,20 @@ int32_t get_stream(pmx_population* pop, const pmx::CompileKey& key, DeviceStream
   if ((rc = upload(os.op_b, &ds->dev.op_b, &ds->allocs)) != PMX_OK) return rc;
   if ((rc = upload(os.op_n, &ds->dev.op_n, &ds->allocs)) != PMX_OK) return rc;
   if ((rc = upload(os.op_rate, &ds->dev.op_rate, &ds->allocs)) != PMX_OK) return rc;
+  if (key.eq_kind == PMX_EQ_ODE) {  // packed per-op records (pmx_devtypes.hpp DevOps::op_rec)
+    std::vector<double> rec(static_cast<size_t>(os.n_ops) * 6, 0.0);
+    const bool times = !os.op_t0.empty();
+    for (int64_t o = 0; o < os.n_ops; ++o) {
+      const uint64_t w = static_cast<uint64_t>(os.op_meta[o]) | (static_cast<uint64_t>(static_cast<uint32_t>(os.op_n[o])) << 32);
+      std::memcpy(&rec[6 * o], &w, 8);
+      rec[6 * o + 1] = os.op_a[o];
+      rec[6 * o + 2] = os.op_b[o];
+      rec[6 * o + 3] = key.n_rate > 0 ? os.op_rate[o * key.n_rate] : 0.0;
+      rec[6 * o + 4] = times ? os.op_t0[o] : 0.0;
+      rec[6 * o + 5] = times ? os.op_t1[o] : 0.0;
+    }
+    if ((rc = upload(rec, &ds->dev.op_rec, &ds->allocs)) != PMX_OK) return rc;
+  }
   if ((rc = upload(os.op_fac, &ds->dev.op_fac, &ds->allocs)) != PMX_OK) return rc;
   if ((rc = upload(os.op_t0, &ds->dev.op_t0, &ds->allocs)) != PMX_OK) return rc;
   if ((rc = upload(os.op_t1, &ds->dev.op_t1, &ds->allocs)) != PMX_OK) return rc;

@@ -47,6 +47,9 @@ struct DevOps {
   const double* op_b;           // [n_ops]
   const int32_t* op_n;          // [n_ops] (ODE)
   const double* op_rate;        // [n_ops*n_rate] (ODE)
+  const double* op_rec;         // [n_ops][6] (ODE): the op packed for the PAIR kernel, whose lanes each fetch their own
+                                //   op: {meta | n << 32 (bits), a, b, rate[0], t0, t1} = three 16-byte loads of one
+                                //   48-byte record instead of five scattered array reads
   const double* op_fac;         // [n_ops*n_derived*PMX_MAX_FACTORS] covariate factors of the derived values (host-evaluated)
   const double* op_t0;          // lag models: absolute start of each PROP / first event time of a RESET's occasion
   const double* op_t1;          // lag models: absolute end of each PROP

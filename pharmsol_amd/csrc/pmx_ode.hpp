@@ -265,6 +265,24 @@ __device__ __forceinline__ void ode_rates(const DevModel& m, const double* __res
     for (int i = 0; i < M::NS; ++i) rs[i] += (i == dest) ? r : 0.0;
   }
 }
+// ... with the first input's rate (r0 = op_rate[o * n_rate]) already in a register
+template <class M>
+__device__ __forceinline__ void ode_rates(const DevModel& m, const double* __restrict__ op_rate, int64_t o, int n_rate,
+                                          double r0, double (&rs)[M::NR]) {
+  if constexpr (M::CUSTOM) {
+#pragma unroll
+    for (int k = 0; k < M::NR; ++k) rs[k] = (k == 0) ? ((n_rate > 0) ? r0 : 0.0) : ((k < n_rate) ? op_rate[o * n_rate + k] : 0.0);
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < M::NS; ++i) rs[i] = 0.0;
+  for (int k = 0; k < n_rate; ++k) {
+    const double r = (k == 0) ? r0 : op_rate[o * n_rate + k];
+    const int dest = (m.infusion_dest[k] >= 0) ? m.infusion_dest[k] : M::CENTRAL;
+#pragma unroll
+    for (int i = 0; i < M::NS; ++i) rs[i] += (i == dest) ? r : 0.0;
+  }
+}
 
 // One constant-rate piece [t0, t1] whose length is only known on the device (a lagged bolus split it):
 // n = ceil(dt / h_max) classic RK4 steps, the host compiler's rule (pmx_compile.cpp, ODE PROP ops).
@@ -440,6 +458,11 @@ __device__ __forceinline__ void ode_grid_body(const DevModel& m, const DevOps& o
 // PAIR: each lane is a small state machine {cursor o, remaining RK4 steps}; one trip of the
 // wave loop performs either one RK4 step or one op per lane, so lanes in different segments
 // of different subjects still step in lock-step (divergent timelines, C4).
+#ifndef PMX_STEPS_PER_TRIP
+#define PMX_STEPS_PER_TRIP 16
+#endif
+constexpr int kStepsPerTrip = PMX_STEPS_PER_TRIP;  // PAIR mode: RK4 steps (or adaptive attempts) a lane takes per trip
+
 template <class M, bool LAG, bool LL, bool ADAPT>
 __device__ __forceinline__ void ode_pair_body(const DevModel& m, const DevOps& ops, const double* __restrict__ theta,
                                               int64_t P, int64_t S, int32_t batch, double* __restrict__ pred,
@@ -500,13 +523,20 @@ __device__ __forceinline__ void ode_pair_body(const DevModel& m, const DevOps& o
   // need an op wait for the longest piece in the wave (measured: C4 2.4 -> 3.9 ms).
   while ((ADAPT ? stepping : rem > 0) || o < o1) {
     if (ADAPT ? stepping : rem > 0) {
+      // up to kStepsPerTrip steps of the open piece: a trip through this state machine costs ~7 bare RK4 steps of
+      // dx/dt = -ke x + r (tools/rk4_latency_probe.hip: 46 ns/step for a lone wave, 333 ns/trip here), and a batch
+      // of a few 10k pairs is one wave per SIMD, i.e. latency-bound.  Bounded, so a lane that needs its next op
+      // waits for at most kStepsPerTrip steps of its neighbours, not for the longest piece in the wave.
       if constexpr (ADAPT) {
-        stepping = dopri5_advance<M>(m, L, x, rs, t_run, t_run_end, as);  // one attempted step per trip
+        for (int j = 0; j < kStepsPerTrip && stepping; ++j) stepping = dopri5_advance<M>(m, L, x, rs, t_run, t_run_end, as);
       } else {
-        double t = 0.0;
-        if constexpr (M::CUSTOM) t = t_piece + static_cast<double>(n_piece - rem) * h;
-        rk4_step<M>(L, x, rs, t, h);
-        --rem;
+        const int32_t kk = rem < kStepsPerTrip ? rem : kStepsPerTrip;
+        for (int32_t j = 0; j < kk; ++j) {
+          double t = 0.0;
+          if constexpr (M::CUSTOM) t = t_piece + static_cast<double>(n_piece - rem + j) * h;
+          rk4_step<M>(L, x, rs, t, h);
+        }
+        rem -= kk;
       }
     } else if (LAG && in_prop) {
       int which;
@@ -536,27 +566,44 @@ __device__ __forceinline__ void ode_pair_body(const DevModel& m, const DevOps& o
         ++o;
       }
     } else {
-      const uint32_t meta = ops.op_meta[o];
+      // every field of the op is fetched before its kind is looked at: independent loads, one memory latency per
+      // op instead of the chain meta -> kind -> payload (a lone wave per SIMD has nothing to hide either behind)
+      // (and from one packed 48-byte record, DevOps::op_rec: the lanes of a wave read 64 different ops, so every
+      // separate array would be another 64-line gather)
+      const double2* __restrict__ rec = reinterpret_cast<const double2*>(ops.op_rec) + o * 3;
+      const double2 rec0 = rec[0];
+      const double2 rec1 = rec[1];
+      const uint64_t mw = static_cast<uint64_t>(__double_as_longlong(rec0.x));
+      const uint32_t meta = static_cast<uint32_t>(mw);
+      const int32_t op_steps = static_cast<int32_t>(mw >> 32);
+      const double a = rec0.y;
+      const double op_h = rec1.x;
+      const double op_r0 = rec1.y;
+      double op_t0 = 0.0, op_t1 = 0.0;
+      if constexpr (LAG || ADAPT || M::CUSTOM) {
+        const double2 rec2 = rec[2];
+        op_t0 = rec2.x;
+        op_t1 = rec2.y;
+      }
       const uint32_t kind = meta & 0xffu;
       const int io = static_cast<int>((meta >> 8) & 0xffffu);
-      const double a = ops.op_a[o];
       bool next_op = true;  // LAG: a PROP / an occasion opening stays the current op until the branch above closes it
       if (kind == OP_PROP) {
-        ode_rates<M>(m, ops.op_rate, o, ops.n_rate, rs);
+        ode_rates<M>(m, ops.op_rate, o, ops.n_rate, op_r0, rs);
         if constexpr (LAG) {
           in_prop = true;
-          t_cur = ops.op_t0[o];
-          t_stop = ops.op_t1[o];
+          t_cur = op_t0;
+          t_stop = op_t1;
           next_op = false;
         } else if constexpr (ADAPT) {
-          t_run = ops.op_t0[o];
-          t_run_end = ops.op_t1[o];
+          t_run = op_t0;
+          t_run_end = op_t1;
           stepping = t_run_end > t_run;
         } else {
-          h = ops.op_b[o];
-          rem = ops.op_n[o];
+          h = op_h;
+          rem = op_steps;
           if constexpr (M::CUSTOM) {
-            t_piece = ops.op_t0[o];
+            t_piece = op_t0;
             n_piece = rem;
           }
         }
@@ -594,7 +641,7 @@ __device__ __forceinline__ void ode_pair_body(const DevModel& m, const DevOps& o
           // boluses landing before the occasion's first remaining event open the occasion (zero rates there)
           int which;
           const double tau = lag_next(m, ops, ls, which);
-          const double t_first = ops.op_t0[o];
+          const double t_first = op_t0;
           if (tau < t_first && t_first < inf) {
 #pragma unroll
             for (int j = 0; j < M::NR; ++j) rs[j] = 0.0;
