@@ -462,6 +462,17 @@ int32_t get_stream(pmx_population* pop, const pmx::CompileKey& key, DeviceStream
       rec[6 * o + 5] = times ? os.op_t1[o] : 0.0;
     }
     if ((rc = upload(rec, &ds->dev.op_rec, &ds->allocs)) != PMX_OK) return rc;
+  } else {  // analytical: {meta (bits), a, b, t0} = 32 bytes
+    std::vector<double> rec(static_cast<size_t>(os.n_ops) * 4, 0.0);
+    const bool times = !os.op_t0.empty();
+    for (int64_t o = 0; o < os.n_ops; ++o) {
+      const uint64_t w = static_cast<uint64_t>(os.op_meta[o]);
+      std::memcpy(&rec[4 * o], &w, 8);
+      rec[4 * o + 1] = os.op_a[o];
+      rec[4 * o + 2] = os.op_b[o];
+      rec[4 * o + 3] = times ? os.op_t0[o] : 0.0;
+    }
+    if ((rc = upload(rec, &ds->dev.op_rec, &ds->allocs)) != PMX_OK) return rc;
   }
   if ((rc = upload(os.op_fac, &ds->dev.op_fac, &ds->allocs)) != PMX_OK) return rc;
   if ((rc = upload(os.op_t0, &ds->dev.op_t0, &ds->allocs)) != PMX_OK) return rc;
@@ -685,6 +696,13 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
     }
   }
   a.ops = ds->dev;
+  {
+    // ODE PAIR kernel, steps per trip of the lane state machine (pmx_ode.hpp ode_pair_body): tools/steps_per_trip_sweep.sh
+    const int64_t n_pairs = batch ? pop->hp.n_subjects : pop->hp.n_subjects * P;
+    int32_t spt = n_pairs <= 131072 ? 32 : 16;
+    if (const char* e = std::getenv("PMX_TUNE_STEPS_PER_TRIP")) spt = std::atoi(e) > 0 ? std::atoi(e) : spt;
+    a.ops.steps_per_trip = spt;
+  }
   a.theta = d_theta;
   a.P = batch ? 1 : P;
   a.S = pop->hp.n_subjects;

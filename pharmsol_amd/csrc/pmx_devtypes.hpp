@@ -47,9 +47,9 @@ struct DevOps {
   const double* op_b;           // [n_ops]
   const int32_t* op_n;          // [n_ops] (ODE)
   const double* op_rate;        // [n_ops*n_rate] (ODE)
-  const double* op_rec;         // [n_ops][6] (ODE): the op packed for the PAIR kernel, whose lanes each fetch their own
-                                //   op: {meta | n << 32 (bits), a, b, rate[0], t0, t1} = three 16-byte loads of one
-                                //   48-byte record instead of five scattered array reads
+  const double* op_rec;         // the ops packed for the PAIR kernels, whose lanes each fetch their own op: one record
+                                //   instead of up to five scattered array reads.  ODE: [n_ops][6] = {meta | n << 32
+                                //   (bits), a, b, rate[0], t0, t1}; analytical: [n_ops][4] = {meta (bits), a, b, t0}
   const double* op_fac;         // [n_ops*n_derived*PMX_MAX_FACTORS] covariate factors of the derived values (host-evaluated)
   const double* op_t0;          // lag models: absolute start of each PROP / first event time of a RESET's occasion
   const double* op_t1;          // lag models: absolute end of each PROP
@@ -63,6 +63,7 @@ struct DevOps {
   double* ll_out;               // [n_subjects x ll_ld]
   int64_t ll_ld;
   int32_t n_rate;
+  int32_t steps_per_trip;       // ODE PAIR kernel: RK4 steps (adaptive attempts) a lane takes per trip of its state machine
   int32_t n_cov;                // covariates per occasion (the segment tables below; custom ODE bodies read them)
   // covariate segments of every (occasion, covariate) cell, as HostPopulation holds them (covariate.rs:189-214)
   const int64_t* cov_seg_off;   // [n_occasions*n_cov + 1]

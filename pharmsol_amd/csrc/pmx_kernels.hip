@@ -654,45 +654,59 @@ __global__ __launch_bounds__(kBlock) void pmx_analytical_pair(DevModel m, DevOps
   double xpad = 0.0;
   double ll_acc = 0.0;
   uint8_t st = st_lane;
-  // exec-masked loop: runs while ANY lane of the wave still has ops (each lane exits at its own o1)
-  for (; o < o1; ++o) {
-    const uint32_t meta = ops.op_meta[o];
-    const uint32_t kind = meta & 0xffu;
-    const int io = static_cast<int>((meta >> 8) & 0xffffu);
-    const double a = ops.op_a[o];
-    const double* cov = ops.op_fac + o * (m.n_derived * PMX_MAX_FACTORS);  // this op's covariate factors
-    if (kind == OP_PROP) {
-      const double r = ops.op_b[o];
-      if constexpr (LAG) {
-        lag_prop<LM::ST, NS>(m, ops, ls, ops.op_t0[o], ops.op_t1[o], r, L.coef, th, x);
-      } else if constexpr (DYN) {
-        if (!lane_advance_dyn<KID>(m, L, cov, x, a, r)) st = PMX_PAIR_COMPLEX_ROOTS;
-      } else {
-        advance<LM::ST>(L.coef, x, a, r);
-      }
-      xpad = 0.0;
-    } else if (kind == OP_OBS) {
-      double y = lane_out<KID>(m, L, x, xpad, io, cov);
-      if (st == PMX_PAIR_COMPLEX_ROOTS || st == PMX_PAIR_BAD_LAG) y = nanv;
-      if constexpr (LL) {
-        ll_accumulate(ops.ll_obs + row * 4, y, ll_acc);
-      } else {
-        if (st == PMX_PAIR_OK && !isfinite(y)) st = PMX_PAIR_NONFINITE;
-        pred[row * ld + p] = y;
-      }
-      ++row;
-    } else if (kind == OP_BOLUS) {
-      const int k = io - m.pm;
-      const double amt = a * fa_of(m, th, io);
+  // exec-masked loop: runs while ANY lane of the wave still has ops (each lane exits at its own o1).  Every lane reads
+  // its own op, so a fetch is a 64-line gather with nothing to hide its latency behind when the batch is a few
+  // thousand pairs (C2: 157 waves on 1024 SIMDs); the ops come as packed 32-byte records (DevOps::op_rec), four
+  // at a time: one memory latency per four ops.
+  const double4* __restrict__ recs = reinterpret_cast<const double4*>(ops.op_rec);
+  for (int64_t og = o; og < o1; og += 4) {
+    const int64_t last = o1 - 1;
+    double4 q = recs[og];
+    double4 q1 = recs[(og + 1 < o1) ? og + 1 : last];
+    double4 q2 = recs[(og + 2 < o1) ? og + 2 : last];
+    double4 q3 = recs[(og + 3 < o1) ? og + 3 : last];
+#pragma unroll 1
+    for (int j = 0; j < 4; ++j, q = q1, q1 = q2, q2 = q3) {  // (rotating the records keeps them in registers)
+      o = og + j;
+      if (o >= o1) break;
+      const uint32_t meta = static_cast<uint32_t>(__double_as_longlong(q.x));
+      const uint32_t kind = meta & 0xffu;
+      const int io = static_cast<int>((meta >> 8) & 0xffffu);
+      const double a = q.y;
+      const double* cov = ops.op_fac + o * (m.n_derived * PMX_MAX_FACTORS);  // this op's covariate factors
+      if (kind == OP_PROP) {
+        const double r = q.z;
+        if constexpr (LAG) {
+          lag_prop<LM::ST, NS>(m, ops, ls, q.w, ops.op_t1[o], r, L.coef, th, x);
+        } else if constexpr (DYN) {
+          if (!lane_advance_dyn<KID>(m, L, cov, x, a, r)) st = PMX_PAIR_COMPLEX_ROOTS;
+        } else {
+          advance<LM::ST>(L.coef, x, a, r);
+        }
+        xpad = 0.0;
+      } else if (kind == OP_OBS) {
+        double y = lane_out<KID>(m, L, x, xpad, io, cov);
+        if (st == PMX_PAIR_COMPLEX_ROOTS || st == PMX_PAIR_BAD_LAG) y = nanv;
+        if constexpr (LL) {
+          ll_accumulate(ops.ll_obs + row * 4, y, ll_acc);
+        } else {
+          if (st == PMX_PAIR_OK && !isfinite(y)) st = PMX_PAIR_NONFINITE;
+          pred[row * ld + p] = y;
+        }
+        ++row;
+      } else if (kind == OP_BOLUS) {
+        const int k = io - m.pm;
+        const double amt = a * fa_of(m, th, io);
 #pragma unroll
-      for (int j = 0; j < NS; ++j) x[j] += (j == k) ? amt : 0.0;
-      if (m.pm && io == 0) xpad += amt;
-    } else {
+        for (int jj = 0; jj < NS; ++jj) x[jj] += (jj == k) ? amt : 0.0;
+        if (m.pm && io == 0) xpad += amt;
+      } else {
 #pragma unroll
-      for (int j = 0; j < NS; ++j) x[j] = io ? L.xinit[j] : 0.0;
-      xpad = 0.0;
-      if constexpr (DYN) st = st_lane;
-      if constexpr (LAG) lag_open_occasion<LM::ST, NS>(m, ops, ls, static_cast<int64_t>(a), ops.op_t0[o], L.coef, th, x);
+        for (int jj = 0; jj < NS; ++jj) x[jj] = io ? L.xinit[jj] : 0.0;
+        xpad = 0.0;
+        if constexpr (DYN) st = st_lane;
+        if constexpr (LAG) lag_open_occasion<LM::ST, NS>(m, ops, ls, static_cast<int64_t>(a), q.w, L.coef, th, x);
+      }
     }
   }
   if constexpr (LL) {

@@ -458,11 +458,6 @@ __device__ __forceinline__ void ode_grid_body(const DevModel& m, const DevOps& o
 // PAIR: each lane is a small state machine {cursor o, remaining RK4 steps}; one trip of the
 // wave loop performs either one RK4 step or one op per lane, so lanes in different segments
 // of different subjects still step in lock-step (divergent timelines, C4).
-#ifndef PMX_STEPS_PER_TRIP
-#define PMX_STEPS_PER_TRIP 16
-#endif
-constexpr int kStepsPerTrip = PMX_STEPS_PER_TRIP;  // PAIR mode: RK4 steps (or adaptive attempts) a lane takes per trip
-
 template <class M, bool LAG, bool LL, bool ADAPT>
 __device__ __forceinline__ void ode_pair_body(const DevModel& m, const DevOps& ops, const double* __restrict__ theta,
                                               int64_t P, int64_t S, int32_t batch, double* __restrict__ pred,
@@ -523,14 +518,16 @@ __device__ __forceinline__ void ode_pair_body(const DevModel& m, const DevOps& o
   // need an op wait for the longest piece in the wave (measured: C4 2.4 -> 3.9 ms).
   while ((ADAPT ? stepping : rem > 0) || o < o1) {
     if (ADAPT ? stepping : rem > 0) {
-      // up to kStepsPerTrip steps of the open piece: a trip through this state machine costs ~7 bare RK4 steps of
-      // dx/dt = -ke x + r (tools/rk4_latency_probe.hip: 46 ns/step for a lone wave, 333 ns/trip here), and a batch
-      // of a few 10k pairs is one wave per SIMD, i.e. latency-bound.  Bounded, so a lane that needs its next op
-      // waits for at most kStepsPerTrip steps of its neighbours, not for the longest piece in the wave.
+      // up to ops.steps_per_trip steps of the open piece: a trip through this state machine costs ~7 bare RK4 steps
+      // of dx/dt = -ke x + r (tools/rk4_latency_probe.hip: 46 ns/step for a lone wave, 333 ns/trip here), and a
+      // batch of a few 10k pairs is one wave per SIMD, i.e. latency-bound.  Bounded, so a lane that needs its next
+      // op waits for at most that many steps of its neighbours, not for the longest piece in the wave; the host
+      // picks the bound from the batch size (pmx_api.cpp).
+      const int32_t spt = ops.steps_per_trip;
       if constexpr (ADAPT) {
-        for (int j = 0; j < kStepsPerTrip && stepping; ++j) stepping = dopri5_advance<M>(m, L, x, rs, t_run, t_run_end, as);
+        for (int32_t j = 0; j < spt && stepping; ++j) stepping = dopri5_advance<M>(m, L, x, rs, t_run, t_run_end, as);
       } else {
-        const int32_t kk = rem < kStepsPerTrip ? rem : kStepsPerTrip;
+        const int32_t kk = rem < spt ? rem : spt;
         for (int32_t j = 0; j < kk; ++j) {
           double t = 0.0;
           if constexpr (M::CUSTOM) t = t_piece + static_cast<double>(n_piece - rem + j) * h;

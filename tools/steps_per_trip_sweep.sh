@@ -1,14 +1,12 @@
 #!/bin/bash
-# PAIR-mode ODE kernel: RK4 steps per trip of the lane state machine (PMX_STEPS_PER_TRIP), libraries built as
-# pharmsol_amd/lib/ab/k<K>.so; C4 at 50k (latency-bound) and 400k subjects (throughput-bound).
+# PAIR-mode ODE kernel: RK4 steps per trip of the lane state machine (PMX_TUNE_STEPS_PER_TRIP) by batch size.
 export PYTHONPATH=$PWD
 mkdir -p gpurun_out
-for k in 1 4 8 16 32; do
-  if [ $k = 8 ]; then unset PMX_LIB; else export PMX_LIB=pharmsol_amd/lib/ab/k$k.so; fi
-  for n in 50000 400000; do
-    python bench.py --workload c4 --subjects $n --no-cpu-baseline 2>/dev/null | python -c "
+for n in 12500 50000 100000 200000 400000; do
+  for k in 1 8 16 32 64 128; do
+    PMX_TUNE_STEPS_PER_TRIP=$k python bench.py --workload c4 --subjects $n --no-cpu-baseline 2>/dev/null | python -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('K=$k subjects %7d  %.3f ms  %.3e steps/s  err %.2e' % (d['config']['subjects_per_gpu'], d['ms_per_step'], d['value'], d['max_rel_err_vs_cpu_ref']))" | tee -a gpurun_out/steps_per_trip.txt
+print('subjects %7d K=%3d  %.3f ms  %.3e steps/s  err %.2e' % (d['config']['subjects_per_gpu'], $k, d['ms_per_step'], d['value'], d['max_rel_err_vs_cpu_ref']))" | tee -a gpurun_out/steps_per_trip.txt
   done
 done
