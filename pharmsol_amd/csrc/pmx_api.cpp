@@ -699,7 +699,7 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
   {
     // ODE PAIR kernel, steps per trip of the lane state machine (pmx_ode.hpp ode_pair_body): tools/steps_per_trip_sweep.sh
     const int64_t n_pairs = batch ? pop->hp.n_subjects : pop->hp.n_subjects * P;
-    int32_t spt = n_pairs <= 131072 ? 32 : 16;
+    int32_t spt = n_pairs <= 131072 ? 48 : 32;
     if (const char* e = std::getenv("PMX_TUNE_STEPS_PER_TRIP")) spt = std::atoi(e) > 0 ? std::atoi(e) : spt;
     a.ops.steps_per_trip = spt;
   }

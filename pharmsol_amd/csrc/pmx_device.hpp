@@ -66,6 +66,15 @@ struct LagState {
   int32_t end[kMaxLagSlots];
 };
 
+// table[input] of a per-input model table for a lane-varying input: a select chain over the (scalar) entries, where
+// indexing the kernel argument would be a vector load from memory
+__device__ __forceinline__ int input_entry(const int32_t (&table)[PMX_MAX_INPUTS], int input) {
+  int v = -1;
+#pragma unroll
+  for (int i = 0; i < PMX_MAX_INPUTS; ++i) v = (i == input) ? table[i] : v;
+  return v;
+}
+
 __device__ __forceinline__ double fa_of(const DevModel& m, const double* __restrict__ th, int input) {
   double f = 1.0;
   if (m.has_fa) {  // wave-uniform; models without bioavailability never enter

@@ -436,7 +436,8 @@ __device__ __forceinline__ void ode_grid_body(const DevModel& m, const DevOps& o
         }
         ++row;
       } else if (kind == OP_BOLUS) {
-        const int dest = (m.bolus_dest[io] >= 0) ? m.bolus_dest[io] : io;
+        const int bd = input_entry(m.bolus_dest, io);
+        const int dest = (bd >= 0) ? bd : io;
         const double amt = a * fa_of(m, th, io);
 #pragma unroll
         for (int i = 0; i < NS; ++i) x[i] += (i == dest) ? amt : 0.0;
@@ -493,6 +494,15 @@ __device__ __forceinline__ void ode_pair_body(const DevModel& m, const DevOps& o
   int64_t o = ops.subj_op_off[s];
   const int64_t o1 = lane_ok ? ops.subj_op_off[s + 1] : o;
   int64_t row = ops.subj_obs_off[s];
+  // The lane's next ops wait in LDS: a ring of kRing packed records per lane (DevOps::op_rec), topped up for EVERY
+  // lane of the wave whenever one lane runs dry.  Lanes consume their ops at their own pace, so without the ring
+  // nearly every trip had some lane waiting for a gather from HBM/L2 (~0.7 us with one wave per SIMD) and the whole
+  // wave with it; with it a wave waits for memory a handful of times per kernel and an op costs an LDS read.
+  constexpr int kRing = 4;
+  constexpr int kOpsPerTrip = 2;  // (3 or 4 measure the same on C4)
+  constexpr int kParts = (LAG || ADAPT || M::CUSTOM) ? 3 : 2;  // 16-byte parts of a record this variant reads
+  __shared__ double2 ring[kRing * kParts * kBlock];
+  int64_t filled = o;  // ops [o, filled) are in the ring, op k in slot k % kRing
   double x[NS], rs[M::NR];
 #pragma unroll
   for (int k = 0; k < NS; ++k) x[k] = 0.0;
@@ -517,6 +527,171 @@ __device__ __forceinline__ void ode_pair_body(const DevModel& m, const DevOps& o
   // chain: with `continue`s the compiler rotates the stepping branch into an inner per-lane loop and lanes that
   // need an op wait for the longest piece in the wave (measured: C4 2.4 -> 3.9 ms).
   while ((ADAPT ? stepping : rem > 0) || o < o1) {
+    {
+      const bool busy = (ADAPT ? stepping : rem > 0) || (LAG && in_prop);
+      const bool dry = !busy && o < o1 && o == filled;
+      if (__ballot(dry) != 0ull) {  // wave-uniform: every lane fills its free slots, all gathers in flight together
+        const double2* __restrict__ recs = reinterpret_cast<const double2*>(ops.op_rec);
+        const int64_t stop = (o + kRing < o1) ? (o + kRing) : o1;
+        // (named values and clamped addresses instead of an array under per-lane conditions: that form ended up in
+        // scratch memory; a lane with nothing to fetch re-reads a record it already holds, or op 0 of the stream)
+        static_assert(kRing == 4, "the top-up below is written out for four slots");
+        const int64_t k0 = filled, k1 = filled + 1, k2 = filled + 2, k3 = filled + 3;
+        const int64_t safe = (stop > 0) ? (stop - 1) : 0;
+        const int64_t c0 = (k0 < stop) ? k0 : safe, c1 = (k1 < stop) ? k1 : safe, c2 = (k2 < stop) ? k2 : safe,
+                      c3 = (k3 < stop) ? k3 : safe;
+        const double2 a0 = recs[c0 * 3], b0 = recs[c0 * 3 + 1];
+        const double2 a1 = recs[c1 * 3], b1 = recs[c1 * 3 + 1];
+        const double2 a2 = recs[c2 * 3], b2 = recs[c2 * 3 + 1];
+        const double2 a3 = recs[c3 * 3], b3 = recs[c3 * 3 + 1];
+        double2 e0 = a0, e1 = a0, e2 = a0, e3 = a0;
+        if constexpr (kParts == 3) {
+          e0 = recs[c0 * 3 + 2];
+          e1 = recs[c1 * 3 + 2];
+          e2 = recs[c2 * 3 + 2];
+          e3 = recs[c3 * 3 + 2];
+        }
+        const auto stash = [&](const double2& ra, const double2& rb, const double2& rc, int64_t k) {
+          if (k < stop) {
+            const int slot = static_cast<int>(k & (kRing - 1));
+            ring[(slot * kParts + 0) * kBlock + threadIdx.x] = ra;
+            ring[(slot * kParts + 1) * kBlock + threadIdx.x] = rb;
+            if constexpr (kParts == 3) ring[(slot * kParts + 2) * kBlock + threadIdx.x] = rc;
+          }
+        };
+        stash(a0, b0, e0, k0);
+        stash(a1, b1, e1, k1);
+        stash(a2, b2, e2, k2);
+        stash(a3, b3, e3, k3);
+        if (stop > filled) filled = stop;
+      }
+    }
+    // Op phase: a lane that is not inside a piece takes up to kOpsPerTrip actions (ops from its ring, lag sub-piece
+    // decisions), so an observation followed by a PROP reaches the stepping phase of the SAME trip; with one action
+    // per trip every op of a lane cost it a whole trip of its neighbours' stepping (C4: 45 ops against ~190 stepping
+    // trips per lane).  Bounded like the stepping, and again one if / else chain per action.
+#pragma unroll 1
+    for (int act = 0; act < kOpsPerTrip; ++act) {
+      const bool idle = !(ADAPT ? stepping : rem > 0);
+      if (idle && LAG && in_prop) {
+        int which;
+        const double tau = lag_next(m, ops, ls, which);
+        const bool bol = tau < t_stop;
+        const double stop = bol ? tau : t_stop;
+        if (stop > t_cur) {  // next sub-piece; n = ceil(dt / h_max) as ode_piece
+          if constexpr (ADAPT) {
+            stepping = true;
+            t_run = t_cur;
+            t_run_end = stop;
+          } else {
+            const double dt = stop - t_cur;
+            double nf = ceil(dt / m.rk4_h_max);
+            if (!(nf >= 1.0)) nf = 1.0;
+            if (nf > 1.0e7) nf = 1.0e7;
+            rem = static_cast<int32_t>(nf);
+            h = dt / static_cast<double>(rem);
+            t_piece = t_cur;
+            n_piece = rem;
+          }
+          t_cur = stop;
+        } else if (bol) {
+          lag_apply_bolus<NS>(m, ops, ls, which, th, x);
+        } else {
+          in_prop = false;
+          ++o;
+        }
+      } else if (idle && o < filled) {
+        // every field of the op is fetched before its kind is looked at: independent loads, one memory latency per
+        // op instead of the chain meta -> kind -> payload (a lone wave per SIMD has nothing to hide either behind)
+        // (and from one packed 48-byte record, DevOps::op_rec, that the top-up above left in the lane's ring: the lanes of
+        // a wave read 64 different ops, so every separate array would be another 64-line gather)
+        const int slot = static_cast<int>(o & (kRing - 1));
+        const double2 rec0 = ring[(slot * kParts + 0) * kBlock + threadIdx.x];
+        const double2 rec1 = ring[(slot * kParts + 1) * kBlock + threadIdx.x];
+        const uint64_t mw = static_cast<uint64_t>(__double_as_longlong(rec0.x));
+        const uint32_t meta = static_cast<uint32_t>(mw);
+        const int32_t op_steps = static_cast<int32_t>(mw >> 32);
+        const double a = rec0.y;
+        const double op_h = rec1.x;
+        const double op_r0 = rec1.y;
+        double op_t0 = 0.0, op_t1 = 0.0;
+        if constexpr (LAG || ADAPT || M::CUSTOM) {
+          const double2 rec2 = ring[(slot * kParts + (kParts - 1)) * kBlock + threadIdx.x];
+          op_t0 = rec2.x;
+          op_t1 = rec2.y;
+        }
+        const uint32_t kind = meta & 0xffu;
+        const int io = static_cast<int>((meta >> 8) & 0xffffu);
+        bool next_op = true;  // LAG: a PROP / an occasion opening stays the current op until the branch above closes it
+        if (kind == OP_PROP) {
+          ode_rates<M>(m, ops.op_rate, o, ops.n_rate, op_r0, rs);
+          if constexpr (LAG) {
+            in_prop = true;
+            t_cur = op_t0;
+            t_stop = op_t1;
+            next_op = false;
+          } else if constexpr (ADAPT) {
+            t_run = op_t0;
+            t_run_end = op_t1;
+            stepping = t_run_end > t_run;
+          } else {
+            h = op_h;
+            rem = op_steps;
+            if constexpr (M::CUSTOM) {
+              t_piece = op_t0;
+              n_piece = rem;
+            }
+          }
+        } else if (kind == OP_OBS) {
+          double y = ode_out<M>(m, L, x, io, a);
+          if (LAG && st == PMX_PAIR_BAD_LAG) y = nanv;
+          if (ADAPT && as.failed) {
+            if (st == PMX_PAIR_OK) st = PMX_PAIR_SOLVER_FAIL;
+            y = nanv;
+          }
+          if constexpr (LL) {
+            ll_accumulate(ops.ll_obs + row * 4, y, ll_acc);
+          } else {
+            if (st == PMX_PAIR_OK && !isfinite(y)) st = PMX_PAIR_NONFINITE;
+            pred[row * ld + p] = y;
+          }
+          ++row;
+        } else if (kind == OP_BOLUS) {
+          const int bd = input_entry(m.bolus_dest, io);
+          const int dest = (bd >= 0) ? bd : io;
+          const double amt = a * fa_of(m, th, io);
+  #pragma unroll
+          for (int j = 0; j < NS; ++j) x[j] += (j == dest) ? amt : 0.0;
+        } else {
+          L.occ = static_cast<int64_t>(a);
+          ode_reset<M>(L, io, x);
+          if constexpr (LAG) {
+            const int64_t occ = static_cast<int64_t>(a);
+  #pragma unroll
+            for (int k = 0; k < kMaxLagSlots; ++k) {
+              if (k < m.n_lag_slots) {
+                ls.cur[k] = static_cast<int32_t>(ops.lagb_off[occ * m.n_lag_slots + k]);
+                ls.end[k] = static_cast<int32_t>(ops.lagb_off[occ * m.n_lag_slots + k + 1]);
+              }
+            }
+            // boluses landing before the occasion's first remaining event open the occasion (zero rates there)
+            int which;
+            const double tau = lag_next(m, ops, ls, which);
+            const double t_first = op_t0;
+            if (tau < t_first && t_first < inf) {
+  #pragma unroll
+              for (int j = 0; j < M::NR; ++j) rs[j] = 0.0;
+              in_prop = true;
+              t_cur = tau;
+              t_stop = t_first;
+              next_op = false;
+            }
+          }
+        }
+        if (next_op) ++o;
+      }
+    }  // op phase
+    // Stepping phase
     if (ADAPT ? stepping : rem > 0) {
       // up to ops.steps_per_trip steps of the open piece: a trip through this state machine costs ~7 bare RK4 steps
       // of dx/dt = -ke x + r (tools/rk4_latency_probe.hip: 46 ns/step for a lone wave, 333 ns/trip here), and a
@@ -535,121 +710,6 @@ __device__ __forceinline__ void ode_pair_body(const DevModel& m, const DevOps& o
         }
         rem -= kk;
       }
-    } else if (LAG && in_prop) {
-      int which;
-      const double tau = lag_next(m, ops, ls, which);
-      const bool bol = tau < t_stop;
-      const double stop = bol ? tau : t_stop;
-      if (stop > t_cur) {  // next sub-piece; n = ceil(dt / h_max) as ode_piece
-        if constexpr (ADAPT) {
-          stepping = true;
-          t_run = t_cur;
-          t_run_end = stop;
-        } else {
-          const double dt = stop - t_cur;
-          double nf = ceil(dt / m.rk4_h_max);
-          if (!(nf >= 1.0)) nf = 1.0;
-          if (nf > 1.0e7) nf = 1.0e7;
-          rem = static_cast<int32_t>(nf);
-          h = dt / static_cast<double>(rem);
-          t_piece = t_cur;
-          n_piece = rem;
-        }
-        t_cur = stop;
-      } else if (bol) {
-        lag_apply_bolus<NS>(m, ops, ls, which, th, x);
-      } else {
-        in_prop = false;
-        ++o;
-      }
-    } else {
-      // every field of the op is fetched before its kind is looked at: independent loads, one memory latency per
-      // op instead of the chain meta -> kind -> payload (a lone wave per SIMD has nothing to hide either behind)
-      // (and from one packed 48-byte record, DevOps::op_rec: the lanes of a wave read 64 different ops, so every
-      // separate array would be another 64-line gather)
-      const double2* __restrict__ rec = reinterpret_cast<const double2*>(ops.op_rec) + o * 3;
-      const double2 rec0 = rec[0];
-      const double2 rec1 = rec[1];
-      const uint64_t mw = static_cast<uint64_t>(__double_as_longlong(rec0.x));
-      const uint32_t meta = static_cast<uint32_t>(mw);
-      const int32_t op_steps = static_cast<int32_t>(mw >> 32);
-      const double a = rec0.y;
-      const double op_h = rec1.x;
-      const double op_r0 = rec1.y;
-      double op_t0 = 0.0, op_t1 = 0.0;
-      if constexpr (LAG || ADAPT || M::CUSTOM) {
-        const double2 rec2 = rec[2];
-        op_t0 = rec2.x;
-        op_t1 = rec2.y;
-      }
-      const uint32_t kind = meta & 0xffu;
-      const int io = static_cast<int>((meta >> 8) & 0xffffu);
-      bool next_op = true;  // LAG: a PROP / an occasion opening stays the current op until the branch above closes it
-      if (kind == OP_PROP) {
-        ode_rates<M>(m, ops.op_rate, o, ops.n_rate, op_r0, rs);
-        if constexpr (LAG) {
-          in_prop = true;
-          t_cur = op_t0;
-          t_stop = op_t1;
-          next_op = false;
-        } else if constexpr (ADAPT) {
-          t_run = op_t0;
-          t_run_end = op_t1;
-          stepping = t_run_end > t_run;
-        } else {
-          h = op_h;
-          rem = op_steps;
-          if constexpr (M::CUSTOM) {
-            t_piece = op_t0;
-            n_piece = rem;
-          }
-        }
-      } else if (kind == OP_OBS) {
-        double y = ode_out<M>(m, L, x, io, a);
-        if (LAG && st == PMX_PAIR_BAD_LAG) y = nanv;
-        if (ADAPT && as.failed) {
-          if (st == PMX_PAIR_OK) st = PMX_PAIR_SOLVER_FAIL;
-          y = nanv;
-        }
-        if constexpr (LL) {
-          ll_accumulate(ops.ll_obs + row * 4, y, ll_acc);
-        } else {
-          if (st == PMX_PAIR_OK && !isfinite(y)) st = PMX_PAIR_NONFINITE;
-          pred[row * ld + p] = y;
-        }
-        ++row;
-      } else if (kind == OP_BOLUS) {
-        const int dest = (m.bolus_dest[io] >= 0) ? m.bolus_dest[io] : io;
-        const double amt = a * fa_of(m, th, io);
-#pragma unroll
-        for (int j = 0; j < NS; ++j) x[j] += (j == dest) ? amt : 0.0;
-      } else {
-        L.occ = static_cast<int64_t>(a);
-        ode_reset<M>(L, io, x);
-        if constexpr (LAG) {
-          const int64_t occ = static_cast<int64_t>(a);
-#pragma unroll
-          for (int k = 0; k < kMaxLagSlots; ++k) {
-            if (k < m.n_lag_slots) {
-              ls.cur[k] = static_cast<int32_t>(ops.lagb_off[occ * m.n_lag_slots + k]);
-              ls.end[k] = static_cast<int32_t>(ops.lagb_off[occ * m.n_lag_slots + k + 1]);
-            }
-          }
-          // boluses landing before the occasion's first remaining event open the occasion (zero rates there)
-          int which;
-          const double tau = lag_next(m, ops, ls, which);
-          const double t_first = op_t0;
-          if (tau < t_first && t_first < inf) {
-#pragma unroll
-            for (int j = 0; j < M::NR; ++j) rs[j] = 0.0;
-            in_prop = true;
-            t_cur = tau;
-            t_stop = t_first;
-            next_op = false;
-          }
-        }
-      }
-      if (next_op) ++o;
     }
   }
   if constexpr (LL) {
