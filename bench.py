@@ -63,6 +63,8 @@ def main():
                          "1 = take the first)")
     ap.add_argument("--ragged", action="store_true",
                     help="C3 with per-subject jittered sampling times (no shared design, no related step lengths)")
+    ap.add_argument("--constant-cov", action="store_true",
+                    help="c5: one wt value per subject instead of 2-4 interpolation knots (coefficients kept across PROPs)")
     ap.add_argument("--ld", type=int, default=0, help="leading dimension of the prediction rows (>= support points; 0 = dense)")
     ap.add_argument("--no-class", action="store_true",
                     help="A/B: disable the classed kernel (shared-design propagator reuse); every subject walks the generic kernel")
@@ -125,8 +127,8 @@ def main():
         P = 512 if args.support == 1000 else args.support
         model = synth.model_three_cpt_abs_wt()
         theta = synth.theta_c5(P)
-        flat_global = synth.population_c5(S_local * world)
-        label = f"C5: three_compartments_with_absorption + wt covariate, {S_local} subjects/GPU x {P} support points"
+        flat_global = synth.population_c5(S_local * world, constant_wt=args.constant_cov)
+        label = f"C5: three_compartments_with_absorption + {'subject-constant' if args.constant_cov else 'time-varying'} wt covariate, {S_local} subjects/GPU x {P} support points"
         dtype_tol = 1e-6
     sh = ShardedPopulation(flat_global, rank, world)
     flat = sh.local

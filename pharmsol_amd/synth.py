@@ -172,8 +172,9 @@ def theta_c5(n_support: int = 512, rng: SplitMix64 = None) -> np.ndarray:
     return np.asarray(out[:n_support])
 
 
-def population_c5(n_subjects: int, rng: SplitMix64 = None) -> FlatPopulation:
-    """oral bolus(0, 100..500) q24h x3 + 10 observations; `wt`: 2-4 linear knots per subject in [50,110] kg."""
+def population_c5(n_subjects: int, rng: SplitMix64 = None, constant_wt: bool = False) -> FlatPopulation:
+    """oral bolus(0, 100..500) q24h x3 + 10 observations; `wt`: 2-4 linear knots per subject in [50,110] kg
+    (``constant_wt``: one knot, i.e. a subject-constant covariate, the usual allometric-scaling case)."""
     rng = rng or SplitMix64(SEED ^ 0x5C)
     S = n_subjects
     E = 13
@@ -187,6 +188,8 @@ def population_c5(n_subjects: int, rng: SplitMix64 = None) -> FlatPopulation:
     for j in range(3):
         v[j::E] = amt
     nk = 2 + (rng.next_u64(S) % np.uint64(3)).astype(np.int64)  # 2..4 knots
+    if constant_wt:
+        nk = np.ones(S, dtype=np.int64)
     koff = np.concatenate([[0], np.cumsum(nk)])
     tot = int(nk.sum())
     ksub = np.repeat(np.arange(S), nk)

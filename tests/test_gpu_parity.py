@@ -91,6 +91,51 @@ def test_c5_three_compartment_absorption_time_varying_wt(cov_time):
     assert_parity(m, flat, theta, TOL_ANALYTICAL, expect_kernel="pmx_analytical_grid<dyn>")
 
 
+def test_c5_subject_constant_covariate():
+    # one wt value per subject (the usual allometric-scaling case) and a mix of constant and interpolated subjects
+    m = synth.model_three_cpt_abs_wt()
+    flat = synth.population_c5(300, constant_wt=True)
+    assert_parity(m, flat, synth.theta_c5(512), TOL_ANALYTICAL, expect_kernel="pmx_analytical_grid<dyn>")
+
+
+@pytest.mark.parametrize("structure,params,states,central", [
+    ("one_compartment", ["ke0", "v0"], ["central"], "central"),
+    ("one_compartment_with_absorption", ["ka", "ke0", "v0"], ["gut", "central"], "central"),
+    ("two_compartments", ["ke0", "kcp", "kpc", "v0"], ["central", "periph"], "central"),
+    ("two_compartments_with_absorption", ["ke0", "ka", "kcp", "kpc", "v0"], ["gut", "central", "periph"], "central"),
+])
+@pytest.mark.parametrize("n_support", [3, 96])
+def test_covariate_derived_constants_of_the_smaller_structures(structure, params, states, central, n_support):
+    # ke = ke0 (wt/70)^0.75 and v = v0 (wt/70), on subjects with a constant wt, with knots, and with two occasions;
+    # GRID and PAIR lane mappings against the oracle
+    m = analytical(name="wt_" + structure, params=params,
+                   derived={"ke": Scaled("ke0", (Pow("wt", 70.0, 0.75),)), "v": Scaled("v0", (Pow("wt", 70.0, 1.0),))},
+                   covariates=["wt"], structure=structure, states=states, outputs=["cp"],
+                   routes=[bolus("dose", states[0])], out={"cp": Ratio(central, "v")})
+    rng = np.random.default_rng(5)
+    subs = []
+    for i in range(40):
+        b = Subject.builder(f"s{i}").bolus(0.0, 100.0 + i, "dose")
+        kind = i % 3
+        b = b.covariate("wt", 0.0, 50.0 + i)
+        if kind == 1:
+            b = b.covariate("wt", 10.0, 90.0 - i)
+        for t in np.sort(rng.uniform(0.2, 30.0, 6)):
+            b = b.missing_observation(float(t), "cp")
+        if kind == 2:
+            b = b.reset().covariate("wt", 0.0, 75.0).bolus(0.0, 50.0, "dose")
+            for t in (1.0, 3.0, 9.0):
+                b = b.missing_observation(t, "cp")
+        subs.append(b.build())
+    flat = m.flatten(Data(subs))
+    n = n_support
+    th = {"ke0": rng.uniform(0.05, 0.4, n), "v0": rng.uniform(10, 60, n), "ka": rng.uniform(1.5, 3.0, n),
+          "kcp": rng.uniform(0.1, 0.6, n), "kpc": rng.uniform(0.05, 0.3, n)}
+    theta = np.stack([th[p] for p in params], axis=1)
+    assert_parity(m, flat, theta, TOL_ANALYTICAL,
+                  expect_kernel="pmx_analytical_grid<dyn>" if n_support >= 48 else "pmx_analytical_pair<dyn>")
+
+
 # --------------------------------------------------------------------------- every kernel, both lane mappings
 @pytest.mark.parametrize("structure,central,theta,subject_fn,diffeq", models.KERNEL_CASES)
 @pytest.mark.parametrize("n_support", [1, 70])
