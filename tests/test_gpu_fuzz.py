@@ -1,6 +1,8 @@
 """Randomised combinations of everything the path supports (structure x CL form x pm_ indexing x init x lag x fa x
 multi-occasion x shared/ragged designs x covariate-derived parameters x lane mapping x prediction / log-likelihood),
 GPU against the CPU oracle.  Each case is seeded; a failure prints its recipe."""
+import os
+
 import numpy as np
 import pytest
 
@@ -121,7 +123,7 @@ def build_case(seed):
     return m, subs, theta, batch, recipe
 
 
-@pytest.mark.parametrize("seed", range(120))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PMX_FUZZ_ANALYTICAL", "120"))))  # (more seeds: set the variable)
 def test_random_analytical_configuration(seed):
     import torch
 
@@ -169,7 +171,7 @@ ODE_MODELS = {  # name -> (n states, n diffeq params, central)
 }
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PMX_FUZZ_ODE", "40"))))
 def test_random_ode_configuration(seed):
     import torch
 
