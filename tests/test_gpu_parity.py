@@ -85,6 +85,13 @@ def test_c4_ode_rk4_divergent_schedules_batch():
     assert rel_err(got, exact).max() <= TOL_ODE
 
 
+def test_c4_at_its_full_size_every_prediction():
+    # BASELINE configs[3] whole: 50k irregular subjects, one lane each (782 waves: the latency-bound shape the lane
+    # state machine, its LDS op ring and the steps-per-trip bound were tuned on) against the RK4 oracle
+    m, flat, theta = synth.config_c4(50_000)
+    assert_parity(m, flat, theta, 1e-9, batch=True, expect_kernel="pmx_ode_rk4_pair")
+
+
 @pytest.mark.parametrize("cov_time", ["segment_dt", "segment_end_abs"])
 def test_c5_three_compartment_absorption_time_varying_wt(cov_time):
     m, flat, theta = synth.config_c5(300, 512, cov_time)
