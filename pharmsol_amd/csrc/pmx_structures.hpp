@@ -58,6 +58,17 @@ __device__ __forceinline__ double pmx_exp(double x) {
   return ldexp(p, static_cast<int>(n));
 }
 
+// 1/x to within an ulp or two: the hardware estimate polished by two Newton steps (what the IEEE division expands to,
+// minus its scaling and fix-up instructions: ~8 issue slots instead of ~15).  For the per-segment coefficient rebuild
+// of covariate models, which spends a third of its time dividing; not correctly rounded, 0 -> NaN instead of inf
+// (either way the lane's predictions are non-finite and flagged).
+__device__ __forceinline__ double pmx_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+
 enum StructId : int { S_ONE = 0, S_ONE_ABS = 1, S_TWO = 2, S_TWO_ABS = 3, S_THREE = 4, S_THREE_ABS = 5 };
 
 // kernel id (include/pmx.h PMX_K_*) -> structure / CL flag, usable on host and device
@@ -303,35 +314,52 @@ struct ThreeCore {
     const double a = k10 + k12 + k13 + k21 + k31;
     const double b = k10 * k21 + k13 * k21 + k10 * k31 + k12 * k31 + k21 * k31;
     const double cc = k10 * k21 * k31;
-    const double m = (3.0 * b - a * a) / 3.0;
-    const double n = (2.0 * (a * a * a) - 9.0 * a * b + 27.0 * cc) / 27.0;
-    const double q = (n * n) / 4.0 + (m * m * m) / 27.0;
+    const double m = (3.0 * b - a * a) * (1.0 / 3.0);
+    const double n = (2.0 * (a * a * a) - 9.0 * a * b + 27.0 * cc) * (1.0 / 27.0);
+    const double q = (n * n) * 0.25 + (m * m * m) * (1.0 / 27.0);
     const bool ok = !(q > 0.0);  // reference panics on q > 0 (:32-34)
     const double alpha = sqrt(-q);
-    const double beta = -n / 2.0;
-    const double gamma = sqrt(beta * beta + alpha * alpha);
-    // The reference takes theta = atan2(alpha, beta), gamma^(1/3) and cos/sin(theta/3) (:36-45), i.e. the principal
-    // cube root z = cr (cs + i sn) of w = beta + i alpha.  Three f64 transcendentals per segment dominate a
-    // covariate model's cost, so z is seeded in single precision (1e-7) and polished with two Newton steps
-    // z <- (2 z + w / z^2) / 3 in f64 (quadratic: 1e-7 -> 1e-14 -> rounding).  Outside the float range the f64
-    // functions are used directly.
+    const double beta = -0.5 * n;
+    // The reference takes gamma = |beta + i alpha|, theta = atan2(alpha, beta), gamma^(1/3) and cos/sin(theta/3)
+    // (:36-45), i.e. the principal cube root z = cr (cs + i sn) of w = beta + i alpha.  Three f64 transcendentals
+    // per segment dominate a covariate model's cost, so z is seeded in single precision and polished with three
+    // Newton steps z <- (2 z + w / z^2) / 3 in f64 (quadratic: 2e-6 -> 4e-12 -> rounding).  The seed needs no
+    // library call: gamma^2 = -m^3/27, so gamma^(1/3) = sqrt(-m/3); atan2 on alpha >= 0 is a degree-8 polynomial in
+    // min/max (Abramowitz & Stegun 4.4.49, 2e-8) plus two reflections; theta/3 <= pi/3 goes straight to the hardware
+    // sine/cosine.  Outside the float range the f64 functions are used directly.
+    const double p3 = -m * (1.0 / 3.0);  // gamma^(2/3)
     double zr, zi;
-    if (gamma > 1.0e-30 && gamma < 1.0e30) {
-      const float thf = atan2f(static_cast<float>(alpha), static_cast<float>(beta));
-      const float crf = cbrtf(static_cast<float>(gamma));
-      float snf, csf;
-      sincosf(thf * (1.0f / 3.0f), &snf, &csf);
-      zr = static_cast<double>(crf * csf);
-      zi = static_cast<double>(crf * snf);
+    if (p3 > 1.0e-20 && p3 < 1.0e20) {
+      const float af = static_cast<float>(alpha), bf = static_cast<float>(beta);
+      const float ax = fabsf(bf);
+      const float mx = fmaxf(ax, af), mn = fminf(ax, af);
+      const float t = mn * __builtin_amdgcn_rcpf(mx);
+      const float s2 = t * t;
+      float pl = 0.0028662257f;
+      pl = fmaf(pl, s2, -0.0161657367f);
+      pl = fmaf(pl, s2, 0.0429096138f);
+      pl = fmaf(pl, s2, -0.0752896400f);
+      pl = fmaf(pl, s2, 0.1065626393f);
+      pl = fmaf(pl, s2, -0.1420889944f);
+      pl = fmaf(pl, s2, 0.1999355085f);
+      pl = fmaf(pl, s2, -0.3333314528f);
+      float thf = fmaf(pl * s2, t, t);
+      thf = (af > ax) ? (1.57079632679f - thf) : thf;
+      thf = (bf < 0.0f) ? (3.14159265359f - thf) : thf;
+      const float ph = thf * (1.0f / 3.0f);
+      const float crf = __builtin_amdgcn_sqrtf(static_cast<float>(p3));
+      zr = static_cast<double>(crf * __cosf(ph));
+      zi = static_cast<double>(crf * __sinf(ph));
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
+      for (int it = 0; it < 3; ++it) {
         const double z2r = zr * zr - zi * zi, z2i = 2.0 * zr * zi;
-        const double inv = 1.0 / (z2r * z2r + z2i * z2i);
+        const double inv = pmx_rcp(z2r * z2r + z2i * z2i);
         const double qr = (beta * z2r + alpha * z2i) * inv, qi = (alpha * z2r - beta * z2i) * inv;
         zr = (2.0 * zr + qr) * (1.0 / 3.0);
         zi = (2.0 * zi + qi) * (1.0 / 3.0);
       }
     } else {
+      const double gamma = sqrt(beta * beta + alpha * alpha);
       const double theta = atan2(alpha, beta);
       const double cr = cbrt(gamma);  // reference: gamma.powf(1.0/3.0)
       double sn, cs;
@@ -340,9 +368,10 @@ struct ThreeCore {
       zi = cr * sn;
     }
     const double rt3 = 1.7320508075688772;
-    l[0] = a / 3.0 + (zr + rt3 * zi);
-    l[1] = a / 3.0 + (zr - rt3 * zi);
-    l[2] = a / 3.0 - 2.0 * zr;
+    const double a3 = a * (1.0 / 3.0);
+    l[0] = a3 + (zr + rt3 * zi);
+    l[1] = a3 + (zr - rt3 * zi);
+    l[2] = a3 - 2.0 * zr;
     return ok;
   }
   // eigen-solve + coefficients: three_compartment_models.rs:24-77
@@ -409,7 +438,7 @@ __device__ __forceinline__ bool three_direct(double k10, double k12, double k13,
   for (int i = 0; i < 3; ++i) {
     const double li = l[i];
     const double lo1 = l[(i + 1) % 3], lo2 = l[(i + 2) % 3];
-    const double inv = 1.0 / ((lo1 - li) * (lo2 - li));
+    const double inv = pmx_rcp((lo1 - li) * (lo2 - li));
     const double u = k21 - li, v = k31 - li, w = K - li;
     const double e = pmx_exp(-(li * dt));
     const double c0 = u * v * inv, c3 = k12 * v * inv, c6 = k13 * u * inv;
@@ -422,12 +451,12 @@ __device__ __forceinline__ bool three_direct(double k10, double k12, double k13,
     p.m[6] = fma(c6, e, p.m[6]);
     p.m[7] = fma(k21 * k13 * inv, e, p.m[7]);
     p.m[8] = fma((w * u - k12 * k21) * inv, e, p.m[8]);
-    const double o = (1.0 - e) * (1.0 / li);
+    const double o = (1.0 - e) * pmx_rcp(li);
     p.j[0] = fma(c0, o, p.j[0]);
     p.j[1] = fma(c3, o, p.j[1]);
     p.j[2] = fma(c6, o, p.j[2]);
     if constexpr (ABS) {
-      const double q = (e - ea) * (1.0 / (ka - li));
+      const double q = (e - ea) * pmx_rcp(ka - li);
       g[0] = fma(c0, q, g[0]);
       g[1] = fma(c3, q, g[1]);
       g[2] = fma(c6, q, g[2]);
