@@ -207,7 +207,7 @@ __device__ __forceinline__ void lag_prop(const DevModel& m, const DevOps& ops, L
 // GRID kernel (analytical)
 // ------------------------------------------------------------------------------------
 template <int KID, bool DYN, bool LAG, bool LL>
-__global__ __launch_bounds__(kBlock, (!LAG && LaneModel<KID>::NS <= 2) ? 4 : ((!LAG && DYN) ? 3 : 1)) void pmx_analytical_grid(DevModel m, DevOps ops, const double* __restrict__ theta,
+__global__ __launch_bounds__(kBlock, (!LAG && LaneModel<KID>::NS <= 2) ? 4 : ((!LAG && DYN) ? 4 : 1)) void pmx_analytical_grid(DevModel m, DevOps ops, const double* __restrict__ theta,
                                                               int64_t P, int64_t S, int32_t s_chunk, int32_t n_ptiles,
                                                               double* __restrict__ pred, int64_t ld,
                                                               uint8_t* __restrict__ status,
