@@ -147,7 +147,7 @@ __device__ __forceinline__ double lane_out(const DevModel& m, const LaneModel<KI
   }
   double xs = select_state<LM::NS>(x, state - m.pm);
   if (m.pm && state == 0) xs = xpad;
-  if (vsrc == PMX_SRC_DERIVED) return xs / apply_factors(m, vidx, vbase, cov);
+  if (vsrc == PMX_SRC_DERIVED) return xs * pmx_rcp(apply_factors(m, vidx, vbase, cov));  // (pmx_structures.hpp: 8 issue slots for 15)
   return xs * inv;
 }
 

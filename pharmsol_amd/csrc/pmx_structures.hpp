@@ -69,6 +69,13 @@ __device__ __forceinline__ double pmx_rcp(double x) {
   return r;
 }
 
+// FAST = the per-segment rebuild of a covariate model (make_prop_dyn); the once-per-lane set-up keeps the IEEE division
+template <bool FAST>
+__device__ __forceinline__ double rcp_of(double x) {
+  if constexpr (FAST) return pmx_rcp(x);
+  return 1.0 / x;
+}
+
 enum StructId : int { S_ONE = 0, S_ONE_ABS = 1, S_TWO = 2, S_TWO_ABS = 3, S_THREE = 4, S_THREE_ABS = 5 };
 
 // kernel id (include/pmx.h PMX_K_*) -> structure / CL flag, usable on host and device
@@ -136,9 +143,10 @@ struct Structure<S_ONE> {
   struct Prop {
     double e, j;
   };
+  template <bool FAST = false>
   __device__ __forceinline__ static bool prepare(const double* kp, Coef& c) {
     c.ke = kp[0];
-    c.inv_ke = 1.0 / kp[0];
+    c.inv_ke = rcp_of<FAST>(kp[0]);
     return true;
   }
   static constexpr int NE = 1;
@@ -161,11 +169,12 @@ struct Structure<S_ONE_ABS> {
   struct Prop {
     double ea, ee, j, g;
   };
+  template <bool FAST = false>
   __device__ __forceinline__ static bool prepare(const double* kp, Coef& c) {
     c.ka = kp[0];
     c.ke = kp[1];
-    c.inv_ke = 1.0 / kp[1];
-    c.ka_over = kp[0] / (kp[0] - kp[1]);
+    c.inv_ke = rcp_of<FAST>(kp[1]);
+    c.ka_over = FAST ? kp[0] * pmx_rcp(kp[0] - kp[1]) : kp[0] / (kp[0] - kp[1]);
     return true;
   }
   static constexpr int NE = 2;
@@ -192,6 +201,7 @@ struct TwoCore {
   double a11, b11, kpc, kcp;  // M11 = a11 E1 + b11 E2 ; M12 = kpc (E2-E1) ; M21 = kcp (E2-E1)
   double a22, b22;            // M22 = a22 E1 + b22 E2
   double i0a, i0b, i1a, i1b;  // infusion vector: I0 = i0a(1-E1)+i0b(1-E2), I1 = i1a(1-E1)+i1b(1-E2)
+  template <bool FAST = false>
   __device__ __forceinline__ bool prepare(double ke, double kcp_, double kpc_) {
     const double s = ke + kcp_ + kpc_;
     double disc = s * s - 4.0 * ke * kpc_;
@@ -199,17 +209,25 @@ struct TwoCore {
     disc = sqrt(disc);
     l1 = (s + disc) / 2.0;
     l2 = (s - disc) / 2.0;
-    inv_d = 1.0 / (l1 - l2);
+    inv_d = rcp_of<FAST>(l1 - l2);
     a11 = l1 - kpc_;
     b11 = kpc_ - l2;
     kpc = kpc_;
     kcp = kcp_;
     a22 = l1 - ke - kcp_;
     b22 = ke + kcp_ - l2;
-    i0a = a11 / l1;
-    i0b = b11 / l2;
-    i1a = -kcp_ / l1;
-    i1b = kcp_ / l2;
+    if constexpr (FAST) {
+      const double r1 = pmx_rcp(l1), r2 = pmx_rcp(l2);
+      i0a = a11 * r1;
+      i0b = b11 * r2;
+      i1a = -kcp_ * r1;
+      i1b = kcp_ * r2;
+    } else {
+      i0a = a11 / l1;
+      i0b = b11 / l2;
+      i1a = -kcp_ / l1;
+      i1b = kcp_ / l2;
+    }
     return ok;
   }
 };
@@ -236,7 +254,10 @@ struct Structure<S_TWO> {
   struct Prop {
     TwoProp p;
   };
-  __device__ __forceinline__ static bool prepare(const double* kp, Coef& c) { return c.t.prepare(kp[0], kp[1], kp[2]); }
+  template <bool FAST = false>
+  __device__ __forceinline__ static bool prepare(const double* kp, Coef& c) {
+    return c.t.template prepare<FAST>(kp[0], kp[1], kp[2]);
+  }
   static constexpr int NE = 2;
   __device__ __forceinline__ static void exps(const Coef& c, double dt, double (&e)[NE]) {
     e[0] = pmx_exp(-c.t.l1 * dt);
@@ -265,11 +286,12 @@ struct Structure<S_TWO_ABS> {
     TwoProp p;
     double ea, g0, g1;
   };
+  template <bool FAST = false>
   __device__ __forceinline__ static bool prepare(const double* kp, Coef& c) {
     // native order [ke, ka, kcp, kpc] (two_compartment_models.rs:62-65)
-    const bool ok = c.t.prepare(kp[0], kp[2], kp[3]);
+    const bool ok = c.t.template prepare<FAST>(kp[0], kp[2], kp[3]);
     c.ka = kp[1];
-    const double r1 = 1.0 / (c.ka - c.t.l1), r2 = 1.0 / (c.ka - c.t.l2);
+    const double r1 = rcp_of<FAST>(c.ka - c.t.l1), r2 = rcp_of<FAST>(c.ka - c.t.l2);
     c.a0a = c.t.a11 * r1;
     c.a0b = c.t.b11 * r2;
     c.a1a = -c.t.kcp * r1;
@@ -586,7 +608,7 @@ __device__ __forceinline__ bool make_prop_dyn(const double* kp, double dt, typen
     return Structure<ST>::make_prop_dyn(kp, dt, p);
   } else {
     typename Structure<ST>::Coef c;
-    const bool ok = Structure<ST>::prepare(kp, c);
+    const bool ok = Structure<ST>::template prepare<true>(kp, c);
     make_prop<ST>(c, dt, p);
     return ok;
   }
