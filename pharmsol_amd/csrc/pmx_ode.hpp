@@ -456,9 +456,10 @@ __device__ __forceinline__ void ode_grid_body(const DevModel& m, const DevOps& o
   }
 }
 
-// PAIR: each lane is a small state machine {cursor o, remaining RK4 steps}; one trip of the
-// wave loop performs either one RK4 step or one op per lane, so lanes in different segments
-// of different subjects still step in lock-step (divergent timelines, C4).
+// PAIR: each lane is a small state machine {cursor o, remaining RK4 steps, ring of fetched ops}.  One trip of the
+// wave loop = a top-up of the rings when a lane ran dry, an op phase (idle lanes take up to two ops) and a stepping
+// phase (lanes inside a piece take up to ops.steps_per_trip steps), so lanes in different segments of different
+// subjects advance together (divergent timelines, C4) and none waits longer than a bounded number of steps.
 template <class M, bool LAG, bool LL, bool ADAPT>
 __device__ __forceinline__ void ode_pair_body(const DevModel& m, const DevOps& ops, const double* __restrict__ theta,
                                               int64_t P, int64_t S, int32_t batch, double* __restrict__ pred,
@@ -523,9 +524,9 @@ __device__ __forceinline__ void ode_pair_body(const DevModel& m, const DevOps& o
   // LAG: an open PROP (or occasion opening) [t_cur, t_stop) that lagged boluses may still split
   bool in_prop = false;
   double t_cur = 0.0, t_stop = 0.0;
-  // ONE action per lane per trip (an RK4 step, a lag sub-piece decision, or an op), written as a single if / else
-  // chain: with `continue`s the compiler rotates the stepping branch into an inner per-lane loop and lanes that
-  // need an op wait for the longest piece in the wave (measured: C4 2.4 -> 3.9 ms).
+  // Every phase is bounded and the op phase is a single if / else chain per action: with `continue`s the compiler
+  // rotated the stepping branch into an unbounded inner per-lane loop and lanes that needed an op waited for the
+  // longest piece in the wave (measured on the first version of this loop: C4 2.4 -> 3.9 ms).
   while ((ADAPT ? stepping : rem > 0) || o < o1) {
     {
       const bool busy = (ADAPT ? stepping : rem > 0) || (LAG && in_prop);
