@@ -405,6 +405,13 @@ typedef struct pmx_op_stream_view {
 int32_t pmx_debug_compile(const pmx_population_desc* pop, const pmx_model_desc* model, pmx_op_stream_view* out);
 void pmx_debug_free(pmx_op_stream_view* view);
 
+/* Host-side introspection of the class planner (no GPU): how the analytical GRID kernels would split this
+ * population for this model.  counts[0] = chunks of exact classes (members share the whole program, step lengths
+ * included), counts[1] = chunks of loose classes (same op kinds / inputs / outputs in the same order, own step
+ * lengths), counts[2] = subjects in either kind of class, counts[3] = subjects left to the generic walker,
+ * counts[4] = members per chunk (0: the model is not classed at all - covariates, lag, bioavailability, ODE). */
+int32_t pmx_debug_class_plan(const pmx_population_desc* pop, const pmx_model_desc* model, int64_t* counts);
+
 #ifdef __cplusplus
 }
 #endif

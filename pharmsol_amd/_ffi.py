@@ -55,6 +55,7 @@ SYMBOLS = [
     ("pmx_last_error", C.c_char_p, []),
     ("pmx_debug_compile", C.c_int32, [_PD, _MD, C.POINTER(_abi.pmx_op_stream_view)]),
     ("pmx_debug_free", None, [C.POINTER(_abi.pmx_op_stream_view)]),
+    ("pmx_debug_class_plan", C.c_int32, [_PD, _MD, C.POINTER(C.c_int64)]),
 ]
 
 

@@ -499,7 +499,9 @@ int32_t get_stream(pmx_population* pop, const pmx::CompileKey& key, DeviceStream
     if (const char* e = std::getenv("PMX_TUNE_MIN_CLASS")) min_class = std::atoi(e) > 0 ? std::atoi(e) : min_class;  // tuning experiments
     bool spread = true;  // (0.94-0.97 vs 1.05-1.11 ms on C3 in most allocations, never slower: tools/alloc_tune.py)
     if (const char* e = std::getenv("PMX_TUNE_SPREAD")) spread = e[0] && e[0] != '0';  // tuning experiments
-    pmx::build_class_plan(pop->hp, os, key.class_g, min_class, &cp, key.ladder, spread);
+    bool loose = true;  // subjects without a shared design still share a program shape: batched with per-member step lengths
+    if (const char* e = std::getenv("PMX_TUNE_LOOSE")) loose = e[0] && e[0] != '0';  // tuning experiments
+    pmx::build_class_plan(pop->hp, os, key.class_g, min_class, &cp, key.ladder, spread, loose);
     if (cp.n_chunks > 0) {
       if ((rc = upload(cp.prog_meta, &ds->cls.prog_meta, &ds->allocs)) != PMX_OK) return rc;
       if ((rc = upload(cp.prog_dt, &ds->cls.prog_dt, &ds->allocs)) != PMX_OK) return rc;
@@ -510,6 +512,7 @@ int32_t get_stream(pmx_population* pop, const pmx::CompileKey& key, DeviceStream
       if ((rc = upload(cp.chunk_subj, &ds->cls.chunk_subj, &ds->allocs)) != PMX_OK) return rc;
       if ((rc = upload(cp.chunk_row, &ds->cls.chunk_row, &ds->allocs)) != PMX_OK) return rc;
       if ((rc = upload(cp.val, &ds->cls.val, &ds->allocs)) != PMX_OK) return rc;
+      if ((rc = upload(cp.dtv, &ds->cls.dtv, &ds->allocs)) != PMX_OK) return rc;
       if ((rc = upload(cp.generic_subjects, &ds->cls.generic_subjects, &ds->allocs)) != PMX_OK) return rc;
       ds->h_chunk_row = cp.chunk_row;
       ds->h_chunk_n = cp.chunk_n;
@@ -532,6 +535,7 @@ int32_t get_stream(pmx_population* pop, const pmx::CompileKey& key, DeviceStream
         if ((rc = upload(off, &ds->d_chunk_obs_off, &ds->allocs)) != PMX_OK) return rc;
       }
       ds->cls.n_chunks = cp.n_chunks;
+      ds->cls.n_chunks_exact = cp.n_chunks_exact;
       ds->cls.n_generic = static_cast<int64_t>(cp.generic_subjects.size());
       ds->cls.G = cp.G;
       ds->n_classed_subjects = cp.n_classed_subjects;
@@ -973,6 +977,35 @@ int32_t pmx_debug_compile(const pmx_population_desc* pop, const pmx_model_desc* 
   out->op_cov = os.op_cov.empty() ? nullptr : os.op_cov.data();
   out->subj_order = os.subj_order.data();
   out->owner = own.release();
+  return PMX_OK;
+}
+
+int32_t pmx_debug_class_plan(const pmx_population_desc* pop, const pmx_model_desc* model, int64_t* counts) {
+  g_err.clear();
+  if (!pop || !model || !counts) return fail(PMX_ERR_INVALID_ARGUMENT, "null argument");
+  pmx_model* m = nullptr;
+  int32_t rc = pmx_model_create(model, &m);
+  if (rc != PMX_OK) return rc;
+  std::unique_ptr<pmx_model> mg(m);
+  pmx::HostPopulation hp;
+  pmx::OpStream os;
+  std::string err;
+  rc = pmx::build_host_population(pop, &hp, &err);
+  if (rc != PMX_OK) return fail(rc, err);
+  const pmx::CompileKey key = key_for(m);
+  rc = pmx::compile_ops(hp, key, &os, &err);
+  if (rc != PMX_OK) return fail(rc, err);
+  for (int i = 0; i < 5; ++i) counts[i] = 0;
+  counts[3] = hp.n_subjects;
+  if (key.class_g > 0) {
+    pmx::ClassPlan cp;
+    pmx::build_class_plan(hp, os, key.class_g, key.class_g / 2, &cp, key.ladder, true, true);
+    counts[0] = cp.n_chunks_exact;
+    counts[1] = cp.n_chunks - cp.n_chunks_exact;
+    counts[2] = cp.n_classed_subjects;
+    counts[3] = static_cast<int64_t>(cp.generic_subjects.size());
+    counts[4] = cp.G;
+  }
   return PMX_OK;
 }
 

@@ -483,7 +483,7 @@ uint32_t ladder_code(double dt, double* prev, double* span) {
 }
 
 void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, int32_t min_class_size, ClassPlan* cp,
-                      bool ladder, bool spread) {
+                      bool ladder, bool spread, bool loose_classes) {
   *cp = ClassPlan{};
   cp->G = G;
   const int64_t S = hp.n_subjects;
@@ -532,13 +532,9 @@ void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, i
   }
   cp->cls_prog_off.push_back(0);
   int32_t out_cls = 0;
-  for (size_t c = 0; c < members.size(); ++c) {
-    const auto& mem = members[c];
-    if (static_cast<int32_t>(mem.size()) < min_class_size) {
-      cp->generic_subjects.insert(cp->generic_subjects.end(), mem.begin(), mem.end());
-      continue;
-    }
-    const int64_t r0 = os.subj_op_off[cls_rep[c]], r1 = os.subj_op_off[cls_rep[c] + 1];
+  // one class -> its program and its chunks; `loose`: the members' PROP lengths differ (dtv), no ladder
+  auto emit_class = [&](const std::vector<int32_t>& mem, int32_t rep, bool loose) {
+    const int64_t r0 = os.subj_op_off[rep], r1 = os.subj_op_off[rep + 1];
     // Program steps: every OBS op is FUSED into the step before it (bit 24 = "emit a row after this step",
     // bits 25-26 = its outeq), so a PROP+OBS pair costs one trip of the device loop.  A second observation
     // at the same instant gets a step of its own (kind OP_OBS = no state change).
@@ -562,7 +558,7 @@ void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, i
       }
     }
     const int64_t L = static_cast<int64_t>(step_meta.size());
-    if (ladder) {
+    if (ladder && !loose) {
       // Exponential ladder (pmx_structures.hpp ladder_pow): bits 27-29 of a PROP step = n when its length is
       // n x the previous PROP's (n = 1: same propagator again).  `span` = how many times the first rung's
       // rounding error has been multiplied; past 1024 the next step starts a fresh ladder.
@@ -574,7 +570,7 @@ void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, i
     }
     for (int64_t i = 0; i < L; ++i) {
       cp->prog_meta.push_back(step_meta[static_cast<size_t>(i)]);
-      cp->prog_dt.push_back(step_dt[static_cast<size_t>(i)]);
+      cp->prog_dt.push_back(loose ? 0.0 : step_dt[static_cast<size_t>(i)]);
     }
     cp->cls_prog_off.push_back(static_cast<int64_t>(cp->prog_meta.size()));
     // Which members share a chunk is free (any G subjects of the class may share a propagator).  `spread`: member j of
@@ -598,6 +594,7 @@ void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, i
       }
       const size_t base = cp->val.size();
       cp->val.resize(base + static_cast<size_t>(L) * G, 0.0);
+      cp->dtv.resize(base + static_cast<size_t>(L) * G, 0.0);
       for (int32_t j = 0; j < n; ++j) {
         const int64_t s0 = os.subj_op_off[pick[static_cast<size_t>(j)]];
         for (int64_t i = 0; i < r1 - r0; ++i) {
@@ -608,11 +605,63 @@ void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, i
           if (kind == OP_BOLUS) v = os.op_a[s0 + i];
           if (kind == OP_PROP) v = os.op_b[s0 + i];
           cp->val[base + static_cast<size_t>(st) * G + j] = v;
+          if (loose && kind == OP_PROP) cp->dtv[base + static_cast<size_t>(st) * G + j] = os.op_a[s0 + i];
         }
       }
       cp->n_classed_subjects += n;
     }
     ++out_cls;
+  };
+  std::vector<int32_t> leftover;  // members of classes too small to batch: second chance as loose classes
+  for (size_t c = 0; c < members.size(); ++c) {
+    if (static_cast<int32_t>(members[c].size()) < min_class_size) {
+      leftover.insert(leftover.end(), members[c].begin(), members[c].end());
+      continue;
+    }
+    emit_class(members[c], cls_rep[c], false);
+  }
+  cp->n_chunks_exact = static_cast<int64_t>(cp->chunk_cls.size());
+  if (loose_classes && !leftover.empty()) {
+    std::sort(leftover.begin(), leftover.end());
+    constexpr uint32_t kShape = 0x00ffffffu;  // kind | io: what a loose class shares (ladder bits and lengths are free)
+    auto same_shape = [&](int64_t x, int64_t y) {
+      const int64_t x0 = os.subj_op_off[x], x1 = os.subj_op_off[x + 1];
+      const int64_t y0 = os.subj_op_off[y], y1 = os.subj_op_off[y + 1];
+      if (x1 - x0 != y1 - y0) return false;
+      for (int64_t i = 0; i < x1 - x0; ++i)
+        if ((os.op_meta[x0 + i] & kShape) != (os.op_meta[y0 + i] & kShape)) return false;
+      return true;
+    };
+    std::unordered_map<uint64_t, std::vector<int32_t>> lbuckets;
+    std::vector<int32_t> lrep;
+    std::vector<std::vector<int32_t>> lmembers;
+    for (int32_t s : leftover) {
+      const int64_t o0 = os.subj_op_off[s], o1 = os.subj_op_off[s + 1];
+      uint64_t h = static_cast<uint64_t>(o1 - o0);
+      for (int64_t o = o0; o < o1; ++o) h = mix64(h, static_cast<uint64_t>(os.op_meta[o] & kShape));
+      auto& ids = lbuckets[h];
+      int32_t cls = -1;
+      for (int32_t c : ids)
+        if (same_shape(lrep[c], s)) {
+          cls = c;
+          break;
+        }
+      if (cls < 0) {
+        cls = static_cast<int32_t>(lrep.size());
+        lrep.push_back(s);
+        lmembers.emplace_back();
+        ids.push_back(cls);
+      }
+      lmembers[cls].push_back(s);
+    }
+    for (size_t c = 0; c < lmembers.size(); ++c) {
+      if (static_cast<int32_t>(lmembers[c].size()) < min_class_size)
+        cp->generic_subjects.insert(cp->generic_subjects.end(), lmembers[c].begin(), lmembers[c].end());
+      else
+        emit_class(lmembers[c], lrep[c], true);
+    }
+  } else {
+    cp->generic_subjects.insert(cp->generic_subjects.end(), leftover.begin(), leftover.end());
   }
   cp->n_chunks = static_cast<int64_t>(cp->chunk_cls.size());
   std::sort(cp->generic_subjects.begin(), cp->generic_subjects.end());

@@ -129,6 +129,13 @@ struct ClassPlan {
   std::vector<int32_t> chunk_subj;     // [n_chunks*G] subject ids, -1 = padding
   std::vector<int64_t> chunk_row;      // [n_chunks*G] first prediction row of each member
   std::vector<double> val;             // per chunk: [program length][G]  BOLUS amount / PROP rate
+  // Chunks [0, n_chunks_exact) belong to classes whose members share the whole program, step lengths included: one
+  // propagator per step serves all G members.  Chunks [n_chunks_exact, n_chunks) belong to LOOSE classes: same op
+  // kinds, inputs and outputs in the same order, but every member has its own step lengths (recorded sampling
+  // times instead of protocol times) - `dtv` holds them, laid out like `val`, and the kernel builds a propagator
+  // per member; what the members still share is the program walk and the paired stores.
+  int64_t n_chunks_exact = 0;
+  std::vector<double> dtv;             // per chunk: [program length][G]  PROP length of each member (loose chunks)
   std::vector<int32_t> generic_subjects;  // subjects left to the generic kernel (ascending)
 };
 
@@ -140,7 +147,7 @@ struct ClassPlan {
 uint32_t ladder_code(double dt, double* prev, double* span);
 
 void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, int32_t min_class_size, ClassPlan* out,
-                      bool ladder = true, bool spread = false);
+                      bool ladder = true, bool spread = false, bool loose_classes = false);
 
 // Validate + copy + sort (Occasion::sort, structs.rs:669-671) + build covariate segments.
 // Returns PMX_OK or an error with `err` filled.

@@ -409,7 +409,7 @@ __device__ __forceinline__ void classed_emit_state(int out_state, const double (
 
 // __launch_bounds__ 2nd argument = waves per SIMD the register allocator must leave room for
 // (4 -> at most 128 VGPRs): the kernel is a latency/bandwidth mix and wants the occupancy.
-template <int KID, bool LL>
+template <int KID, bool LL, bool PERDT>
 __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx_analytical_classed(
     DevModel m, DevOps ops, DevClassPlan cp, const double* __restrict__ theta, int64_t P, int32_t chunks_per_block,
     int32_t n_ptiles, double* __restrict__ pred, int64_t ld, uint8_t* __restrict__ status) {
@@ -430,7 +430,10 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
   // chunk-blocks take chunks cblock, cblock + n_cblocks, ... (grid stride): the blocks resident at one moment then
   // work on neighbouring chunks, which keeps each of the G write fronts compact (see build_class_plan `spread`)
   const int64_t n_cblocks = static_cast<int64_t>(gridDim.x) / n_ptiles;
-  if (cblock >= cp.n_chunks) return;
+  // this launch's share of the plan: the chunks with shared step lengths, or (PERDT) the loose ones behind them
+  const int64_t c_begin = PERDT ? cp.n_chunks_exact : 0;
+  const int64_t c_end = PERDT ? cp.n_chunks : cp.n_chunks_exact;
+  if (c_begin + cblock >= c_end) return;
   const uint32_t lane = threadIdx.x & 63u;
   const bool upper = lane >= 32u;
   const int64_t p_even = static_cast<int64_t>(ptile) * kBlock + (threadIdx.x & ~63u) + 2u * (lane & 31u);
@@ -462,10 +465,12 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
   const auto chunk_subj = as_const(cp.chunk_subj);
   const auto chunk_row = as_const(cp.chunk_row);
   const auto val = as_const(cp.val);
+  const auto dtv = as_const(cp.dtv);
+  (void)dtv;
   const double* __restrict__ th = theta + pc * m.nparams;
 
   (void)chunks_per_block;
-  for (int64_t c = cblock; c < cp.n_chunks; c += n_cblocks) {
+  for (int64_t c = c_begin + cblock; c < c_end; c += n_cblocks) {
     const int32_t cls = chunk_cls[c];
     const int32_t n_live = chunk_n[c];
     int64_t voff = chunk_val_off[c];
@@ -516,20 +521,33 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
       const uint32_t kind = meta & 0xffu;
       const int io = static_cast<int>((meta >> 8) & 0xffffu);
       if (kind == OP_PROP) {
-        const uint32_t rung = (meta >> 27) & 7u;
-        if (rung == 0u) {
-          LM::S::exps(coef, prog_dt[o], ex);
-        } else if (rung != 1u) {
-          ladder_pow<LM::S::NE>(ex, rung);
-        }
-        typename LM::S::Prop pr;
-        LM::S::from_exps(coef, ex, pr);
+        if constexpr (PERDT) {
+          // loose chunk: every member has its own step length, hence its own propagator; the members still share
+          // the walk through the program (one scalar decode per step instead of G) and the paired stores
 #pragma unroll
-        for (int j = 0; j < G; ++j) {
-          LM::S::apply(pr, x[j], val[voff + j]);
-          // keep the scheduler from interleaving all G updates (it would hold old and new state of
-          // every member at once: +2*NS*G registers, one wave per SIMD less)
-          if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+          for (int j = 0; j < G; ++j) {
+            typename LM::S::Prop pr;
+            LM::S::exps(coef, dtv[voff + j], ex);
+            LM::S::from_exps(coef, ex, pr);
+            LM::S::apply(pr, x[j], val[voff + j]);
+            if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
+          const uint32_t rung = (meta >> 27) & 7u;
+          if (rung == 0u) {
+            LM::S::exps(coef, prog_dt[o], ex);
+          } else if (rung != 1u) {
+            ladder_pow<LM::S::NE>(ex, rung);
+          }
+          typename LM::S::Prop pr;
+          LM::S::from_exps(coef, ex, pr);
+#pragma unroll
+          for (int j = 0; j < G; ++j) {
+            LM::S::apply(pr, x[j], val[voff + j]);
+            // keep the scheduler from interleaving all G updates (it would hold old and new state of
+            // every member at once: +2*NS*G registers, one wave per SIMD less)
+            if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+          }
         }
       } else if (kind == OP_BOLUS) {
 #pragma unroll
@@ -837,20 +855,42 @@ hipError_t launch_analytical(const LaunchArgs& a, const char** name) {
         // enough blocks to fill the chip several times over, few enough that lane_setup stays amortised
         // (chunks are taken in grid-stride order; one chunk per block up to 32k blocks measured best: tools/cpb_on_one_allocation.py)
         // (the log-likelihood variant writes almost nothing: it prefers fewer, longer blocks that amortise the lane setup)
-        int64_t cpb = (a.cls.n_chunks * a.n_ptiles) / (a.ops.ll_obs != nullptr ? 8192 : 32768);
-        if (cpb < 1) cpb = 1;
-        if (cpb > 8) cpb = 8;
-        if (const char* e = std::getenv("PMX_TUNE_CPB")) cpb = std::atoi(e) > 0 ? std::atoi(e) : cpb;  // tuning experiments
-        const int64_t cblocks = ((a.cls.n_chunks + cpb - 1) / cpb + 7) / 8 * 8;  // whole XCD groups
-        if (a.ops.ll_obs != nullptr) {
-          *name = "pmx_analytical_classed<ll>";
-          hipLaunchKernelGGL((pmx_analytical_classed<KID, true>), dim3(static_cast<uint32_t>(cblocks * a.n_ptiles)),
-                             dim3(grid_threads(a.P)), 0, st, a.m, a.ops, a.cls, a.theta, a.P, static_cast<int32_t>(cpb), a.n_ptiles,
-                             a.pred, a.ld, a.status);
-        } else {
-          hipLaunchKernelGGL((pmx_analytical_classed<KID, false>), dim3(static_cast<uint32_t>(cblocks * a.n_ptiles)),
-                             dim3(grid_threads(a.P)), 0, st, a.m, a.ops, a.cls, a.theta, a.P, static_cast<int32_t>(cpb), a.n_ptiles,
-                             a.pred, a.ld, a.status);
+        const bool ll = a.ops.ll_obs != nullptr;
+        const int64_t n_exact = a.cls.n_chunks_exact, n_loose = a.cls.n_chunks - a.cls.n_chunks_exact;
+        auto blocks_for = [&](int64_t n, int64_t* cpb_out) {
+          int64_t cpb = (n * a.n_ptiles) / (ll ? 8192 : 32768);
+          if (cpb < 1) cpb = 1;
+          if (cpb > 8) cpb = 8;
+          if (const char* e = std::getenv("PMX_TUNE_CPB")) cpb = std::atoi(e) > 0 ? std::atoi(e) : cpb;  // tuning experiments
+          *cpb_out = cpb;
+          return ((n + cpb - 1) / cpb + 7) / 8 * 8;  // whole XCD groups
+        };
+        if (n_exact > 0) {
+          int64_t cpb = 1;
+          const int64_t cblocks = blocks_for(n_exact, &cpb);
+          if (ll) {
+            *name = "pmx_analytical_classed<ll>";
+            hipLaunchKernelGGL((pmx_analytical_classed<KID, true, false>), dim3(static_cast<uint32_t>(cblocks * a.n_ptiles)),
+                               dim3(grid_threads(a.P)), 0, st, a.m, a.ops, a.cls, a.theta, a.P, static_cast<int32_t>(cpb), a.n_ptiles,
+                               a.pred, a.ld, a.status);
+          } else {
+            hipLaunchKernelGGL((pmx_analytical_classed<KID, false, false>), dim3(static_cast<uint32_t>(cblocks * a.n_ptiles)),
+                               dim3(grid_threads(a.P)), 0, st, a.m, a.ops, a.cls, a.theta, a.P, static_cast<int32_t>(cpb), a.n_ptiles,
+                               a.pred, a.ld, a.status);
+          }
+        }
+        if (n_loose > 0) {  // subjects that share a program shape but not its step lengths
+          int64_t cpb = 1;
+          const int64_t cblocks = blocks_for(n_loose, &cpb);
+          if (n_exact == 0) *name = ll ? "pmx_analytical_classed<ll,loose>" : "pmx_analytical_classed<loose>";
+          if (ll)
+            hipLaunchKernelGGL((pmx_analytical_classed<KID, true, true>), dim3(static_cast<uint32_t>(cblocks * a.n_ptiles)),
+                               dim3(grid_threads(a.P)), 0, st, a.m, a.ops, a.cls, a.theta, a.P, static_cast<int32_t>(cpb), a.n_ptiles,
+                               a.pred, a.ld, a.status);
+          else
+            hipLaunchKernelGGL((pmx_analytical_classed<KID, false, true>), dim3(static_cast<uint32_t>(cblocks * a.n_ptiles)),
+                               dim3(grid_threads(a.P)), 0, st, a.m, a.ops, a.cls, a.theta, a.P, static_cast<int32_t>(cpb), a.n_ptiles,
+                               a.pred, a.ld, a.status);
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;

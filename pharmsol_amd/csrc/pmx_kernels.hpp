@@ -21,10 +21,12 @@ struct DevClassPlan {
   const int32_t* chunk_subj;
   const int64_t* chunk_row;  // [n_chunks*G] first prediction row of each member (0 for padding)
   const double* val;
+  const double* dtv;                // loose chunks: each member's own PROP lengths, laid out like val
   const double* cobs;               // log-likelihood mode: per chunk [observation k][3][G] = value, const term, weight
   const int64_t* chunk_obs_off;     // [n_chunks] offset of the chunk's block in cobs
   const int32_t* generic_subjects;  // subjects the generic GRID kernel still has to walk
   int64_t n_chunks;
+  int64_t n_chunks_exact;           // chunks [0, n_chunks_exact): shared step lengths; the rest: loose (pmx_compile.hpp)
   int64_t n_generic;
   int32_t G;
   int32_t zero_status;  // how the analytical GRID kernels own their status bytes (no memset precedes a launch):

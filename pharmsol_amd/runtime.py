@@ -305,6 +305,17 @@ def last_kernel_name() -> str:
     return _ffi.lib().pmx_last_kernel_name().decode()
 
 
+def class_plan(model, flat: FlatPopulation) -> dict:
+    """Host-side introspection (``pmx_debug_class_plan``): how the analytical GRID kernels would batch this
+    population.  Needs no GPU."""
+    md = model.desc() if not isinstance(model, _abi.pmx_model_desc) else model
+    pd = flat.desc()
+    counts = (C.c_int64 * 5)()
+    _ffi.check(_ffi.lib().pmx_debug_class_plan(C.byref(pd), C.byref(md), counts))
+    return dict(chunks_exact=int(counts[0]), chunks_loose=int(counts[1]), classed_subjects=int(counts[2]),
+                generic_subjects=int(counts[3]), members_per_chunk=int(counts[4]))
+
+
 def compile_ops(model, flat: FlatPopulation) -> dict:
     """Host-side introspection (``pmx_debug_compile``): the op stream the device would walk, as numpy
     arrays.  Needs no GPU."""

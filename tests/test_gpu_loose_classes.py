@@ -1,0 +1,114 @@
+"""Loose classes (pmx_compile.hpp ClassPlan): subjects that share a program SHAPE (op kinds, inputs, outputs in the
+same order) but not its step lengths - recorded sampling times instead of protocol times - are batched G at a time
+like the members of an exact class, each with its own propagator per step.  GPU against the CPU oracle, predictions
+and fused log-likelihood, alone and mixed with exact classes and with subjects no class takes."""
+import numpy as np
+import pytest
+
+import oracle
+from pharmsol_amd import Analytical, AssayErrorModel, AssayErrorModels, Data, ErrorPoly, Ratio, Subject, _abi, runtime, synth
+from tests import models
+from tests.test_gpu_fuzz import STRUCTS, kernel_theta
+
+pytestmark = pytest.mark.gpu
+
+
+def check(model, flat, theta, expect_kernel, loglik=False, tol=1e-6):
+    import torch
+
+    pop = runtime.DevicePopulation(flat, 0)
+    dirty = torch.full((flat.n_subjects, theta.shape[0]), 177, dtype=torch.uint8, device="cuda")
+    if loglik:
+        em = AssayErrorModels.empty().add(0, AssayErrorModel.additive(ErrorPoly(0.05, 0.1, 0.0, 0.0), 0.1))
+        got, st = runtime.loglik(model, pop, em, np.ascontiguousarray(theta), status=dirty)
+        want, wst = oracle.loglik(model, flat, em, theta)
+    else:
+        got, st = runtime.predict(model, pop, np.ascontiguousarray(theta), status=dirty)
+        want, wst = oracle.predict(model, flat, theta)
+    torch.cuda.synchronize()
+    assert runtime.last_kernel_name().startswith(expect_kernel), runtime.last_kernel_name()
+    got, st = got.cpu().numpy(), st.cpu().numpy()
+    np.testing.assert_array_equal(st, wst)
+    ok = np.isfinite(want)
+    np.testing.assert_array_equal(np.isfinite(got), ok)
+    scale = np.maximum(np.abs(want[ok]), (1.0 if loglik else 1e-9 * np.abs(want[ok]).max()) + 1e-300)
+    assert (np.abs(got[ok] - want[ok]) / scale).max() < tol
+
+
+def with_observed_values(flat, model, theta, seed):
+    """Measured values for the log-likelihood: the oracle's predictions at the first support point, with noise; a fifth missing."""
+    want, _ = oracle.predict(model, flat, theta[:1])
+    rng = np.random.default_rng(seed)
+    vals = np.abs(np.where(np.isfinite(want[:, 0]), want[:, 0], 1.0)) * np.exp(rng.normal(0, 0.2, want.shape[0])) + 0.05
+    vals[rng.random(vals.shape) < 0.2] = np.nan
+    flat.ev_value = flat.ev_value.copy()
+    flat.ev_value[flat.ev_kind == _abi.PMX_EV_OBSERVATION] = vals
+    return flat
+
+
+@pytest.mark.parametrize("n_support", [64, 96, 301])
+@pytest.mark.parametrize("loglik", [False, True])
+def test_jittered_c3_population_runs_as_loose_classes(n_support, loglik):
+    model = synth.model_two_cpt_iv()
+    flat = synth.population_c23(1003, ragged=True)  # 1003: the last chunk is partial
+    theta = synth.theta_c3(n_support)
+    if loglik:
+        flat = with_observed_values(flat, model, theta, 3)
+    check(model, flat, theta, "pmx_analytical_classed<ll,loose>" if loglik else "pmx_analytical_classed<loose>", loglik)
+
+
+def shaped_subject(rng, shape, i):
+    """One of three program shapes with this subject's own times: 0 = infusion + 6 samples, 1 = bolus + infusion + 4
+    samples over two occasions, 2 = two boluses with a sample at the second dose time."""
+    b = Subject.builder(f"s{i}")
+    if shape == 0:
+        b = b.infusion(0.0, 300.0 + i, 0, 0.5 + 0.5 * rng.random())
+        for t in np.sort(rng.uniform(0.6, 30.0, 6)):
+            b = b.missing_observation(float(t), 0)
+    elif shape == 1:
+        b = b.bolus(0.0, 100.0 + i, 0).infusion(float(rng.uniform(1.0, 2.0)), 200.0, 0, 1.0)
+        for t in np.sort(rng.uniform(3.5, 20.0, 2)):
+            b = b.missing_observation(float(t), 0)
+        b = b.reset().bolus(0.0, 50.0, 0)
+        for t in np.sort(rng.uniform(0.5, 12.0, 2)):
+            b = b.missing_observation(float(t), 0)
+    else:
+        t2 = float(rng.uniform(6.0, 12.0))
+        b = b.bolus(0.0, 80.0, 0).missing_observation(float(rng.uniform(0.5, 5.0)), 0).bolus(t2, 80.0, 0)
+        b = b.missing_observation(t2, 0).missing_observation(t2 + float(rng.uniform(1.0, 9.0)), 0)
+    return b.build()
+
+
+@pytest.mark.parametrize("structure", ["one_compartment", "one_compartment_with_absorption", "two_compartments_cl",
+                                       "two_compartments_with_absorption", "three_compartments",
+                                       "three_compartments_cl_with_absorption"])
+@pytest.mark.parametrize("loglik", [False, True])
+def test_exact_loose_and_unclassed_subjects_in_one_population(structure, loglik):
+    ns, nk, central = STRUCTS[structure]
+    rng = np.random.default_rng(21)
+    model = Analytical.new(structure, {0: Ratio(central, nk)}, nparams=nk + 1).with_nstates(ns).with_ndrugs(1).with_nout(1)
+    subs = []
+    proto = shaped_subject(rng, 0, 0)
+    for i in range(37):  # a shared design: exact classes
+        b = Subject.builder(f"e{i}")
+        for ev in proto.occasions[0].events:
+            b = b.infusion(ev.time, ev.amount + i, 0, ev.duration) if hasattr(ev, "duration") else b.missing_observation(ev.time, 0)
+        subs.append(b.build())
+    for i in range(61):  # three shapes with individual times: loose classes
+        subs.append(shaped_subject(rng, i % 3, i))
+    for i in range(5):  # shapes nobody shares, and an empty subject: the generic walker
+        subs.append(models.random_subject(rng, multi_occasion=bool(i % 2)))
+    subs.insert(40, Subject.builder("empty").build())
+    order = rng.permutation(len(subs))
+    flat = model.flatten(Data([subs[k] for k in order]))
+    n = 72
+    theta = np.concatenate([kernel_theta(structure, n, rng), rng.uniform(10, 80, (n, 1))], axis=1)
+    if loglik:
+        flat = with_observed_values(flat, model, theta, 5)
+    check(model, flat, theta, "pmx_analytical_classed", loglik)
+
+
+def test_loose_classes_can_be_switched_off(monkeypatch):
+    monkeypatch.setenv("PMX_TUNE_LOOSE", "0")
+    model = synth.model_two_cpt_iv()
+    check(model, synth.population_c23(200, ragged=True), synth.theta_c3(64), "pmx_analytical_grid")

@@ -250,3 +250,31 @@ def test_graft_entry_build_is_consistent_with_the_library():
     import __graft_entry__ as g
 
     g.build()
+
+
+def test_class_planner_exact_loose_and_generic_subjects():
+    """pmx_debug_class_plan: a shared design -> exact classes; the same shape with individual times -> loose classes;
+    shapes nobody shares and empty subjects -> the generic walker; covariate models are not classed."""
+    from pharmsol_amd import Analytical, Data, Ratio, Subject, runtime, synth
+
+    m = synth.model_two_cpt_iv()
+    exact = runtime.class_plan(m, synth.population_c23(1003))
+    assert exact == dict(chunks_exact=126, chunks_loose=0, classed_subjects=1003, generic_subjects=0, members_per_chunk=8)
+    loose = runtime.class_plan(m, synth.population_c23(1003, ragged=True))
+    assert loose == dict(chunks_exact=0, chunks_loose=126, classed_subjects=1003, generic_subjects=0, members_per_chunk=8)
+    assert runtime.class_plan(synth.model_three_cpt_abs_wt(), synth.population_c5(50))["members_per_chunk"] == 0
+
+    model = Analytical.new("one_compartment", {0: Ratio(0, 1)}, nparams=2).with_nstates(1).with_ndrugs(1).with_nout(1)
+    rng = np.random.default_rng(0)
+    subs = []
+    for i in range(20):  # shared design
+        subs.append(Subject.builder(f"e{i}").bolus(0.0, 100.0 + i, 0).missing_observation(1.0, 0).missing_observation(4.0, 0).build())
+    for i in range(13):  # same shape, own times
+        t = np.sort(rng.uniform(0.5, 9.0, 2))
+        subs.append(Subject.builder(f"l{i}").bolus(0.0, 100.0, 0).missing_observation(float(t[0]), 0).missing_observation(float(t[1]), 0).build())
+    for i in range(3):  # one more shape, too few members for a class of its own (min = G / 2 = 4)
+        subs.append(Subject.builder(f"g{i}").bolus(0.0, 10.0, 0).missing_observation(float(rng.uniform(1, 2)), 0).build())
+    subs.append(Subject.builder("empty").build())
+    plan = runtime.class_plan(model, model.flatten(Data(subs)))
+    # 20 exact -> 3 chunks of 8; 13 loose -> 2 chunks; 3 + the empty subject stay generic
+    assert plan == dict(chunks_exact=3, chunks_loose=2, classed_subjects=33, generic_subjects=4, members_per_chunk=8)
