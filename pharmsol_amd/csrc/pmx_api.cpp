@@ -396,18 +396,16 @@ pmx::CompileKey key_for(const pmx_model* m) {
     k.n_rate = 1;
     k.rate_input = m->d.pmetrics_indexing ? 1 : 0;
     // classed fast path: theta-only coefficients, no covariates, plain indexing
-    bool has_fa = false;
-    for (int i = 0; i < PMX_MAX_INPUTS; ++i) {
+    for (int i = 0; i < PMX_MAX_INPUTS; ++i)
       if (m->d.lag_param[i] >= 0) k.lag_mask |= (1u << i);
-      if (m->d.fa_param[i] >= 0) has_fa = true;  // per-lane bolus amounts: the classed kernel's values are wave-uniform
-    }
+    // (bioavailability does not stop classing: the amounts in the plan are the recorded ones, each lane scales them)
     const char* nl = std::getenv("PMX_DISABLE_LADDER");  // fresh exp() on every step (A/B and parity checks)
     k.ladder = !m->dyn && k.lag_mask == 0 && !(nl && nl[0] && nl[0] != '0');
     k.n_derived = m->d.n_derived;
     std::memcpy(k.derived, m->d.derived, sizeof(k.derived));
     const char* off = std::getenv("PMX_DISABLE_CLASSING");
     const bool disabled = off && off[0] && off[0] != '0';
-    if (!disabled && !m->dyn && !m->d.pmetrics_indexing && m->d.n_covariates == 0 && k.lag_mask == 0 && !has_fa) {
+    if (!disabled && !m->dyn && !m->d.pmetrics_indexing && m->d.n_covariates == 0 && k.lag_mask == 0) {
       const int st = pmx::kernel_structure(m->d.kernel);
       k.class_g = (st == pmx::S_ONE || st == pmx::S_ONE_ABS || st == pmx::S_TWO) ? 8 : 4;  // == ClassBatch<KID>::G
     }

@@ -550,9 +550,10 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
           }
         }
       } else if (kind == OP_BOLUS) {
+        const double f = fa_of(m, th, io);  // the lane's bioavailability of this input (1.0 when the model has none)
 #pragma unroll
         for (int j = 0; j < G; ++j) {
-          const double a = val[voff + j];  // (models with bioavailability are never classed: pmx_api.cpp key_for)
+          const double a = val[voff + j] * f;
 #pragma unroll
           for (int i = 0; i < NS; ++i) x[j][i] += (i == io) ? a : 0.0;
         }

@@ -112,3 +112,23 @@ def test_loose_classes_can_be_switched_off(monkeypatch):
     monkeypatch.setenv("PMX_TUNE_LOOSE", "0")
     model = synth.model_two_cpt_iv()
     check(model, synth.population_c23(200, ragged=True), synth.theta_c3(64), "pmx_analytical_grid")
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_bioavailability_models_are_classed(ragged):
+    # fa scales the recorded bolus amount per lane (structs.rs:645-666): the plan keeps the recorded amounts
+    model = Analytical.new("one_compartment_with_absorption", {0: Ratio(1, 2)}, nparams=4, fa={0: 3})
+    model = model.with_nstates(2).with_ndrugs(1).with_nout(1)
+    rng = np.random.default_rng(8)
+    subs = []
+    for i in range(90):
+        b = Subject.builder(f"s{i}").bolus(0.0, 100.0 + i, 0).bolus(12.0, 50.0, 0)
+        times = [1.0, 2.0, 6.0, 12.0, 13.0, 20.0]
+        if ragged:
+            times = [t * (1.0 + 0.1 * (rng.random() - 0.5)) if t != 12.0 else t for t in times]
+        for t in times:
+            b = b.missing_observation(float(t), 0)
+        subs.append(b.build())
+    n = 80
+    theta = np.stack([rng.uniform(1.0, 3.0, n), rng.uniform(0.05, 0.4, n), rng.uniform(10, 60, n), rng.uniform(0.3, 1.0, n)], 1)
+    check(model, model.flatten(Data(subs)), theta, "pmx_analytical_classed<loose>" if ragged else "pmx_analytical_classed")
