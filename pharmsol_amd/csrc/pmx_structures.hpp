@@ -448,6 +448,7 @@ __device__ __forceinline__ bool three_direct(double k10, double k12, double k13,
   double l[3];
   const bool ok = ThreeCore::eigen(k10, k12, k13, k21, k31, l);
   const double K = k10 + k12 + k13;
+  const double k1331 = k13 * k31, k1221 = k12 * k21, k1231 = k12 * k31, k2113 = k21 * k13;
   if constexpr (ABS) ea = pmx_exp(-ka * dt);
 #pragma unroll
   for (int k = 0; k < 9; ++k) p.m[k] = 0.0;
@@ -460,25 +461,41 @@ __device__ __forceinline__ bool three_direct(double k10, double k12, double k13,
   for (int i = 0; i < 3; ++i) {
     const double li = l[i];
     const double lo1 = l[(i + 1) % 3], lo2 = l[(i + 2) % 3];
-    const double inv = pmx_rcp((lo1 - li) * (lo2 - li));
+    // the three reciprocals of this eigenvalue - 1/d_i, 1/l_i and (ABS) 1/(ka - l_i) - from ONE Newton reciprocal of
+    // their product (a third of this loop's instructions were reciprocals)
+    const double di = (lo1 - li) * (lo2 - li);
+    double inv, il, ia = 0.0;
+    if constexpr (ABS) {
+      const double kl = ka - li;
+      const double dl = di * li;
+      const double r = pmx_rcp(dl * kl);
+      inv = r * (li * kl);
+      il = r * (di * kl);
+      ia = r * dl;
+    } else {
+      const double r = pmx_rcp(di * li);
+      inv = r * li;
+      il = r * di;
+    }
     const double u = k21 - li, v = k31 - li, w = K - li;
+    const double ui = u * inv, vi = v * inv;
     const double e = pmx_exp(-(li * dt));
-    const double c0 = u * v * inv, c3 = k12 * v * inv, c6 = k13 * u * inv;
+    const double c0 = u * vi, c3 = k12 * vi, c6 = k13 * ui;
     p.m[0] = fma(c0, e, p.m[0]);
-    p.m[1] = fma(k21 * v * inv, e, p.m[1]);
-    p.m[2] = fma(k31 * u * inv, e, p.m[2]);
+    p.m[1] = fma(k21 * vi, e, p.m[1]);
+    p.m[2] = fma(k31 * ui, e, p.m[2]);
     p.m[3] = fma(c3, e, p.m[3]);
-    p.m[4] = fma((w * v - k13 * k31) * inv, e, p.m[4]);
-    p.m[5] = fma(k12 * k31 * inv, e, p.m[5]);
+    p.m[4] = fma(fma(w, v, -k1331) * inv, e, p.m[4]);
+    p.m[5] = fma(k1231 * inv, e, p.m[5]);
     p.m[6] = fma(c6, e, p.m[6]);
-    p.m[7] = fma(k21 * k13 * inv, e, p.m[7]);
-    p.m[8] = fma((w * u - k12 * k21) * inv, e, p.m[8]);
-    const double o = (1.0 - e) * pmx_rcp(li);
+    p.m[7] = fma(k2113 * inv, e, p.m[7]);
+    p.m[8] = fma(fma(w, u, -k1221) * inv, e, p.m[8]);
+    const double o = (1.0 - e) * il;
     p.j[0] = fma(c0, o, p.j[0]);
     p.j[1] = fma(c3, o, p.j[1]);
     p.j[2] = fma(c6, o, p.j[2]);
     if constexpr (ABS) {
-      const double q = (e - ea) * pmx_rcp(ka - li);
+      const double q = (e - ea) * ia;
       g[0] = fma(c0, q, g[0]);
       g[1] = fma(c3, q, g[1]);
       g[2] = fma(c6, q, g[2]);
