@@ -405,7 +405,11 @@ pmx::CompileKey key_for(const pmx_model* m) {
     std::memcpy(k.derived, m->d.derived, sizeof(k.derived));
     const char* off = std::getenv("PMX_DISABLE_CLASSING");
     const bool disabled = off && off[0] && off[0] != '0';
-    if (!disabled && !m->dyn && !m->d.pmetrics_indexing && m->d.n_covariates == 0 && k.lag_mask == 0) {
+    bool reads_pad = false;  // pm_ indexing: an output on model state 0 reads the wrapper's pad slot (generic walker only)
+    if (m->d.pmetrics_indexing)
+      for (int o = 0; o < m->d.nout && o < PMX_MAX_OUT; ++o)
+        if (m->d.out[o].state == 0) reads_pad = true;
+    if (!disabled && !m->dyn && !reads_pad && m->d.n_covariates == 0 && k.lag_mask == 0) {
       const int st = pmx::kernel_structure(m->d.kernel);
       k.class_g = (st == pmx::S_ONE || st == pmx::S_ONE_ABS || st == pmx::S_TWO) ? 8 : 4;  // == ClassBatch<KID>::G
     }

@@ -513,6 +513,15 @@ void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, i
       cp->generic_subjects.push_back(static_cast<int32_t>(s));
       continue;
     }
+    if (os.key.rate_input == 1) {  // pm_ indexing: a bolus into input 0 lands in the wrapper's pad slot (generic walker only)
+      bool pad_dose = false;
+      for (int64_t o = o0; o < o1; ++o)
+        if ((os.op_meta[o] & 0xffu) == OP_BOLUS && ((os.op_meta[o] >> 8) & 0xffffu) == 0u) pad_dose = true;
+      if (pad_dose) {
+        cp->generic_subjects.push_back(static_cast<int32_t>(s));
+        continue;
+      }
+    }
     uint64_t h = static_cast<uint64_t>(o1 - o0);
     for (int64_t o = o0; o < o1; ++o) h = mix64(h, sig_key(o));
     auto& ids = buckets[h];

@@ -555,23 +555,25 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
         for (int j = 0; j < G; ++j) {
           const double a = val[voff + j] * f;
 #pragma unroll
-          for (int i = 0; i < NS; ++i) x[j][i] += (i == io) ? a : 0.0;
+          for (int i = 0; i < NS; ++i) x[j][i] += (i == io - m.pm) ? a : 0.0;  // (pm_: model input 1 = kernel state 0)
         }
       } else if (kind == OP_RESET) {
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
           double xi = 0.0;
-          if (io && m.has_init && m.init_param[i] >= 0) xi = th[m.init_param[i]];
+          if (io && m.has_init && m.init_param[i + m.pm] >= 0) xi = th[m.init_param[i + m.pm]];
 #pragma unroll
           for (int j = 0; j < G; ++j) x[j][i] = xi;
         }
       }  // (kind == OP_OBS: a second observation at the same instant, no state change)
       if ((meta >> 24) & 1u) {  // the observation fused into this step (pmx_compile.cpp build_class_plan)
         const int oq = static_cast<int>((meta >> 25) & 3u);
-        int out_state = m.out[0].state;
+        // (pm_ models: the plan only holds subjects that never dose the pad slot and models that never read it, so
+        // kernel state = model state - 1 is all the wrapper amounts to; pmx_compile.cpp build_class_plan)
+        int out_state = m.out[0].state - m.pm;
         double inv_vol = inv_vol0;
         if (oq != 0) {  // outputs beyond the first: rare, re-derive the volume instead of keeping 4 live
-          out_state = m.out[oq].state;
+          out_state = m.out[oq].state - m.pm;
           const double v = (m.out[oq].vol_src == PMX_SRC_PRIMARY) ? th[m.out[oq].vol_index] : 1.0;
           inv_vol = lane_good ? 1.0 / v : inv_vol0;
         }

@@ -132,3 +132,30 @@ def test_bioavailability_models_are_classed(ragged):
     n = 80
     theta = np.stack([rng.uniform(1.0, 3.0, n), rng.uniform(0.05, 0.4, n), rng.uniform(10, 60, n), rng.uniform(0.3, 1.0, n)], 1)
     check(model, model.flatten(Data(subs)), theta, "pmx_analytical_classed<loose>" if ragged else "pmx_analytical_classed")
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_pmetrics_indexed_models_are_classed(ragged):
+    # pm_ wrappers (analytical/mod.rs:62-90): model state / input 1 is the kernel's 0; subjects that dose the pad slot
+    # (input 0) stay with the generic walker, the others are classed
+    model = Analytical.new("pm_one_compartment_with_absorption", {0: Ratio(2, 2)}, nparams=3)
+    model = model.with_nstates(3).with_ndrugs(2).with_nout(1)
+    rng = np.random.default_rng(9)
+    subs = []
+    for i in range(70):
+        b = Subject.builder(f"s{i}").bolus(0.0, 100.0 + i, 1).infusion(6.0, 60.0, 1, 2.0)
+        if i % 10 == 0:
+            b = b.bolus(3.0, 25.0, 0)  # into the pad slot: dropped by the wrapper, not classed here
+        times = [1.0, 2.0, 6.0, 9.0, 13.0, 20.0]
+        if ragged:
+            times = [t * (1.0 + 0.1 * (rng.random() - 0.5)) for t in times]
+        for t in times:
+            b = b.missing_observation(float(t), 0)
+        subs.append(b.build())
+    flat = model.flatten(Data(subs))
+    plan = runtime.class_plan(model, flat)
+    assert plan["generic_subjects"] == 7 and plan["classed_subjects"] == 63
+    assert (plan["chunks_loose"] > 0) == ragged
+    n = 80
+    theta = np.stack([rng.uniform(1.0, 3.0, n), rng.uniform(0.05, 0.4, n), rng.uniform(10, 60, n)], 1)
+    check(model, flat, theta, "pmx_analytical_classed<loose>" if ragged else "pmx_analytical_classed")
