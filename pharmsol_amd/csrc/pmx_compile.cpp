@@ -663,8 +663,11 @@ void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, i
       }
       lmembers[cls].push_back(s);
     }
+    // a loose chunk does G members' arithmetic whatever it holds (no propagator to share): below ~3/4 full the
+    // generic walker is the cheaper way to serve its subjects
+    const int32_t min_loose = std::max(min_class_size, (3 * G + 3) / 4);
     for (size_t c = 0; c < lmembers.size(); ++c) {
-      if (static_cast<int32_t>(lmembers[c].size()) < min_class_size)
+      if (static_cast<int32_t>(lmembers[c].size()) < min_loose)
         cp->generic_subjects.insert(cp->generic_subjects.end(), lmembers[c].begin(), lmembers[c].end());
       else
         emit_class(lmembers[c], lrep[c], true);
