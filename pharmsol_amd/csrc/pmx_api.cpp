@@ -409,7 +409,10 @@ pmx::CompileKey key_for(const pmx_model* m) {
     if (m->d.pmetrics_indexing)
       for (int o = 0; o < m->d.nout && o < PMX_MAX_OUT; ++o)
         if (m->d.out[o].state == 0) reads_pad = true;
-    if (!disabled && !m->dyn && !reads_pad && m->d.n_covariates == 0 && k.lag_mask == 0) {
+    // (one lagged input is classed too: in an exact class the bolus times are shared, so a lane's split points and the
+    // propagator of every sub-interval serve all G members)
+    const bool lag_ok = (k.lag_mask & (k.lag_mask - 1u)) == 0u;
+    if (!disabled && !m->dyn && !reads_pad && m->d.n_covariates == 0 && lag_ok) {
       const int st = pmx::kernel_structure(m->d.kernel);
       k.class_g = (st == pmx::S_ONE || st == pmx::S_ONE_ABS || st == pmx::S_TWO) ? 8 : 4;  // == ClassBatch<KID>::G
     }
@@ -507,6 +510,8 @@ int32_t get_stream(pmx_population* pop, const pmx::CompileKey& key, DeviceStream
     if (cp.n_chunks > 0) {
       if ((rc = upload(cp.prog_meta, &ds->cls.prog_meta, &ds->allocs)) != PMX_OK) return rc;
       if ((rc = upload(cp.prog_dt, &ds->cls.prog_dt, &ds->allocs)) != PMX_OK) return rc;
+      if ((rc = upload(cp.prog_t0, &ds->cls.prog_t0, &ds->allocs)) != PMX_OK) return rc;
+      if ((rc = upload(cp.prog_t1, &ds->cls.prog_t1, &ds->allocs)) != PMX_OK) return rc;
       if ((rc = upload(cp.cls_prog_off, &ds->cls.cls_prog_off, &ds->allocs)) != PMX_OK) return rc;
       if ((rc = upload(cp.chunk_cls, &ds->cls.chunk_cls, &ds->allocs)) != PMX_OK) return rc;
       if ((rc = upload(cp.chunk_n, &ds->cls.chunk_n, &ds->allocs)) != PMX_OK) return rc;

@@ -487,6 +487,9 @@ void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, i
   *cp = ClassPlan{};
   cp->G = G;
   const int64_t S = hp.n_subjects;
+  const bool lagged = os.n_lag_slots == 1;  // (the caller only asks for a plan of a lag model when one input is lagged)
+  if (os.n_lag_slots > 1) return;
+  if (lagged) loose_classes = false;  // loose members do not share the times
   auto sig_key = [&](int64_t o) -> uint64_t {  // what must match between class members, per op
     const uint32_t kind = os.op_meta[o] & 0xffu;
     uint64_t bits = 0;
@@ -499,7 +502,21 @@ void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, i
     if (a1 - a0 != b1 - b0) return false;
     for (int64_t i = 0; i < a1 - a0; ++i) {
       if (os.op_meta[a0 + i] != os.op_meta[b0 + i]) return false;
-      if ((os.op_meta[a0 + i] & 0xffu) == OP_PROP && std::memcmp(&os.op_a[a0 + i], &os.op_a[b0 + i], 8) != 0) return false;
+      const uint32_t kind = os.op_meta[a0 + i] & 0xffu;
+      if (kind == OP_PROP && std::memcmp(&os.op_a[a0 + i], &os.op_a[b0 + i], 8) != 0) return false;
+      if (lagged) {  // members of a lag class also share every absolute time a lane's lagged boluses are compared with
+        if (kind == OP_PROP && (std::memcmp(&os.op_t0[a0 + i], &os.op_t0[b0 + i], 8) != 0 ||
+                                std::memcmp(&os.op_t1[a0 + i], &os.op_t1[b0 + i], 8) != 0))
+          return false;
+        if (kind == OP_RESET) {
+          if (std::memcmp(&os.op_t0[a0 + i], &os.op_t0[b0 + i], 8) != 0) return false;
+          const int64_t oa = static_cast<int64_t>(os.op_a[a0 + i]), ob = static_cast<int64_t>(os.op_a[b0 + i]);
+          const int64_t la = os.lagb_off[oa], lb = os.lagb_off[ob];
+          const int64_t na = os.lagb_off[oa + 1] - la;
+          if (na != os.lagb_off[ob + 1] - lb) return false;
+          if (na > 0 && std::memcmp(&os.lagb_time[la], &os.lagb_time[lb], static_cast<size_t>(na) * 8) != 0) return false;
+        }
+      }
     }
     return true;
   };
@@ -523,7 +540,21 @@ void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, i
       }
     }
     uint64_t h = static_cast<uint64_t>(o1 - o0);
-    for (int64_t o = o0; o < o1; ++o) h = mix64(h, sig_key(o));
+    for (int64_t o = o0; o < o1; ++o) {
+      h = mix64(h, sig_key(o));
+      if (lagged) {
+        uint64_t bits = 0;
+        std::memcpy(&bits, &os.op_t0[o], 8);
+        h = mix64(h, bits);
+        if ((os.op_meta[o] & 0xffu) == OP_RESET) {
+          const int64_t oc = static_cast<int64_t>(os.op_a[o]);
+          for (int64_t q = os.lagb_off[oc]; q < os.lagb_off[oc + 1]; ++q) {
+            std::memcpy(&bits, &os.lagb_time[q], 8);
+            h = mix64(h, bits);
+          }
+        }
+      }
+    }
     auto& ids = buckets[h];
     int32_t cls = -1;
     for (int32_t c : ids)
@@ -549,7 +580,7 @@ void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, i
     // at the same instant gets a step of its own (kind OP_OBS = no state change).
     std::vector<int32_t> step_of_op(static_cast<size_t>(r1 - r0), -1);
     std::vector<uint32_t> step_meta;
-    std::vector<double> step_dt;
+    std::vector<double> step_dt, step_t0, step_t1;
     for (int64_t o = r0; o < r1; ++o) {
       const uint32_t kind = os.op_meta[o] & 0xffu;
       const uint32_t io = (os.op_meta[o] >> 8) & 0xffffu;
@@ -559,10 +590,14 @@ void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, i
         } else {
           step_meta.push_back(make_meta(OP_OBS, 0) | (1u << 24) | ((io & 3u) << 25));
           step_dt.push_back(0.0);
+          step_t0.push_back(0.0);
+          step_t1.push_back(0.0);
         }
       } else {
         step_meta.push_back(make_meta(kind, io));
         step_dt.push_back(kind == OP_PROP ? os.op_a[o] : 0.0);
+        step_t0.push_back(lagged ? os.op_t0[o] : 0.0);
+        step_t1.push_back(lagged ? os.op_t1[o] : 0.0);
         step_of_op[static_cast<size_t>(o - r0)] = static_cast<int32_t>(step_meta.size()) - 1;
       }
     }
@@ -580,6 +615,8 @@ void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, i
     for (int64_t i = 0; i < L; ++i) {
       cp->prog_meta.push_back(step_meta[static_cast<size_t>(i)]);
       cp->prog_dt.push_back(loose ? 0.0 : step_dt[static_cast<size_t>(i)]);
+      cp->prog_t0.push_back(step_t0[static_cast<size_t>(i)]);
+      cp->prog_t1.push_back(step_t1[static_cast<size_t>(i)]);
     }
     cp->cls_prog_off.push_back(static_cast<int64_t>(cp->prog_meta.size()));
     // Which members share a chunk is free (any G subjects of the class may share a propagator).  `spread`: member j of
@@ -613,6 +650,7 @@ void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, i
           double v = 0.0;
           if (kind == OP_BOLUS) v = os.op_a[s0 + i];
           if (kind == OP_PROP) v = os.op_b[s0 + i];
+          if (kind == OP_RESET && lagged) v = os.op_a[s0 + i];  // this member's occasion: where its lagged boluses are listed
           cp->val[base + static_cast<size_t>(st) * G + j] = v;
           if (loose && kind == OP_PROP) cp->dtv[base + static_cast<size_t>(st) * G + j] = os.op_a[s0 + i];
         }

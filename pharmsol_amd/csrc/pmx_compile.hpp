@@ -122,6 +122,9 @@ struct ClassPlan {
   int64_t n_classed_subjects = 0;
   std::vector<uint32_t> prog_meta;     // concatenated class programs: kind | io<<8 | obs_after<<24 | outeq<<25
   std::vector<double> prog_dt;         // PROP: dt
+  // lag models (one lagged input; exact classes only): the absolute [t0, t1) of every PROP step and, on a RESET step,
+  // the time of the occasion's first event that stays in the list - what a lane compares its lagged bolus times with
+  std::vector<double> prog_t0, prog_t1;
   std::vector<int64_t> cls_prog_off;   // [n_classes+1]
   std::vector<int32_t> chunk_cls;      // [n_chunks]
   std::vector<int32_t> chunk_n;        // [n_chunks] live members (<= G)

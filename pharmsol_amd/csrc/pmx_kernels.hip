@@ -409,7 +409,11 @@ __device__ __forceinline__ void classed_emit_state(int out_state, const double (
 
 // __launch_bounds__ 2nd argument = waves per SIMD the register allocator must leave room for
 // (4 -> at most 128 VGPRs): the kernel is a latency/bandwidth mix and wants the occupancy.
-template <int KID, bool LL, bool PERDT>
+// LAGC: one lagged input (exact classes only).  The members of a class share every bolus TIME, so a lane's lagged
+// landing times t + lag(theta) - its split points inside a PROP step - are the same for all G members: one propagator
+// per sub-interval still serves the whole batch; only the amounts are the members' own (lag_prop / lag_open_occasion
+// of the generic walker, over G states at once).
+template <int KID, bool LL, bool PERDT, bool LAGC = false>
 __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx_analytical_classed(
     DevModel m, DevOps ops, DevClassPlan cp, const double* __restrict__ theta, int64_t P, int32_t chunks_per_block,
     int32_t n_ptiles, double* __restrict__ pred, int64_t ld, uint8_t* __restrict__ status) {
@@ -454,6 +458,17 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
     lane_good = L.ok;
     inv_vol0 = L.ok ? L.inv_vol[0] : __longlong_as_double(0x7ff8000000000000LL);
   }
+  double lagv = 0.0;      // LAGC: this lane's lag time of the lagged input
+  bool lane_badlag = false;
+  if constexpr (LAGC) {
+    lagv = theta[pc * m.nparams + m.lag_param[0]];
+    if (!(lagv >= 0.0)) {  // negative or NaN lag: PMX_PAIR_BAD_LAG, rows NaN (the generic walker's rule)
+      lane_badlag = true;
+      inv_vol0 = __longlong_as_double(0x7ff8000000000000LL);
+    }
+  }
+  const double kInf = __longlong_as_double(0x7ff0000000000000LL);
+  (void)kInf;
   // the plan arrays are read-only for the whole launch and every index below is wave-uniform:
   // constant-address-space pointers make these scalar (s_load) fetches
   const auto prog_meta = as_const(cp.prog_meta);
@@ -516,12 +531,53 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
     // the lane's exponentials outlive a step: bits 27-29 of a PROP step say how this step's length relates
     // to the previous PROP's (0 = unrelated: exp(); 1 = equal; n = 2..4: n times as long: ladder_pow)
     double ex[LM::S::NE];
+    // LAGC: cursor into the current occasion's list of lagged boluses (relative: the members' lists run in parallel),
+    // the list's length and member 0's list (the shared times); reset_voff = the val row with the members' occasions
+    int32_t lcur = 0, lcnt = 0;
+    int64_t lbase0 = 0, reset_voff = 0;
+    // every member advances by dt (per lane) under its own rate / takes its own amount of the lagged bolus at lcur
+    auto advance_all = [&](double dt, int64_t rate_off, bool with_rate) {
+      typename LM::S::Prop pr;
+      make_prop<LM::ST>(coef, dt, pr);
+#pragma unroll
+      for (int j = 0; j < G; ++j) LM::S::apply(pr, x[j], with_rate ? val[rate_off + j] : 0.0);
+    };
+    auto bolus_all = [&]() {
+      const double f = fa_of(m, th, m.lag_input[0]);
+      const int dest = m.lag_dest[0];
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const int64_t occ = static_cast<int64_t>(val[reset_voff + j]);  // (padding members: occasion 0, amounts unused)
+        const double amt = ops.lagb_amount[as_const(ops.lagb_off)[occ] + lcur] * f;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) x[j][i] += (i == dest) ? amt : 0.0;
+      }
+      ++lcur;
+    };
+    auto lag_tau = [&]() { return (lcur < lcnt) ? (ops.lagb_time[lbase0 + lcur] + lagv) : kInf; };
+    (void)advance_all;
+    (void)bolus_all;
+    (void)lag_tau;
     for (int64_t o = pb; o < pe; ++o, voff += G) {
       const uint32_t meta = prog_meta[o];
       const uint32_t kind = meta & 0xffu;
       const int io = static_cast<int>((meta >> 8) & 0xffffu);
       if (kind == OP_PROP) {
-        if constexpr (PERDT) {
+        if constexpr (LAGC) {
+          // lag_prop: split [t0, t1) at this lane's lagged landing times
+          const double t1 = as_const(cp.prog_t1)[o];
+          double t = as_const(cp.prog_t0)[o];
+          for (;;) {
+            const double tau = lag_tau();
+            if (!(tau < t1)) break;
+            if (tau > t) {
+              advance_all(tau - t, voff, true);
+              t = tau;
+            }
+            bolus_all();
+          }
+          if (t1 > t) advance_all(t1 - t, voff, true);
+        } else if constexpr (PERDT) {
           // loose chunk: every member has its own step length, hence its own propagator; the members still share
           // the walk through the program (one scalar decode per step instead of G) and the paired stores
 #pragma unroll
@@ -564,6 +620,27 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
           if (io && m.has_init && m.init_param[i + m.pm] >= 0) xi = th[m.init_param[i + m.pm]];
 #pragma unroll
           for (int j = 0; j < G; ++j) x[j][i] = xi;
+        }
+        if constexpr (LAGC) {
+          // lag_open_occasion: point the cursor at this occasion's list, run the boluses that land before the
+          // occasion's first remaining event (no infusion can be active there)
+          reset_voff = voff;
+          const int64_t occ0 = static_cast<int64_t>(val[voff]);
+          lbase0 = as_const(ops.lagb_off)[occ0];
+          lcnt = static_cast<int32_t>(as_const(ops.lagb_off)[occ0 + 1] - lbase0);
+          lcur = 0;
+          const double t_first = as_const(cp.prog_t0)[o];
+          bool started = false;
+          double t = 0.0;
+          for (;;) {
+            const double tau = lag_tau();
+            if (!(tau < t_first)) break;
+            if (started && tau > t) advance_all(tau - t, voff, false);
+            t = tau;
+            started = true;
+            bolus_all();
+          }
+          if (started && t_first > t && t_first < kInf) advance_all(t_first - t, voff, false);
         }
       }  // (kind == OP_OBS: a second observation at the same instant, no state change)
       if ((meta >> 24) & 1u) {  // the observation fused into this step (pmx_compile.cpp build_class_plan)
@@ -619,13 +696,14 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
     }
     // status bytes: the library zeroes the array before the launch (PMX_PAIR_OK == 0); only failures are
     // written here, so the healthy case issues no byte stores at all
-    if (status != nullptr && (cp.zero_status == 2 || __any(((bad != 0u || !lane_good) && lane_ok) ? 1 : 0))) {
+    if (status != nullptr && (cp.zero_status == 2 || __any(((bad != 0u || !lane_good || lane_badlag) && lane_ok) ? 1 : 0))) {
       if (cp.zero_status == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clearing store above lands first
 #pragma unroll
       for (int j = 0; j < G; ++j) {
         if (j < n_live) {
           const int64_t sid = chunk_subj[c * G + j];
-          const uint8_t st = !lane_good ? PMX_PAIR_COMPLEX_ROOTS : (((bad >> j) & 1u) ? PMX_PAIR_NONFINITE : PMX_PAIR_OK);
+          const uint8_t st = !lane_good ? PMX_PAIR_COMPLEX_ROOTS
+                             : (lane_badlag ? PMX_PAIR_BAD_LAG : (((bad >> j) & 1u) ? PMX_PAIR_NONFINITE : PMX_PAIR_OK));
           if (lane_ok && (st != PMX_PAIR_OK || cp.zero_status == 2)) status[sid * P + p] = st;
         }
       }
@@ -852,7 +930,7 @@ hipError_t launch_analytical(const LaunchArgs& a, const char** name) {
     int64_t n_walk = a.S;
     const int32_t* list = nullptr;
     *name = kNameGrid;
-    if constexpr (!DYN && !LAG) {
+    if constexpr (!DYN) {
       if (a.use_classes && a.cls.n_chunks > 0) {
         *name = "pmx_analytical_classed";
         // enough blocks to fill the chip several times over, few enough that lane_setup stays amortised
@@ -871,17 +949,19 @@ hipError_t launch_analytical(const LaunchArgs& a, const char** name) {
         if (n_exact > 0) {
           int64_t cpb = 1;
           const int64_t cblocks = blocks_for(n_exact, &cpb);
+          if (LAG) *name = ll ? "pmx_analytical_classed<ll,lag>" : "pmx_analytical_classed<lag>";
           if (ll) {
-            *name = "pmx_analytical_classed<ll>";
-            hipLaunchKernelGGL((pmx_analytical_classed<KID, true, false>), dim3(static_cast<uint32_t>(cblocks * a.n_ptiles)),
+            if (!LAG) *name = "pmx_analytical_classed<ll>";
+            hipLaunchKernelGGL((pmx_analytical_classed<KID, true, false, LAG>), dim3(static_cast<uint32_t>(cblocks * a.n_ptiles)),
                                dim3(grid_threads(a.P)), 0, st, a.m, a.ops, a.cls, a.theta, a.P, static_cast<int32_t>(cpb), a.n_ptiles,
                                a.pred, a.ld, a.status);
           } else {
-            hipLaunchKernelGGL((pmx_analytical_classed<KID, false, false>), dim3(static_cast<uint32_t>(cblocks * a.n_ptiles)),
+            hipLaunchKernelGGL((pmx_analytical_classed<KID, false, false, LAG>), dim3(static_cast<uint32_t>(cblocks * a.n_ptiles)),
                                dim3(grid_threads(a.P)), 0, st, a.m, a.ops, a.cls, a.theta, a.P, static_cast<int32_t>(cpb), a.n_ptiles,
                                a.pred, a.ld, a.status);
           }
         }
+        if constexpr (!LAG)
         if (n_loose > 0) {  // subjects that share a program shape but not its step lengths
           int64_t cpb = 1;
           const int64_t cblocks = blocks_for(n_loose, &cpb);

@@ -14,6 +14,8 @@ namespace pmx {
 struct DevClassPlan {
   const uint32_t* prog_meta;
   const double* prog_dt;
+  const double* prog_t0;            // lag models: absolute start of a PROP step / first remaining event time of a RESET step
+  const double* prog_t1;            // lag models: absolute end of a PROP step
   const int64_t* cls_prog_off;
   const int32_t* chunk_cls;
   const int32_t* chunk_n;

@@ -159,3 +159,47 @@ def test_pmetrics_indexed_models_are_classed(ragged):
     n = 80
     theta = np.stack([rng.uniform(1.0, 3.0, n), rng.uniform(0.05, 0.4, n), rng.uniform(10, 60, n)], 1)
     check(model, flat, theta, "pmx_analytical_classed<loose>" if ragged else "pmx_analytical_classed")
+
+
+@pytest.mark.parametrize("structure", ["one_compartment_with_absorption", "two_compartments_with_absorption",
+                                       "three_compartments_cl_with_absorption"])
+@pytest.mark.parametrize("loglik", [False, True])
+def test_lag_time_models_on_a_shared_design_are_classed(structure, loglik):
+    # one lagged input: the bolus times are the class's, so every lane's landing times t + lag(theta) split the PROP
+    # steps of all G members alike (lag_prop / lag_open_occasion of the generic walker over the whole batch).  Lags
+    # of 0, inside a step, across several observations, across a later dose and beyond the last event; two occasions,
+    # the second dosed before its first sample.
+    ns, nk, central = STRUCTS[structure]
+    rng = np.random.default_rng(31)
+    model = Analytical.new(structure, {0: Ratio(central, nk)}, nparams=nk + 3, lag={0: nk + 1}, fa={0: nk + 2})
+    model = model.with_nstates(ns).with_ndrugs(1).with_nout(1)
+    subs = []
+    for i in range(45):
+        b = Subject.builder(f"s{i}").bolus(0.0, 100.0 + i, 0).bolus(12.0, 40.0 + i, 0).infusion(2.0, 30.0, 0, 1.5)
+        for t in (0.5, 1.0, 2.0, 4.0, 12.0, 12.5, 20.0):
+            b = b.missing_observation(t, 0)
+        b = b.reset().bolus(0.0, 75.0, 0).bolus(0.0, 5.0 + i, 0)
+        for t in (3.0, 6.0):
+            b = b.missing_observation(t, 0)
+        subs.append(b.build())
+    subs.append(models.random_subject(rng))  # a design of its own: generic walker
+    flat = model.flatten(Data(subs))
+    n = 64
+    lag = rng.choice([0.0, 0.25, 0.75, 1.5, 3.0, 13.0, 40.0], size=n)
+    theta = np.concatenate([kernel_theta(structure, n, rng), rng.uniform(10, 80, (n, 1)), lag[:, None],
+                            rng.uniform(0.4, 1.0, (n, 1))], axis=1)
+    if loglik:
+        flat = with_observed_values(flat, model, theta, 7)
+    check(model, flat, theta, "pmx_analytical_classed<ll,lag>" if loglik else "pmx_analytical_classed<lag>", loglik)
+    plan = runtime.class_plan(model, flat)
+    assert plan["classed_subjects"] == 45 and plan["chunks_loose"] == 0 and plan["generic_subjects"] == 1
+    if not loglik:  # the device's own guard (the reference has none): a negative or NaN lag flags the pair, rows NaN
+        import torch
+
+        bad = theta.copy()
+        bad[5, nk + 1], bad[6, nk + 1] = -1.0, np.nan
+        pred, st = runtime.predict(model, runtime.DevicePopulation(flat, 0), np.ascontiguousarray(bad))
+        torch.cuda.synchronize()
+        pred, st = pred.cpu().numpy(), st.cpu().numpy()
+        assert (st[:, 5:7] == _abi.PMX_PAIR_BAD_LAG).all() and np.isnan(pred[:, 5:7]).all()
+        assert (np.delete(st, [5, 6], axis=1) == 0).all() and np.isfinite(np.delete(pred, [5, 6], axis=1)).all()
