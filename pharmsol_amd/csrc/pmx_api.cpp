@@ -743,7 +743,7 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
     a.cls.cobs = slot->d_cobs;
     a.cls.chunk_obs_off = ds->d_chunk_obs_off;
     if (llreq->d_sigma_err) *llreq->d_sigma_err = slot->d_err;
-    if (pop->any_censored) a.use_classes = 0;  // the classed blocks carry {value, const, weight} only: censored rows take the generic walk
+    a.ll_censored = pop->any_censored ? 1 : 0;  // (known once the population's observation arrays are on the device)
   }
   // GRID (lane = support point, wave-uniform op stream) vs PAIR (lane = pair, divergent streams): measured crossovers
   // (tools/pairgrid_sweep.sh) are 8 support points when the classed kernel serves most subjects, ~48 when every

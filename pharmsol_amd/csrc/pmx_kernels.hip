@@ -23,6 +23,8 @@
 // ode/mod.rs:609-823 (ODE event loop; diffsol replaced by fixed-step RK4).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include <cstdlib>
 
 #include <cmath>
@@ -413,7 +415,9 @@ __device__ __forceinline__ void classed_emit_state(int out_state, const double (
 // landing times t + lag(theta) - its split points inside a PROP step - are the same for all G members: one propagator
 // per sub-interval still serves the whole batch; only the amounts are the members' own (lag_prop / lag_open_occasion
 // of the generic walker, over G states at once).
-template <int KID, bool LL, bool PERDT, bool LAGC = false>
+// CENS (log-likelihood mode): the population holds censored observations; their rows are marked in the chunk blocks
+// and folded from their full records (a separate instantiation: the extra branch costs the uncensored kernel 9 %).
+template <int KID, bool LL, bool PERDT, bool LAGC = false, bool CENS = false>
 __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx_analytical_classed(
     DevModel m, DevOps ops, DevClassPlan cp, const double* __restrict__ theta, int64_t P, int32_t chunks_per_block,
     int32_t n_ptiles, double* __restrict__ pred, int64_t ld, uint8_t* __restrict__ status) {
@@ -509,6 +513,8 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
     double* slot[G / 2];  // this lane's 16-byte slot in the first prediction row of each member pair
     double ll_acc[G];     // log-likelihood mode: running sum of each member
     int64_t cobs_off = 0;  // log-likelihood mode: the chunk's {value, const, weight} block, advanced per observation
+    int64_t kobs = 0;      // ... and how many observations of the program have been folded
+    (void)kobs;
     if constexpr (LL) {
       cobs_off = as_const(cp.chunk_obs_off)[c];
 #pragma unroll
@@ -671,11 +677,16 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
           for (int j = 0; j < G; ++j) {
             if (ov_w[j] != 0.0) {  // wave-uniform; weight 0 = missing observation (or chunk padding)
               const double y = select_state<NS>(x[j], out_state) * inv_vol;
-              const double d = ov_y[j] - y;
-              ll_acc[j] += ov_c[j] - (d * d) * ov_w[j];
+              if (CENS && ov_w[j] < 0.0) {  // censored row (marker from pmx_ll_prepare_chunks): the generic fold on its full record
+                ll_accumulate(as_const(ops.ll_obs) + (chunk_row[c * G + j] + kobs) * 4, y, ll_acc[j]);
+              } else {
+                const double d = ov_y[j] - y;
+                ll_acc[j] += ov_c[j] - (d * d) * ov_w[j];
+              }
             }
           }
           cobs_off += 3 * G;
+          ++kobs;
         } else {
           // wave-uniform: the state is picked by a scalar branch, not per-lane selects
           classed_emit_state<0, G, NS>(out_state, x, inv_vol, slot, kld, upper, pair_full, pair_half, any_half, n_live,
@@ -946,34 +957,30 @@ hipError_t launch_analytical(const LaunchArgs& a, const char** name) {
           *cpb_out = cpb;
           return ((n + cpb - 1) / cpb + 7) / 8 * 8;  // whole XCD groups
         };
+        auto launch_cls = [&](auto ll_c, auto perdt_c, auto cens_c, int64_t n) {
+          int64_t cpb = 1;
+          const int64_t cblocks = blocks_for(n, &cpb);
+          hipLaunchKernelGGL((pmx_analytical_classed<KID, decltype(ll_c)::value, decltype(perdt_c)::value, LAG, decltype(cens_c)::value>),
+                             dim3(static_cast<uint32_t>(cblocks * a.n_ptiles)), dim3(grid_threads(a.P)), 0, st, a.m, a.ops, a.cls,
+                             a.theta, a.P, static_cast<int32_t>(cpb), a.n_ptiles, a.pred, a.ld, a.status);
+        };
+        using T = std::true_type;
+        using F = std::false_type;
+        const bool cens = ll && a.ll_censored != 0;
         if (n_exact > 0) {
-          int64_t cpb = 1;
-          const int64_t cblocks = blocks_for(n_exact, &cpb);
           if (LAG) *name = ll ? "pmx_analytical_classed<ll,lag>" : "pmx_analytical_classed<lag>";
-          if (ll) {
-            if (!LAG) *name = "pmx_analytical_classed<ll>";
-            hipLaunchKernelGGL((pmx_analytical_classed<KID, true, false, LAG>), dim3(static_cast<uint32_t>(cblocks * a.n_ptiles)),
-                               dim3(grid_threads(a.P)), 0, st, a.m, a.ops, a.cls, a.theta, a.P, static_cast<int32_t>(cpb), a.n_ptiles,
-                               a.pred, a.ld, a.status);
-          } else {
-            hipLaunchKernelGGL((pmx_analytical_classed<KID, false, false, LAG>), dim3(static_cast<uint32_t>(cblocks * a.n_ptiles)),
-                               dim3(grid_threads(a.P)), 0, st, a.m, a.ops, a.cls, a.theta, a.P, static_cast<int32_t>(cpb), a.n_ptiles,
-                               a.pred, a.ld, a.status);
-          }
+          else if (ll) *name = "pmx_analytical_classed<ll>";
+          if (!ll) launch_cls(F{}, F{}, F{}, n_exact);
+          else if (cens) launch_cls(T{}, F{}, T{}, n_exact);
+          else launch_cls(T{}, F{}, F{}, n_exact);
         }
-        if constexpr (!LAG)
-        if (n_loose > 0) {  // subjects that share a program shape but not its step lengths
-          int64_t cpb = 1;
-          const int64_t cblocks = blocks_for(n_loose, &cpb);
-          if (n_exact == 0) *name = ll ? "pmx_analytical_classed<ll,loose>" : "pmx_analytical_classed<loose>";
-          if (ll)
-            hipLaunchKernelGGL((pmx_analytical_classed<KID, true, true>), dim3(static_cast<uint32_t>(cblocks * a.n_ptiles)),
-                               dim3(grid_threads(a.P)), 0, st, a.m, a.ops, a.cls, a.theta, a.P, static_cast<int32_t>(cpb), a.n_ptiles,
-                               a.pred, a.ld, a.status);
-          else
-            hipLaunchKernelGGL((pmx_analytical_classed<KID, false, true>), dim3(static_cast<uint32_t>(cblocks * a.n_ptiles)),
-                               dim3(grid_threads(a.P)), 0, st, a.m, a.ops, a.cls, a.theta, a.P, static_cast<int32_t>(cpb), a.n_ptiles,
-                               a.pred, a.ld, a.status);
+        if constexpr (!LAG) {
+          if (n_loose > 0) {  // subjects that share a program shape but not its step lengths
+            if (n_exact == 0) *name = ll ? "pmx_analytical_classed<ll,loose>" : "pmx_analytical_classed<loose>";
+            if (!ll) launch_cls(F{}, T{}, F{}, n_loose);
+            else if (cens) launch_cls(T{}, T{}, T{}, n_loose);
+            else launch_cls(T{}, T{}, F{}, n_loose);
+          }
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
@@ -1099,7 +1106,13 @@ __global__ __launch_bounds__(256) void pmx_ll_prepare_chunks(LLPrepareArgs a) {
   for (int32_t i = threadIdx.x; i < total; i += 256) {
     const int32_t j = i % a.G, f = (i / a.G) % 3, k = i / (3 * a.G);
     double v = 0.0;
-    if (j < n_live) v = a.obs4[(a.chunk_row[ch * a.G + j] + k) * 4 + f];
+    if (j < n_live) {
+      const double* rec = a.obs4 + (a.chunk_row[ch * a.G + j] + k) * 4;
+      v = rec[f];
+      // a censored row (BLOQ / ALOQ): its weight slot carries -1 as a marker, the kernel then takes the row's full
+      // record {value, const, weight, censor scale} from obs4 (rare, out of the main path)
+      if (f == 2 && rec[3] != 0.0 && v == v) v = -1.0;
+    }
     a.cobs[base + i] = v;
   }
 }

@@ -51,6 +51,7 @@ struct LaunchArgs {
   int32_t n_ptiles;  // GRID: ceil(P / 256)
   int32_t dyn;       // analytical: kernel parameters depend on covariates (re-prepare per PROP)
   int32_t adaptive;     // ODE: PMX_SOLVER_DOPRI5
+  int32_t ll_censored;  // log-likelihood mode: the population holds censored observations (classed kernel's CENS variant)
   int32_t use_classes;  // GRID analytical: run the classed kernel on cls.n_chunks, the generic one on the rest
   DevClassPlan cls;
   const int32_t* subj_list;  // GRID: walk these subjects instead of 0..S-1 (nullptr = all)

@@ -164,14 +164,14 @@ def _censor_some(flat, rng, frac_bloq=0.15, frac_aloq=0.1, frac_poly=0.2):
 @pytest.mark.parametrize("n_support", [70, 5])
 def test_censored_observations_and_per_observation_error_polynomials(n_support):
     """Censor::BLOQ / ALOQ rows take log CDF / log survival (distributions.rs:52-103), an observation's own ErrorPoly
-    replaces the model's (error_model.rs:1051-1054).  A shared design normally runs the classed kernel; censored
-    rows route it through the generic walk."""
+    replaces the model's (error_model.rs:1051-1054).  A shared design runs the classed kernel; censored rows are
+    marked in its chunk blocks and folded from their full records."""
     rng = np.random.default_rng(11)
     m, flat, theta = synth.config_c3(200, max(n_support, 8))
     theta = theta[:n_support]
     flat = _censor_some(with_observed_values(m, flat, theta[:1], rng), rng)
     assert_ll_parity(m, flat, EM_ADD, theta,
-                     expect_kernel="pmx_analytical_grid" if n_support >= 32 else "pmx_analytical_pair")
+                     expect_kernel="pmx_analytical_classed<ll>" if n_support >= 32 else "pmx_analytical_pair")
     # error polynomials alone keep the classed kernel
     flat.ev_censor = None
     assert_ll_parity(m, flat, EM_PROP, theta,

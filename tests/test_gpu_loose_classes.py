@@ -203,3 +203,17 @@ def test_lag_time_models_on_a_shared_design_are_classed(structure, loglik):
         pred, st = pred.cpu().numpy(), st.cpu().numpy()
         assert (st[:, 5:7] == _abi.PMX_PAIR_BAD_LAG).all() and np.isnan(pred[:, 5:7]).all()
         assert (np.delete(st, [5, 6], axis=1) == 0).all() and np.isfinite(np.delete(pred, [5, 6], axis=1)).all()
+
+
+def test_censored_observations_in_loose_classes():
+    # BLOQ / ALOQ rows and per-observation error polynomials on a population with individual sampling times: the
+    # loose chunks mark the censored rows and fold them from their full records
+    from tests.test_gpu_likelihood import EM_ADD, _censor_some, assert_ll_parity
+    from tests.test_gpu_likelihood import with_observed_values as observed
+
+    rng = np.random.default_rng(12)
+    model = synth.model_two_cpt_iv()
+    flat = synth.population_c23(203, ragged=True)
+    theta = synth.theta_c3(72)
+    flat = _censor_some(observed(model, flat, theta[:1], rng), rng)
+    assert_ll_parity(model, flat, EM_ADD, theta, expect_kernel="pmx_analytical_classed<ll,loose>")
