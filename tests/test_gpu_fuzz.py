@@ -223,3 +223,70 @@ def test_random_ode_configuration(seed):
         scale = np.maximum(np.abs(want[ok]), 1e-3 * np.abs(want[ok]).max() + 1e-300)
         err = (np.abs(got[ok] - want[ok]) / scale).max()
         assert err < (2e-6 if adaptive else 1e-9), (err, recipe, runtime.last_kernel_name())
+
+
+STATE_NAMES = {1: ["central"], 2: ["central", "periph"], 3: ["central", "periph1", "periph2"]}
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PMX_FUZZ_COVARIATE", "60"))))
+def test_random_covariate_model(seed):
+    """Covariate-derived rate constants (and, half the time, a covariate-derived volume) on every structure, CL forms
+    included: the per-segment coefficient rebuild (Newton reciprocals, single-precision-seeded cube root) against the
+    oracle's IEEE arithmetic, GRID and PAIR lane mappings, one or two occasions, constant and interpolated covariates."""
+    import torch
+    from pharmsol_amd import Lin
+
+    rng = np.random.default_rng(9000 + seed)
+    name = list(STRUCTS)[int(rng.integers(0, len(STRUCTS)))]
+    ns, nk, central = STRUCTS[name]
+    knames = _abi.KERNEL_PARAMETER_NAMES[name]
+    absorb = "absorption" in name
+    states = (["gut"] if absorb else []) + STATE_NAMES[ns - (1 if absorb else 0)]
+    # the elimination parameter (ke / k10 / cl) scales with weight; the volume behind the output may too
+    elim = next(k for k in knames if k in ("ke", "k10", "cl"))
+    params = [k + "0" if k == elim else k for k in knames]
+    derived = {elim: Scaled(elim + "0", (Pow("wt", 70.0, 0.75),) if rng.random() < 0.6 else (Lin("wt", 70.0, 0.004),))}
+    vol_in_kernel = next((k for k in knames if k in ("v", "vc")), None)
+    if vol_in_kernel is None:
+        params.append("v")
+        out_vol = "v"
+        if rng.random() < 0.5:
+            params[-1] = "v0"
+            derived["v"] = Scaled("v0", (Pow("wt", 70.0, 1.0),))
+    else:
+        out_vol = vol_in_kernel
+    m = analytical(name=f"fz{seed}", params=params, derived=derived, covariates=["wt"], structure=name, states=states,
+                   outputs=["cp"], routes=[bolus("dose", states[0]), infusion("iv", "central")], out={"cp": Ratio("central", out_vol)})
+    subs = []
+    n_sub = int(rng.integers(3, 30))
+    for i in range(n_sub):
+        b = Subject.builder(f"s{i}").covariate("wt", 0.0, float(rng.uniform(45, 110)))
+        if rng.random() < 0.5:
+            b = b.covariate("wt", float(rng.uniform(5, 30)), float(rng.uniform(45, 110)))
+        b = b.bolus(0.0, float(rng.uniform(50, 300)), "dose")
+        if rng.random() < 0.5:
+            b = b.infusion(float(rng.uniform(0.5, 6)), float(rng.uniform(50, 200)), "iv", float(rng.uniform(0.5, 3)))
+        for t in np.sort(rng.uniform(0.2, 40.0, int(rng.integers(2, 9)))):
+            b = b.missing_observation(float(t), "cp")
+        if rng.random() < 0.3:
+            b = b.reset().covariate("wt", 0.0, float(rng.uniform(45, 110))).bolus(0.0, 80.0, "dose")
+            for t in np.sort(rng.uniform(0.5, 20.0, 3)):
+                b = b.missing_observation(float(t), "cp")
+        subs.append(b.build())
+    n = int(rng.choice([2, 9, 40, 70, 130]))
+    kt = kernel_theta(name, n, rng)
+    theta = kt if vol_in_kernel is not None else np.concatenate([kt, rng.uniform(10, 80, (n, 1))], axis=1)
+    recipe = dict(seed=seed, structure=name, derived=list(derived), subjects=n_sub, support=n)
+    flat = m.flatten(Data(subs))
+    pop = runtime.DevicePopulation(flat, 0)
+    pred, st = runtime.predict(m, pop, np.ascontiguousarray(theta))
+    torch.cuda.synchronize()
+    got, st = pred.cpu().numpy(), st.cpu().numpy()
+    want, wst = oracle.predict(m, flat, theta)
+    np.testing.assert_array_equal(st, wst, err_msg=str(recipe))
+    ok = np.isfinite(want)
+    np.testing.assert_array_equal(np.isfinite(got), ok, err_msg=str(recipe))
+    if ok.any():
+        scale = np.maximum(np.abs(want[ok]), 1e-9 * np.abs(want[ok]).max() + 1e-300)
+        err = (np.abs(got[ok] - want[ok]) / scale).max()
+        assert err < 1e-6, (err, recipe, runtime.last_kernel_name())
