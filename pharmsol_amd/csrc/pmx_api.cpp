@@ -412,8 +412,14 @@ pmx::CompileKey key_for(const pmx_model* m) {
     // (one lagged input is classed too: in an exact class the bolus times are shared, so a lane's split points and the
     // propagator of every sub-interval serve all G members)
     const bool lag_ok = (k.lag_mask & (k.lag_mask - 1u)) == 0u;
-    if (!disabled && !m->dyn && !reads_pad && m->d.n_covariates == 0 && lag_ok) {
-      const int st = pmx::kernel_structure(m->d.kernel);
+    // (covariate-derived constants are classed by program shape alone, each member with its own factor rows)
+    const bool plain = !m->dyn && m->d.n_covariates == 0;
+    // ... where it pays: the one- and two-state structures (1-cpt + absorption 3.41 -> 2.87 ms on the C5 design); from
+    // three states up the rebuild is so dominated by its own arithmetic that the batch gains nothing (C5: 19.4 -> 19.9 ms)
+    const int st = pmx::kernel_structure(m->d.kernel);
+    const bool dyn_ok = m->dyn && !m->d.pmetrics_indexing && k.lag_mask == 0 &&
+                        (st == pmx::S_ONE || st == pmx::S_ONE_ABS || st == pmx::S_TWO);
+    if (!disabled && !reads_pad && lag_ok && (plain || dyn_ok)) {
       k.class_g = (st == pmx::S_ONE || st == pmx::S_ONE_ABS || st == pmx::S_TWO) ? 8 : 4;  // == ClassBatch<KID>::G
     }
   } else {
@@ -520,6 +526,9 @@ int32_t get_stream(pmx_population* pop, const pmx::CompileKey& key, DeviceStream
       if ((rc = upload(cp.chunk_row, &ds->cls.chunk_row, &ds->allocs)) != PMX_OK) return rc;
       if ((rc = upload(cp.val, &ds->cls.val, &ds->allocs)) != PMX_OK) return rc;
       if ((rc = upload(cp.dtv, &ds->cls.dtv, &ds->allocs)) != PMX_OK) return rc;
+      if ((rc = upload(cp.facp, &ds->cls.facp, &ds->allocs)) != PMX_OK) return rc;
+      if ((rc = upload(cp.faco, &ds->cls.faco, &ds->allocs)) != PMX_OK) return rc;
+      ds->cls.n_fac = cp.n_fac;
       if ((rc = upload(cp.generic_subjects, &ds->cls.generic_subjects, &ds->allocs)) != PMX_OK) return rc;
       ds->h_chunk_row = cp.chunk_row;
       ds->h_chunk_n = cp.chunk_n;

@@ -487,6 +487,10 @@ void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, i
   *cp = ClassPlan{};
   cp->G = G;
   const int64_t S = hp.n_subjects;
+  const bool dyn = os.key.n_derived > 0 && !os.op_fac.empty();  // covariate-derived constants: nothing to share but the program shape
+  const size_t nfac = static_cast<size_t>(os.key.n_derived) * PMX_MAX_FACTORS;
+  cp->n_fac = static_cast<int32_t>(nfac);
+  if (dyn) loose_classes = true;
   const bool lagged = os.n_lag_slots == 1;  // (the caller only asks for a plan of a lag model when one input is lagged)
   if (os.n_lag_slots > 1) return;
   if (lagged) loose_classes = false;  // loose members do not share the times
@@ -579,6 +583,7 @@ void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, i
     // bits 25-26 = its outeq), so a PROP+OBS pair costs one trip of the device loop.  A second observation
     // at the same instant gets a step of its own (kind OP_OBS = no state change).
     std::vector<int32_t> step_of_op(static_cast<size_t>(r1 - r0), -1);
+    std::vector<int32_t> obs_step_of_op(static_cast<size_t>(r1 - r0), -1);  // OBS op -> the step that emits its row
     std::vector<uint32_t> step_meta;
     std::vector<double> step_dt, step_t0, step_t1;
     for (int64_t o = r0; o < r1; ++o) {
@@ -587,7 +592,9 @@ void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, i
       if (kind == OP_OBS) {
         if (!step_meta.empty() && ((step_meta.back() >> 24) & 1u) == 0u) {
           step_meta.back() |= (1u << 24) | ((io & 3u) << 25);
+          obs_step_of_op[static_cast<size_t>(o - r0)] = static_cast<int32_t>(step_meta.size()) - 1;
         } else {
+          obs_step_of_op[static_cast<size_t>(o - r0)] = static_cast<int32_t>(step_meta.size());
           step_meta.push_back(make_meta(OP_OBS, 0) | (1u << 24) | ((io & 3u) << 25));
           step_dt.push_back(0.0);
           step_t0.push_back(0.0);
@@ -641,10 +648,22 @@ void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, i
       const size_t base = cp->val.size();
       cp->val.resize(base + static_cast<size_t>(L) * G, 0.0);
       cp->dtv.resize(base + static_cast<size_t>(L) * G, 0.0);
+      if (dyn) {
+        cp->facp.resize((base + static_cast<size_t>(L) * G) * nfac, 1.0);
+        cp->faco.resize((base + static_cast<size_t>(L) * G) * nfac, 1.0);
+      }
       for (int32_t j = 0; j < n; ++j) {
         const int64_t s0 = os.subj_op_off[pick[static_cast<size_t>(j)]];
         for (int64_t i = 0; i < r1 - r0; ++i) {
           const int32_t st = step_of_op[static_cast<size_t>(i)];
+          if (dyn) {  // this member's covariate factors at the op: the PROP's rate constants, the observation's volume
+            const int32_t so = obs_step_of_op[static_cast<size_t>(i)];
+            const double* src = &os.op_fac[static_cast<size_t>(s0 + i) * nfac];
+            if (so >= 0)
+              std::memcpy(&cp->faco[(base + static_cast<size_t>(so) * G + j) * nfac], src, nfac * sizeof(double));
+            else if (st >= 0 && (os.op_meta[s0 + i] & 0xffu) == OP_PROP)
+              std::memcpy(&cp->facp[(base + static_cast<size_t>(st) * G + j) * nfac], src, nfac * sizeof(double));
+          }
           if (st < 0) continue;
           const uint32_t kind = os.op_meta[s0 + i] & 0xffu;
           double v = 0.0;
@@ -661,7 +680,7 @@ void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, i
   };
   std::vector<int32_t> leftover;  // members of classes too small to batch: second chance as loose classes
   for (size_t c = 0; c < members.size(); ++c) {
-    if (static_cast<int32_t>(members[c].size()) < min_class_size) {
+    if (dyn || static_cast<int32_t>(members[c].size()) < min_class_size) {
       leftover.insert(leftover.end(), members[c].begin(), members[c].end());
       continue;
     }

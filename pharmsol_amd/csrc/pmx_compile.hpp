@@ -139,6 +139,10 @@ struct ClassPlan {
   // per member; what the members still share is the program walk and the paired stores.
   int64_t n_chunks_exact = 0;
   std::vector<double> dtv;             // per chunk: [program length][G]  PROP length of each member (loose chunks)
+  // covariate-derived rate constants / volumes (every class is loose then): the members' own covariate factors
+  // (OpStream::op_fac rows) of the step's PROP and of the observation fused into it, [program length][G][n_fac]
+  int32_t n_fac = 0;
+  std::vector<double> facp, faco;
   std::vector<int32_t> generic_subjects;  // subjects left to the generic kernel (ascending)
 };
 

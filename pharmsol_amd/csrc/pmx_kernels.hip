@@ -417,7 +417,10 @@ __device__ __forceinline__ void classed_emit_state(int out_state, const double (
 // of the generic walker, over G states at once).
 // CENS (log-likelihood mode): the population holds censored observations; their rows are marked in the chunk blocks
 // and folded from their full records (a separate instantiation: the extra branch costs the uncensored kernel 9 %).
-template <int KID, bool LL, bool PERDT, bool LAGC = false, bool CENS = false>
+// DYNC (with PERDT): covariate-derived rate constants / volumes.  The members share the program shape only; each
+// rebuilds its propagator from its own covariate factors (the generic walker's lane_advance_dyn, the plan's facp
+// rows) and scales its output by its own volume (lane_out, faco rows).  Complex roots are a member's, per occasion.
+template <int KID, bool LL, bool PERDT, bool LAGC = false, bool CENS = false, bool DYNC = false>
 __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx_analytical_classed(
     DevModel m, DevOps ops, DevClassPlan cp, const double* __restrict__ theta, int64_t P, int32_t chunks_per_block,
     int32_t n_ptiles, double* __restrict__ pred, int64_t ld, uint8_t* __restrict__ status) {
@@ -455,13 +458,19 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
   typename LM::S::Coef coef;
   double inv_vol0;  // 1/volume of output 0 (NaN for a lane with complex roots: all its predictions are NaN)
   bool lane_good;
-  {
+  LM Ld;  // DYNC: the lane's base parameters, kept for the per-member rebuilds
+  if constexpr (DYNC) {
+    lane_setup<KID, true>(m, theta + pc * m.nparams, Ld);
+    lane_good = true;
+    inv_vol0 = Ld.inv_vol[0];
+  } else {
     LM L;
     lane_setup<KID, false>(m, theta + pc * m.nparams, L);
     coef = L.coef;
     lane_good = L.ok;
     inv_vol0 = L.ok ? L.inv_vol[0] : __longlong_as_double(0x7ff8000000000000LL);
   }
+  (void)Ld;
   double lagv = 0.0;      // LAGC: this lane's lag time of the lagged input
   bool lane_badlag = false;
   if constexpr (LAGC) {
@@ -534,6 +543,8 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
 #pragma unroll
       for (int i = 0; i < NS; ++i) x[j][i] = 0.0;
     uint32_t bad = 0;  // bit j: member j emitted a non-finite prediction
+    uint32_t cplx = 0;  // DYNC: bit j: a rebuild of member j found complex eigenvalues in the current occasion
+    (void)cplx;
     // the lane's exponentials outlive a step: bits 27-29 of a PROP step say how this step's length relates
     // to the previous PROP's (0 = unrelated: exp(); 1 = equal; n = 2..4: n times as long: ladder_pow)
     double ex[LM::S::NE];
@@ -583,6 +594,13 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
             bolus_all();
           }
           if (t1 > t) advance_all(t1 - t, voff, true);
+        } else if constexpr (DYNC) {
+          const int64_t nf = cp.n_fac;
+#pragma unroll
+          for (int j = 0; j < G; ++j) {
+            if (!lane_advance_dyn<KID>(m, Ld, cp.facp + (voff + j) * nf, x[j], dtv[voff + j], val[voff + j])) cplx |= (1u << j);
+            if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+          }
         } else if constexpr (PERDT) {
           // loose chunk: every member has its own step length, hence its own propagator; the members still share
           // the walk through the program (one scalar decode per step instead of G) and the paired stores
@@ -624,6 +642,10 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
         for (int i = 0; i < NS; ++i) {
           double xi = 0.0;
           if (io && m.has_init && m.init_param[i + m.pm] >= 0) xi = th[m.init_param[i + m.pm]];
+          if constexpr (DYNC) {  // a new occasion re-derives its coefficients: what the last one flagged is forgotten
+            cplx = 0;
+            bad = 0;
+          }
 #pragma unroll
           for (int j = 0; j < G; ++j) x[j][i] = xi;
         }
@@ -676,7 +698,11 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
 #pragma unroll
           for (int j = 0; j < G; ++j) {
             if (ov_w[j] != 0.0) {  // wave-uniform; weight 0 = missing observation (or chunk padding)
-              const double y = select_state<NS>(x[j], out_state) * inv_vol;
+              double y = select_state<NS>(x[j], out_state) * inv_vol;
+              if constexpr (DYNC) {
+                y = ((cplx >> j) & 1u) ? __longlong_as_double(0x7ff8000000000000LL)
+                                       : lane_out<KID>(m, Ld, x[j], 0.0, oq, cp.faco + (voff + j) * cp.n_fac);
+              }
               if (CENS && ov_w[j] < 0.0) {  // censored row (marker from pmx_ll_prepare_chunks): the generic fold on its full record
                 ll_accumulate(as_const(ops.ll_obs) + (chunk_row[c * G + j] + kobs) * 4, y, ll_acc[j]);
               } else {
@@ -688,9 +714,18 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
           cobs_off += 3 * G;
           ++kobs;
         } else {
-          // wave-uniform: the state is picked by a scalar branch, not per-lane selects
-          classed_emit_state<0, G, NS>(out_state, x, inv_vol, slot, kld, upper, pair_full, pair_half, any_half, n_live,
-                                       bad);
+          if constexpr (DYNC) {
+            double ys[G][1];  // each member's prediction under its own volume (NaN while its occasion has complex roots)
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+              ys[j][0] = ((cplx >> j) & 1u) ? __longlong_as_double(0x7ff8000000000000LL)
+                                            : lane_out<KID>(m, Ld, x[j], 0.0, oq, cp.faco + (voff + j) * cp.n_fac);
+            classed_emit<0, G, 1>(ys, 1.0, slot, kld, upper, pair_full, pair_half, any_half, n_live, bad);
+          } else {
+            // wave-uniform: the state is picked by a scalar branch, not per-lane selects
+            classed_emit_state<0, G, NS>(out_state, x, inv_vol, slot, kld, upper, pair_full, pair_half, any_half, n_live,
+                                         bad);
+          }
           kld += ld;
         }
       }
@@ -707,13 +742,13 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
     }
     // status bytes: the library zeroes the array before the launch (PMX_PAIR_OK == 0); only failures are
     // written here, so the healthy case issues no byte stores at all
-    if (status != nullptr && (cp.zero_status == 2 || __any(((bad != 0u || !lane_good || lane_badlag) && lane_ok) ? 1 : 0))) {
+    if (status != nullptr && (cp.zero_status == 2 || __any(((bad != 0u || cplx != 0u || !lane_good || lane_badlag) && lane_ok) ? 1 : 0))) {
       if (cp.zero_status == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clearing store above lands first
 #pragma unroll
       for (int j = 0; j < G; ++j) {
         if (j < n_live) {
           const int64_t sid = chunk_subj[c * G + j];
-          const uint8_t st = !lane_good ? PMX_PAIR_COMPLEX_ROOTS
+          const uint8_t st = (!lane_good || ((cplx >> j) & 1u)) ? PMX_PAIR_COMPLEX_ROOTS
                              : (lane_badlag ? PMX_PAIR_BAD_LAG : (((bad >> j) & 1u) ? PMX_PAIR_NONFINITE : PMX_PAIR_OK));
           if (lane_ok && (st != PMX_PAIR_OK || cp.zero_status == 2)) status[sid * P + p] = st;
         }
@@ -941,7 +976,7 @@ hipError_t launch_analytical(const LaunchArgs& a, const char** name) {
     int64_t n_walk = a.S;
     const int32_t* list = nullptr;
     *name = kNameGrid;
-    if constexpr (!DYN) {
+    if constexpr (!(DYN && LAG)) {
       if (a.use_classes && a.cls.n_chunks > 0) {
         *name = "pmx_analytical_classed";
         // enough blocks to fill the chip several times over, few enough that lane_setup stays amortised
@@ -960,7 +995,8 @@ hipError_t launch_analytical(const LaunchArgs& a, const char** name) {
         auto launch_cls = [&](auto ll_c, auto perdt_c, auto cens_c, int64_t n) {
           int64_t cpb = 1;
           const int64_t cblocks = blocks_for(n, &cpb);
-          hipLaunchKernelGGL((pmx_analytical_classed<KID, decltype(ll_c)::value, decltype(perdt_c)::value, LAG, decltype(cens_c)::value>),
+          hipLaunchKernelGGL((pmx_analytical_classed<KID, decltype(ll_c)::value, decltype(perdt_c)::value, LAG, decltype(cens_c)::value,
+                                                     (DYN && decltype(perdt_c)::value)>),
                              dim3(static_cast<uint32_t>(cblocks * a.n_ptiles)), dim3(grid_threads(a.P)), 0, st, a.m, a.ops, a.cls,
                              a.theta, a.P, static_cast<int32_t>(cpb), a.n_ptiles, a.pred, a.ld, a.status);
         };
@@ -977,6 +1013,7 @@ hipError_t launch_analytical(const LaunchArgs& a, const char** name) {
         if constexpr (!LAG) {
           if (n_loose > 0) {  // subjects that share a program shape but not its step lengths
             if (n_exact == 0) *name = ll ? "pmx_analytical_classed<ll,loose>" : "pmx_analytical_classed<loose>";
+            if (DYN) *name = ll ? "pmx_analytical_classed<ll,dyn>" : "pmx_analytical_classed<dyn>";
             if (!ll) launch_cls(F{}, T{}, F{}, n_loose);
             else if (cens) launch_cls(T{}, T{}, T{}, n_loose);
             else launch_cls(T{}, T{}, F{}, n_loose);

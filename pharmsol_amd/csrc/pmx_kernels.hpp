@@ -24,6 +24,10 @@ struct DevClassPlan {
   const int64_t* chunk_row;  // [n_chunks*G] first prediction row of each member (0 for padding)
   const double* val;
   const double* dtv;                // loose chunks: each member's own PROP lengths, laid out like val
+  const double* facp;               // covariate models: [..][G][n_fac] covariate factors of each member's PROP ...
+  const double* faco;               // ... and of the observation fused into the step
+  int32_t n_fac;
+  int32_t pad_;
   const double* cobs;               // log-likelihood mode: per chunk [observation k][3][G] = value, const term, weight
   const int64_t* chunk_obs_off;     // [n_chunks] offset of the chunk's block in cobs
   const int32_t* generic_subjects;  // subjects the generic GRID kernel still has to walk

@@ -140,7 +140,8 @@ def test_covariate_derived_constants_of_the_smaller_structures(structure, params
           "kcp": rng.uniform(0.1, 0.6, n), "kpc": rng.uniform(0.05, 0.3, n)}
     theta = np.stack([th[p] for p in params], axis=1)
     assert_parity(m, flat, theta, TOL_ANALYTICAL,
-                  expect_kernel="pmx_analytical_grid<dyn>" if n_support >= 48 else "pmx_analytical_pair<dyn>")
+                  expect_kernel=("pmx_analytical_classed<dyn>" if structure != "two_compartments_with_absorption" else "pmx_analytical_grid<dyn>")
+                  if n_support >= 48 else "pmx_analytical_pair<dyn>")
 
 
 # --------------------------------------------------------------------------- every kernel, both lane mappings
@@ -533,7 +534,7 @@ def test_pmetrics_csv_population_end_to_end():
     flat = eq.flatten(data)
     assert flat.n_subjects == 40 and flat.n_occasions == 60
     th = np.stack([rng.uniform(0.05, 0.4, 48), rng.uniform(10, 60, 48)], axis=1)
-    assert_parity(eq, flat, th, TOL_ANALYTICAL, expect_kernel="pmx_analytical_grid<dyn>")
+    assert_parity(eq, flat, th, TOL_ANALYTICAL, expect_kernel="pmx_analytical_")
 
 
 def test_small_support_grids_pick_the_measured_lane_mapping():

@@ -254,7 +254,7 @@ def test_graft_entry_build_is_consistent_with_the_library():
 
 def test_class_planner_exact_loose_and_generic_subjects():
     """pmx_debug_class_plan: a shared design -> exact classes; the same shape with individual times -> loose classes;
-    shapes nobody shares and empty subjects -> the generic walker; covariate models are not classed."""
+    shapes nobody shares and empty subjects -> the generic walker; covariate models -> loose classes only."""
     from pharmsol_amd import Analytical, Data, Ratio, Subject, runtime, synth
 
     m = synth.model_two_cpt_iv()
@@ -262,7 +262,16 @@ def test_class_planner_exact_loose_and_generic_subjects():
     assert exact == dict(chunks_exact=126, chunks_loose=0, classed_subjects=1003, generic_subjects=0, members_per_chunk=8)
     loose = runtime.class_plan(m, synth.population_c23(1003, ragged=True))
     assert loose == dict(chunks_exact=0, chunks_loose=126, classed_subjects=1003, generic_subjects=0, members_per_chunk=8)
+    # covariate-derived constants: the three-compartment rebuild gains nothing from batching and stays generic ...
     assert runtime.class_plan(synth.model_three_cpt_abs_wt(), synth.population_c5(50))["members_per_chunk"] == 0
+    # ... the one- and two-state structures are classed by program shape (loose chunks), each member with its own factors
+    from pharmsol_amd import Pow, Scaled, analytical, bolus
+
+    small = analytical(name="wt1", params=["ka", "ke0", "v"], derived={"ke": Scaled("ke0", (Pow("wt", 70.0, 0.75),))},
+                       covariates=["wt"], structure="one_compartment_with_absorption", states=["gut", "central"],
+                       outputs=["cp"], routes=[bolus("oral", "gut")], out={"cp": Ratio("central", "v")})
+    cov = runtime.class_plan(small, synth.population_c5(50))
+    assert cov == dict(chunks_exact=0, chunks_loose=7, classed_subjects=50, generic_subjects=0, members_per_chunk=8)
 
     model = Analytical.new("one_compartment", {0: Ratio(0, 1)}, nparams=2).with_nstates(1).with_ndrugs(1).with_nout(1)
     rng = np.random.default_rng(0)
