@@ -63,7 +63,9 @@ enum {
   PMX_PAIR_OK = 0,
   PMX_PAIR_COMPLEX_ROOTS = 1, /* reference panics: two_compartment_models.rs:20-22, three_compartment_models.rs:32-34 */
   PMX_PAIR_NONFINITE = 2,     /* a prediction is NaN/inf (PharmsolError::NonFiniteLikelihood-style guard) */
-  PMX_PAIR_BAD_LAG = 3,       /* the support point gives a negative or NaN lag time: its predictions are NaN */
+  PMX_PAIR_BAD_LAG = 3,       /* the support point gives a NaN lag time: its predictions are NaN (the reference panics in
+                                 its sort).  A NEGATIVE lag is not an error: the bolus moves earlier, as in the reference
+                                 (`if l != 0.0 { time += l }`, src/data/structs.rs:629-634) */
   PMX_PAIR_SOLVER_FAIL = 4    /* adaptive ODE solver: step size underflow (PharmsolError::DiffsolError, error/mod.rs:25) */
 };
 
@@ -381,6 +383,10 @@ const char* pmx_last_kernel_name(void);
 
 /* Message of the last failing call made by this thread ("" if none). */
 const char* pmx_last_error(void);
+
+/* The library's developer switches (PMX_DISABLE_CLASSING, PMX_DISABLE_LADDER, PMX_TUNE_*) are read
+ * from the environment ONCE, at the first call that needs them.  This re-reads them (tuning scripts, tests). */
+void pmx_debug_reload_env(void);
 
 /* ---- host-side introspection (needs no device) ------------------------------ */
 /* The flattened op stream the device walks for (population, model): what the

@@ -56,6 +56,7 @@ SYMBOLS = [
     ("pmx_debug_compile", C.c_int32, [_PD, _MD, C.POINTER(_abi.pmx_op_stream_view)]),
     ("pmx_debug_free", None, [C.POINTER(_abi.pmx_op_stream_view)]),
     ("pmx_debug_class_plan", C.c_int32, [_PD, _MD, C.POINTER(C.c_int64)]),
+    ("pmx_debug_reload_env", None, []),
 ]
 
 

@@ -30,6 +30,49 @@ int32_t fail(int32_t code, const std::string& msg) {
   return code;
 }
 
+// Developer switches (INTEGRATION.md "environment switches").  Read ONCE, at the first call that needs them: a
+// std::getenv per launch is measurable on the 11 us C2 pass.  pmx_debug_reload_env() re-reads them (tuning scripts
+// and tests that flip a switch inside one process).
+struct Tunables {
+  bool disable_ladder = false, disable_classing = false;
+  int32_t steps_per_trip = 0, grid_min_p = 0, min_class = 0, cpb = 0;
+  int32_t spread = -1, loose = -1;  // -1 = library default
+  void load() {
+    auto flag = [](const char* n) {
+      const char* e = std::getenv(n);
+      return e && e[0] && e[0] != '0';
+    };
+    auto num = [](const char* n) {
+      const char* e = std::getenv(n);
+      const int v = e ? std::atoi(e) : 0;
+      return v > 0 ? v : 0;
+    };
+    auto tri = [](const char* n) {
+      const char* e = std::getenv(n);
+      return e ? ((e[0] && e[0] != '0') ? 1 : 0) : -1;
+    };
+    disable_ladder = flag("PMX_DISABLE_LADDER");
+    disable_classing = flag("PMX_DISABLE_CLASSING");
+    steps_per_trip = num("PMX_TUNE_STEPS_PER_TRIP");
+    grid_min_p = num("PMX_TUNE_GRID_MIN_P");
+    min_class = num("PMX_TUNE_MIN_CLASS");
+    cpb = num("PMX_TUNE_CPB");
+    spread = tri("PMX_TUNE_SPREAD");
+    loose = tri("PMX_TUNE_LOOSE");
+  }
+};
+std::mutex g_tun_mu;
+Tunables g_tun;
+bool g_tun_loaded = false;
+Tunables tunables() {
+  std::lock_guard<std::mutex> lock(g_tun_mu);
+  if (!g_tun_loaded) {
+    g_tun.load();
+    g_tun_loaded = true;
+  }
+  return g_tun;
+}
+
 #define PMX_HIP(call)                                                                              \
   do {                                                                                             \
     hipError_t e_ = (call);                                                                        \
@@ -163,6 +206,12 @@ int32_t pmx_device_count(void) {
 }
 
 const char* pmx_last_error(void) { return g_err.c_str(); }
+
+void pmx_debug_reload_env(void) {
+  std::lock_guard<std::mutex> lock(g_tun_mu);
+  g_tun.load();
+  g_tun_loaded = true;
+}
 const char* pmx_last_kernel_name(void) { return g_kernel_name; }
 
 int32_t pmx_population_create(const pmx_population_desc* desc, int32_t device, pmx_population** out) {
@@ -399,12 +448,11 @@ pmx::CompileKey key_for(const pmx_model* m) {
     for (int i = 0; i < PMX_MAX_INPUTS; ++i)
       if (m->d.lag_param[i] >= 0) k.lag_mask |= (1u << i);
     // (bioavailability does not stop classing: the amounts in the plan are the recorded ones, each lane scales them)
-    const char* nl = std::getenv("PMX_DISABLE_LADDER");  // fresh exp() on every step (A/B and parity checks)
-    k.ladder = !m->dyn && k.lag_mask == 0 && !(nl && nl[0] && nl[0] != '0');
+    const Tunables tun = tunables();
+    k.ladder = !m->dyn && k.lag_mask == 0 && !tun.disable_ladder;  // (switch: fresh exp() on every step, A/B and parity checks)
     k.n_derived = m->d.n_derived;
     std::memcpy(k.derived, m->d.derived, sizeof(k.derived));
-    const char* off = std::getenv("PMX_DISABLE_CLASSING");
-    const bool disabled = off && off[0] && off[0] != '0';
+    const bool disabled = tun.disable_classing;
     bool reads_pad = false;  // pm_ indexing: an output on model state 0 reads the wrapper's pad slot (generic walker only)
     if (m->d.pmetrics_indexing)
       for (int o = 0; o < m->d.nout && o < PMX_MAX_OUT; ++o)
@@ -506,12 +554,10 @@ int32_t get_stream(pmx_population* pop, const pmx::CompileKey& key, DeviceStream
   }
   if (key.class_g > 0) {
     pmx::ClassPlan cp;
-    int32_t min_class = key.class_g / 2;
-    if (const char* e = std::getenv("PMX_TUNE_MIN_CLASS")) min_class = std::atoi(e) > 0 ? std::atoi(e) : min_class;  // tuning experiments
-    bool spread = true;  // (0.94-0.97 vs 1.05-1.11 ms on C3 in most allocations, never slower: tools/alloc_tune.py)
-    if (const char* e = std::getenv("PMX_TUNE_SPREAD")) spread = e[0] && e[0] != '0';  // tuning experiments
-    bool loose = true;  // subjects without a shared design still share a program shape: batched with per-member step lengths
-    if (const char* e = std::getenv("PMX_TUNE_LOOSE")) loose = e[0] && e[0] != '0';  // tuning experiments
+    const Tunables tun = tunables();  // (tuning experiments)
+    const int32_t min_class = tun.min_class > 0 ? tun.min_class : key.class_g / 2;
+    const bool spread = tun.spread < 0 ? true : tun.spread != 0;  // (0.94-0.97 vs 1.05-1.11 ms on C3 in most allocations, never slower: tools/alloc_tune.py)
+    const bool loose = tun.loose < 0 ? true : tun.loose != 0;  // subjects without a shared design still share a program shape: batched with per-member step lengths
     pmx::build_class_plan(pop->hp, os, key.class_g, min_class, &cp, key.ladder, spread, loose);
     if (cp.n_chunks > 0) {
       if ((rc = upload(cp.prog_meta, &ds->cls.prog_meta, &ds->allocs)) != PMX_OK) return rc;
@@ -624,7 +670,6 @@ int32_t acquire_ll_slot(const pmx_model* model, pmx_population* pop, DeviceStrea
   }
   PMX_HIP(hipStreamWaitEvent(st, slot->ev, 0));  // after the slot's last fill / read, whatever stream that was on
   if (!hit) {
-    slot->em.assign(em, em + nout);
     pmx::LLPrepareArgs a{};
     a.obs_y = pop->d_obs_y;
     a.obs_outeq = pop->d_obs_outeq;
@@ -642,8 +687,15 @@ int32_t acquire_ll_slot(const pmx_model* model, pmx_population* pop, DeviceStrea
     a.G = ds->cls.G;
     a.cobs = slot->d_cobs;
     a.stream = stream;
-    PMX_HIP(hipMemsetAsync(slot->d_err, 0, sizeof(int32_t), st));
-    PMX_HIP(pmx::launch_ll_prepare(a));
+    // Filling: until the event below is recorded behind the fill, the slot must not be hit by another host thread (its
+    // stream would only wait for the slot's PREVIOUS use and read a half-written table).  pop->mu is held throughout; a
+    // failed fill leaves the slot keyless.
+    slot->em.clear();
+    hipError_t fe = hipMemsetAsync(slot->d_err, 0, sizeof(int32_t), st);
+    if (fe == hipSuccess) fe = pmx::launch_ll_prepare(a);
+    if (fe == hipSuccess) fe = hipEventRecord(slot->ev, st);
+    if (fe != hipSuccess) return fail(PMX_ERR_HIP, std::string("log-likelihood table fill: ") + hipGetErrorString(fe));
+    slot->em.assign(em, em + nout);
   }
   slot->stamp = ++ds->ll_stamp;
   slot->host_users++;
@@ -719,9 +771,8 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
   {
     // ODE PAIR kernel, steps per trip of the lane state machine (pmx_ode.hpp ode_pair_body): tools/steps_per_trip_sweep.sh
     const int64_t n_pairs = batch ? pop->hp.n_subjects : pop->hp.n_subjects * P;
-    int32_t spt = n_pairs <= 131072 ? 48 : 32;
-    if (const char* e = std::getenv("PMX_TUNE_STEPS_PER_TRIP")) spt = std::atoi(e) > 0 ? std::atoi(e) : spt;
-    a.ops.steps_per_trip = spt;
+    const int32_t spt_tuned = tunables().steps_per_trip;
+    a.ops.steps_per_trip = spt_tuned > 0 ? spt_tuned : (n_pairs <= 131072 ? 48 : 32);
   }
   a.theta = d_theta;
   a.P = batch ? 1 : P;
@@ -760,7 +811,8 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
   int64_t grid_min_p = 32;
   if (d.eq_kind == PMX_EQ_ANALYTICAL)
     grid_min_p = (a.use_classes && 2 * ds->n_classed_subjects >= a.S) ? 8 : 48;
-  if (const char* e = std::getenv("PMX_TUNE_GRID_MIN_P")) grid_min_p = std::atoi(e) > 0 ? std::atoi(e) : grid_min_p;  // tuning experiments
+  if (const int32_t g = tunables().grid_min_p; g > 0) grid_min_p = g;  // tuning experiments
+  a.tune_cpb = tunables().cpb;
   if (!batch && P >= grid_min_p) {
     a.mode = pmx::MODE_GRID;
     a.n_ptiles = static_cast<int32_t>((P + 255) / 256);

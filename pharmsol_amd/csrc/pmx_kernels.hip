@@ -25,8 +25,6 @@
 
 #include <type_traits>
 
-#include <cstdlib>
-
 #include <cmath>
 #include <cstdint>
 
@@ -233,7 +231,8 @@ __global__ __launch_bounds__(kBlock, (!LAG && LaneModel<KID>::NS <= 2) ? 4 : ((!
     for (int k = 0; k < kMaxLagSlots; ++k) {
       ls.lag[k] = (k < m.n_lag_slots) ? th[m.lag_param[k]] : 0.0;
       ls.cur[k] = ls.end[k] = 0;
-      if (k < m.n_lag_slots && !(ls.lag[k] >= 0.0) && st_lane0 == PMX_PAIR_OK) st_lane0 = PMX_PAIR_BAD_LAG;
+      // a negative lag moves the bolus EARLIER, like the reference's `time += l` (structs.rs:629-634); NaN is flagged
+      if (k < m.n_lag_slots && ls.lag[k] != ls.lag[k] && st_lane0 == PMX_PAIR_OK) st_lane0 = PMX_PAIR_BAD_LAG;
     }
   }
   const uint8_t st_lane = st_lane0;
@@ -267,6 +266,8 @@ __global__ __launch_bounds__(kBlock, (!LAG && LaneModel<KID>::NS <= 2) ? 4 : ((!
     double xpad = 0.0;
     double ll_acc = 0.0;
     uint8_t st = st_lane;
+    uint8_t st_sticky = PMX_PAIR_OK;  // DYN: first failure of an EARLIER occasion (the reference errors out for the whole subject)
+    (void)st_sticky;
     // status bytes: no memset precedes the launch.  mode 1 (n_support % 8 == 0, aligned array): the wave clears this
     // subject's 64 bytes with 8 lanes x 8 bytes and only failures are written later; mode 2: every pair's byte is written.
     if (zero_status == 1 && status != nullptr) {
@@ -319,10 +320,16 @@ __global__ __launch_bounds__(kBlock, (!LAG && LaneModel<KID>::NS <= 2) ? 4 : ((!
 #pragma unroll
         for (int i = 0; i < NS; ++i) x[i] = io ? L.xinit[i] : 0.0;
         xpad = 0.0;
-        if constexpr (DYN) st = st_lane;  // a new occasion re-derives its coefficients
+        if constexpr (DYN) {  // a new occasion re-derives its coefficients: its rows are finite again, the pair stays failed
+          if (st_sticky == PMX_PAIR_OK) st_sticky = st;
+          st = st_lane;
+        }
         if constexpr (LAG)
           lag_open_occasion<LM::ST, NS>(m, ops, ls, static_cast<int64_t>(a), c_op_t0[o], L.coef, th, x);
       }
+    }
+    if constexpr (DYN) {
+      if (st_sticky != PMX_PAIR_OK) st = st_sticky;
     }
     if constexpr (LL) {
       if (st == PMX_PAIR_OK && !isfinite(ll_acc)) st = PMX_PAIR_NONFINITE;  // NonFiniteLikelihood (prediction.rs:119-124)
@@ -475,7 +482,7 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
   bool lane_badlag = false;
   if constexpr (LAGC) {
     lagv = theta[pc * m.nparams + m.lag_param[0]];
-    if (!(lagv >= 0.0)) {  // negative or NaN lag: PMX_PAIR_BAD_LAG, rows NaN (the generic walker's rule)
+    if (lagv != lagv) {  // NaN lag: PMX_PAIR_BAD_LAG, rows NaN (the generic walker's rule; a negative lag is a shift to earlier)
       lane_badlag = true;
       inv_vol0 = __longlong_as_double(0x7ff8000000000000LL);
     }
@@ -544,7 +551,10 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
       for (int i = 0; i < NS; ++i) x[j][i] = 0.0;
     uint32_t bad = 0;  // bit j: member j emitted a non-finite prediction
     uint32_t cplx = 0;  // DYNC: bit j: a rebuild of member j found complex eigenvalues in the current occasion
+    uint32_t cplx_any = 0, bad_any = 0;  // DYNC: ... in an earlier occasion (status is sticky, the rows are not)
     (void)cplx;
+    (void)cplx_any;
+    (void)bad_any;
     // the lane's exponentials outlive a step: bits 27-29 of a PROP step say how this step's length relates
     // to the previous PROP's (0 = unrelated: exp(); 1 = equal; n = 2..4: n times as long: ladder_pow)
     double ex[LM::S::NE];
@@ -642,7 +652,9 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
         for (int i = 0; i < NS; ++i) {
           double xi = 0.0;
           if (io && m.has_init && m.init_param[i + m.pm] >= 0) xi = th[m.init_param[i + m.pm]];
-          if constexpr (DYNC) {  // a new occasion re-derives its coefficients: what the last one flagged is forgotten
+          if constexpr (DYNC) {  // a new occasion re-derives its coefficients: its rows are finite again, but the pair
+            cplx_any |= cplx;    // stays failed (the reference errors out for the whole subject)
+            bad_any |= bad;
             cplx = 0;
             bad = 0;
           }
@@ -679,8 +691,16 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
         double inv_vol = inv_vol0;
         if (oq != 0) {  // outputs beyond the first: rare, re-derive the volume instead of keeping 4 live
           out_state = m.out[oq].state - m.pm;
-          const double v = (m.out[oq].vol_src == PMX_SRC_PRIMARY) ? th[m.out[oq].vol_index] : 1.0;
-          inv_vol = lane_good ? 1.0 / v : inv_vol0;
+          // (the volume may be a derived value WITHOUT covariate factors, which is still classed: its base parameter)
+          int vp = -1;
+          if (m.out[oq].vol_src == PMX_SRC_PRIMARY) vp = m.out[oq].vol_index;
+          if (m.out[oq].vol_src == PMX_SRC_DERIVED) {
+#pragma unroll
+            for (int dd = 0; dd < PMX_MAX_DERIVED; ++dd)
+              if (dd == m.out[oq].vol_index) vp = m.derived[dd].src_param;
+          }
+          const double v = (vp >= 0) ? th[vp] : 1.0;
+          inv_vol = (lane_good && !lane_badlag) ? 1.0 / v : __longlong_as_double(0x7ff8000000000000LL);
         }
         if constexpr (LL) {
           // fold the G predictions into the members' sums instead of storing them (ll_accumulate, per member;
@@ -729,6 +749,10 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
           kld += ld;
         }
       }
+    }
+    if constexpr (DYNC) {
+      cplx |= cplx_any;
+      bad |= bad_any;
     }
     if constexpr (LL) {
 #pragma unroll
@@ -784,7 +808,8 @@ __global__ __launch_bounds__(kBlock) void pmx_analytical_pair(DevModel m, DevOps
     for (int k = 0; k < kMaxLagSlots; ++k) {
       ls.lag[k] = (k < m.n_lag_slots) ? th[m.lag_param[k]] : 0.0;
       ls.cur[k] = ls.end[k] = 0;
-      if (k < m.n_lag_slots && !(ls.lag[k] >= 0.0) && st_lane0 == PMX_PAIR_OK) st_lane0 = PMX_PAIR_BAD_LAG;
+      // a negative lag moves the bolus EARLIER, like the reference's `time += l` (structs.rs:629-634); NaN is flagged
+      if (k < m.n_lag_slots && ls.lag[k] != ls.lag[k] && st_lane0 == PMX_PAIR_OK) st_lane0 = PMX_PAIR_BAD_LAG;
     }
   }
   const uint8_t st_lane = st_lane0;
@@ -799,6 +824,8 @@ __global__ __launch_bounds__(kBlock) void pmx_analytical_pair(DevModel m, DevOps
   double xpad = 0.0;
   double ll_acc = 0.0;
   uint8_t st = st_lane;
+  uint8_t st_sticky = PMX_PAIR_OK;  // DYN: first failure of an earlier occasion (see the GRID kernel)
+  (void)st_sticky;
   // exec-masked loop: runs while ANY lane of the wave still has ops (each lane exits at its own o1).  Every lane reads
   // its own op, so a fetch is a 64-line gather with nothing to hide its latency behind when the batch is a few
   // thousand pairs (C2: 157 waves on 1024 SIMDs); the ops come as packed 32-byte records (DevOps::op_rec), four
@@ -849,10 +876,16 @@ __global__ __launch_bounds__(kBlock) void pmx_analytical_pair(DevModel m, DevOps
 #pragma unroll
         for (int jj = 0; jj < NS; ++jj) x[jj] = io ? L.xinit[jj] : 0.0;
         xpad = 0.0;
-        if constexpr (DYN) st = st_lane;
+        if constexpr (DYN) {
+          if (st_sticky == PMX_PAIR_OK) st_sticky = st;
+          st = st_lane;
+        }
         if constexpr (LAG) lag_open_occasion<LM::ST, NS>(m, ops, ls, static_cast<int64_t>(a), q.w, L.coef, th, x);
       }
     }
+  }
+  if constexpr (DYN) {
+    if (st_sticky != PMX_PAIR_OK) st = st_sticky;
   }
   if constexpr (LL) {
     if (st == PMX_PAIR_OK && !isfinite(ll_acc)) st = PMX_PAIR_NONFINITE;
@@ -988,7 +1021,7 @@ hipError_t launch_analytical(const LaunchArgs& a, const char** name) {
           int64_t cpb = (n * a.n_ptiles) / (ll ? 8192 : 32768);
           if (cpb < 1) cpb = 1;
           if (cpb > 8) cpb = 8;
-          if (const char* e = std::getenv("PMX_TUNE_CPB")) cpb = std::atoi(e) > 0 ? std::atoi(e) : cpb;  // tuning experiments
+          if (a.tune_cpb > 0) cpb = a.tune_cpb;  // tuning experiments (PMX_TUNE_CPB, read once by pmx_api.cpp)
           *cpb_out = cpb;
           return ((n + cpb - 1) / cpb + 7) / 8 * 8;  // whole XCD groups
         };
@@ -1122,7 +1155,7 @@ __global__ __launch_bounds__(256) void pmx_ll_prepare_obs(LLPrepareArgs a) {
     q2 = 1.0 / (2.0 * sigma * sigma);
     q3 = (cz == 0) ? 0.0 : ((cz > 0 ? 1.0 : -1.0) / (sigma * 1.4142135623730951));
     if (bad) {  // NegativeSigma / NonFiniteSigma: the row (and so the subject's sum) becomes NaN
-      q1 = __longlong_as_double(0x7ff8000000000000LL);
+      q0 = q1 = __longlong_as_double(0x7ff8000000000000LL);  // (q0 too: the censored fold reads value and scale only)
       q2 = 1.0;
       atomicAdd(a.err, 1);
     }

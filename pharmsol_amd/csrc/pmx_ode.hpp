@@ -381,7 +381,7 @@ __device__ __forceinline__ void ode_grid_body(const DevModel& m, const DevOps& o
     for (int k = 0; k < kMaxLagSlots; ++k) {
       ls.lag[k] = (k < m.n_lag_slots) ? th[m.lag_param[k]] : 0.0;
       ls.cur[k] = ls.end[k] = 0;
-      if (k < m.n_lag_slots && !(ls.lag[k] >= 0.0)) {
+      if (k < m.n_lag_slots && ls.lag[k] != ls.lag[k]) {  // NaN; a negative lag shifts the bolus earlier (structs.rs:629-634)
         st_lane = PMX_PAIR_BAD_LAG;
         ls.lag[k] = 0.0;  // keep the walk finite; every output of this lane is NaN anyway
       }
@@ -483,7 +483,7 @@ __device__ __forceinline__ void ode_pair_body(const DevModel& m, const DevOps& o
     for (int k = 0; k < kMaxLagSlots; ++k) {
       ls.lag[k] = (k < m.n_lag_slots) ? th[m.lag_param[k]] : 0.0;
       ls.cur[k] = ls.end[k] = 0;
-      if (k < m.n_lag_slots && !(ls.lag[k] >= 0.0)) {
+      if (k < m.n_lag_slots && ls.lag[k] != ls.lag[k]) {  // NaN; a negative lag shifts the bolus earlier (structs.rs:629-634)
         st = PMX_PAIR_BAD_LAG;
         ls.lag[k] = 0.0;
       }

@@ -7,19 +7,21 @@ import pytest
 
 import oracle
 from pharmsol_amd import Analytical, AssayErrorModel, AssayErrorModels, Data, ErrorPoly, Ratio, Subject, _abi, runtime, synth
+from pharmsol_amd import bolus as bolus_route
 from tests import models
 from tests.test_gpu_fuzz import STRUCTS, kernel_theta
 
 pytestmark = pytest.mark.gpu
 
 
-def check(model, flat, theta, expect_kernel, loglik=False, tol=1e-6):
+def check(model, flat, theta, expect_kernel, loglik=False, tol=1e-6, em=None):
     import torch
 
     pop = runtime.DevicePopulation(flat, 0)
     dirty = torch.full((flat.n_subjects, theta.shape[0]), 177, dtype=torch.uint8, device="cuda")
     if loglik:
-        em = AssayErrorModels.empty().add(0, AssayErrorModel.additive(ErrorPoly(0.05, 0.1, 0.0, 0.0), 0.1))
+        if em is None:
+            em = AssayErrorModels.empty().add(0, AssayErrorModel.additive(ErrorPoly(0.05, 0.1, 0.0, 0.0), 0.1))
         got, st = runtime.loglik(model, pop, em, np.ascontiguousarray(theta), status=dirty)
         want, wst = oracle.loglik(model, flat, em, theta)
     else:
@@ -109,9 +111,16 @@ def test_exact_loose_and_unclassed_subjects_in_one_population(structure, loglik)
 
 
 def test_loose_classes_can_be_switched_off(monkeypatch):
+    from pharmsol_amd import _ffi
+
     monkeypatch.setenv("PMX_TUNE_LOOSE", "0")
-    model = synth.model_two_cpt_iv()
-    check(model, synth.population_c23(200, ragged=True), synth.theta_c3(64), "pmx_analytical_grid")
+    _ffi.lib().pmx_debug_reload_env()  # the switches are read once per process; this re-reads them
+    try:
+        model = synth.model_two_cpt_iv()
+        check(model, synth.population_c23(200, ragged=True), synth.theta_c3(64), "pmx_analytical_grid")
+    finally:
+        monkeypatch.delenv("PMX_TUNE_LOOSE")
+        _ffi.lib().pmx_debug_reload_env()
 
 
 @pytest.mark.parametrize("ragged", [False, True])
@@ -217,3 +226,75 @@ def test_censored_observations_in_loose_classes():
     theta = synth.theta_c3(72)
     flat = _censor_some(observed(model, flat, theta[:1], rng), rng)
     assert_ll_parity(model, flat, EM_ADD, theta, expect_kernel="pmx_analytical_classed<ll,loose>")
+
+
+# --------------------------------------------------------------------------- more than one output equation
+def _two_output_subjects(rng, kind, n):
+    """Observations alternate between output 0 (central / v) and output 1 (peripheral / v2)."""
+    subs = []
+    if kind == "exact":
+        for i in range(n):
+            b = Subject.builder(f"x{i}").infusion(0.0, 300.0 + i, 0, 0.5).bolus(6.0, 40.0 + i, 0)
+            for k, t in enumerate((0.5, 1.0, 2.0, 6.0, 6.0, 8.0, 12.0)):
+                b = b.missing_observation(t, k % 2)
+            subs.append(b.build())
+    else:
+        for i in range(n):
+            b = Subject.builder(f"l{i}").infusion(0.0, 300.0 + i, 0, 0.5 + 0.5 * rng.random())
+            for k, t in enumerate(np.sort(rng.uniform(0.6, 30.0, 6))):
+                b = b.missing_observation(float(t), k % 2)
+            subs.append(b.build())
+    return subs
+
+
+@pytest.mark.parametrize("kind", ["exact", "loose"])
+@pytest.mark.parametrize("loglik", [False, True])
+def test_two_output_equations_in_classed_kernels(kind, loglik):
+    """nout = 2: the classed kernels re-derive the volume of outputs beyond the first (the fused 2-bit outeq of a
+    program step); volumes are a primary parameter and a derived value WITHOUT covariate factors (still classed:
+    its base parameter is the volume, like lane_setup / the oracle's model_out)."""
+    from pharmsol_amd import Scaled, analytical, infusion as inf_route
+
+    rng = np.random.default_rng(31)
+    m = analytical(name="two_out", params=["ke", "kcp", "kpc", "v", "v2raw"], derived={"v2": Scaled("v2raw", ())},
+                   structure="two_compartments", states=["central", "peripheral"], outputs=["0", "1"],
+                   routes=[inf_route("0", "central"), bolus_route("0", "central")],
+                   out={"0": Ratio("central", "v"), "1": Ratio("peripheral", "v2")})
+    subs = _two_output_subjects(rng, kind, 43)
+    flat = m.flatten(Data(subs))
+    theta = np.concatenate([synth.theta_c3(72), rng.uniform(5, 40, (72, 1))], axis=1)
+    if loglik:
+        flat = with_observed_values(flat, m, theta, 9)
+        em = (AssayErrorModels.empty().add(0, AssayErrorModel.additive(ErrorPoly(0.05, 0.1, 0.0, 0.0), 0.1))
+              .add(1, AssayErrorModel.proportional(ErrorPoly(0.1, 0.05, 0.0, 0.0), 0.5)))
+        check(m, flat, theta, "pmx_analytical_classed", loglik, em=em)
+    else:
+        check(m, flat, theta, "pmx_analytical_classed", loglik)
+
+
+def test_two_output_equations_in_a_lag_class_with_a_bad_lane():
+    """LAGC variant + nout = 2: a NaN-lag lane must come back NaN on BOTH outputs (the secondary volume used to be
+    recomputed without the lane's poison)."""
+    import torch
+
+    m = Analytical.new("one_compartment_with_absorption", {0: Ratio(1, 2), 1: Ratio(0, 3)}, nparams=5, lag={0: 4})
+    m = m.with_nstates(2).with_ndrugs(1).with_nout(2)
+    subs = []
+    for i in range(40):
+        b = Subject.builder(f"g{i}").bolus(0.0, 100.0 + i, 0).bolus(12.0, 50.0, 0)
+        for k, t in enumerate((0.5, 1.0, 2.0, 4.0, 12.0, 13.0, 16.0)):
+            b = b.missing_observation(t, k % 2)
+        subs.append(b.build())
+    flat = m.flatten(Data(subs))
+    rng = np.random.default_rng(33)
+    n = 64
+    th = np.stack([rng.uniform(1.0, 2.0, n), rng.uniform(0.05, 0.3, n), rng.uniform(10, 50, n), rng.uniform(1, 3, n),
+                   np.round(rng.uniform(-1, 3, n) * 2) / 2], axis=1)
+    check(m, flat, th, "pmx_analytical_classed<lag>")
+    th[11, 4] = np.nan
+    pop = runtime.DevicePopulation(flat, 0)
+    got, st = runtime.predict(m, pop, th)
+    torch.cuda.synchronize()
+    got, st = got.cpu().numpy(), st.cpu().numpy()
+    assert np.isnan(got[:, 11]).all() and (st[:, 11] == _abi.PMX_PAIR_BAD_LAG).all()
+    assert np.isfinite(np.delete(got, 11, axis=1)).all() and (np.delete(st, 11, axis=1) == 0).all()

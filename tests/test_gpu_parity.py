@@ -372,19 +372,41 @@ def test_ode_two_lagged_inputs_and_negative_lag():
     flat = m.flatten(Data(_lag_subjects(rng, 30, two_inputs=True)))
     th = np.concatenate([synth.theta_c3(64), rng.uniform(0, 2.5, (64, 2))], axis=1)
     assert_parity(m, flat, th, TOL_ODE, expect_kernel="pmx_ode_rk4_grid<lag>")
+    # a negative lag moves the bolus earlier (`if l != 0.0 { time += l }`, structs.rs:629-634): device == oracle
     th[5, 4] = -1.0
+    th[9, 5] = -2.5
+    assert_parity(m, flat, th, TOL_ODE, expect_kernel="pmx_ode_rk4_grid<lag>")
+    assert_parity(m, flat, th[:12], TOL_ODE, expect_kernel="pmx_ode_rk4_pair<lag>")
+    th[5, 4] = np.nan  # the reference panics in its sort; the device flags the pair
     got, st = gpu_predict(m, flat, th)
     assert (st[:, 5] == _abi.PMX_PAIR_BAD_LAG).all() and np.isnan(got[:, 5]).all()
     assert (np.delete(st, 5, axis=1) == 0).all()
 
 
-def test_negative_lag_is_flagged():
+@pytest.mark.parametrize("n_support", [40, 8])
+def test_negative_lag_shifts_the_bolus_earlier_like_the_reference(n_support):
+    """structs.rs:629-634: `if l != 0.0 { *bolus.mut_time() += l }` has no sign check - a negative lag is a shift to an
+    earlier time, possibly before the occasion's first event or before another dose.  Device == oracle on the generic
+    walker, on an exact class (shared design: LAGC kernel) and on the PAIR kernel; only NaN is flagged."""
     m = Analytical.new("one_compartment", {0: Ratio(0, 1)}, nparams=3, lag={0: 2}).with_nstates(1).with_ndrugs(1).with_nout(1)
-    s = Subject.builder("neg").bolus(1.0, 10.0, 0).missing_observation(2.0, 0).build()
-    th = np.array([[0.1, 5.0, 0.5]] * 40)
-    th[7, 2] = -0.25
+    s = Subject.builder("neg").bolus(1.0, 10.0, 0).missing_observation(0.9, 0).missing_observation(2.0, 0).build()
+    th = np.array([[0.1, 5.0, 0.5]] * n_support)
+    th[7, 2] = -0.25   # lands at 0.75: before the first observation of the list
+    th[3, 2] = -4.0    # lands at -3: before time zero
+    got, want = assert_parity(m, m.flatten(s), th, TOL_ANALYTICAL)
+    assert got[0, 7] > 0 and got[0, 0] == 0.0  # the observation at 0.9 sees the early bolus, and only that lane
+    rng = np.random.default_rng(93)
+    subs = _lag_subjects(rng, 40)
+    th2 = np.stack([rng.uniform(0.05, 0.3, n_support), rng.uniform(10, 50, n_support),
+                    np.round(rng.uniform(-3, 3, n_support) * 2) / 2], axis=1)
+    assert_parity(m, m.flatten(Data(subs)), th2, TOL_ANALYTICAL)
+    shared = [Subject.builder(f"c{i}").bolus(2.0, 10.0 + i, 0).missing_observation(1.0, 0).bolus(6.0, 5.0, 0)
+              .missing_observation(4.0, 0).missing_observation(8.0, 0).build() for i in range(33)]
+    assert_parity(m, m.flatten(Data(shared)), th2, TOL_ANALYTICAL,
+                  expect_kernel="pmx_analytical_classed<lag>" if n_support >= 32 else "pmx_analytical_pair<lag>")
+    th[7, 2] = np.nan
     got, st = gpu_predict(m, m.flatten(s), th)
-    assert st[0, 7] == _abi.PMX_PAIR_BAD_LAG and np.isnan(got[0, 7])
+    assert st[0, 7] == _abi.PMX_PAIR_BAD_LAG and np.isnan(got[:, 7]).all()
     assert (np.delete(st, 7, axis=1) == 0).all() and np.isfinite(np.delete(got, 7, axis=1)).all()
 
 
@@ -688,3 +710,47 @@ def test_placed_prediction_buffer():
     del pred, out
     gc.collect()
     assert free0 - torch.cuda.mem_get_info()[0] < (8 << 20)
+
+
+@pytest.mark.parametrize("structure,n_support", [("two_compartments", 70), ("two_compartments", 9),
+                                                  ("three_compartments", 70)])
+def test_a_failed_first_occasion_keeps_the_pair_failed(structure, n_support):
+    """Covariate-derived rate constants are rebuilt per segment, so complex eigenvalues belong to an OCCASION: the next
+    occasion's rows are finite again, but the pair stays PMX_PAIR_COMPLEX_ROOTS (the reference panics for the whole
+    subject; the oracle keeps its status sticky).  Generic walker (3 states), classed<dyn> (2 states), PAIR."""
+    from pharmsol_amd import Lin
+
+    two = structure == "two_compartments"
+    params = ["ke", "kcp0", "kpc", "v"] if two else ["k10", "k120", "k13", "k21", "k31", "v"]
+    dname, src = ("kcp", "kcp0") if two else ("k12", "k120")
+    m = analytical(name="sticky", params=params, derived={dname: Scaled(src, (Lin("wt", 70.0, 0.1),))}, covariates=["wt"],
+                   structure=structure, states=["central", "periph"] if two else ["central", "p1", "p2"], outputs=["cp"],
+                   routes=[bolus("dose", "central")], out={"cp": Ratio("central", "v")})
+    subs = []
+    for i in range(24):
+        # occasion 0: wt = 40 -> factor 1 + 0.1 (40 - 70) = -2: a negative transfer constant, complex roots for some
+        # support points; occasion 1: wt = 70 -> factor 1
+        b = Subject.builder(f"s{i}").covariate("wt", 0.0, 40.0 if i % 2 == 0 else 70.0).bolus(0.0, 100.0 + i, "dose")
+        for t in (1.0, 2.0 + 0.01 * i, 6.0):
+            b = b.missing_observation(t, "cp")
+        b = b.reset().covariate("wt", 0.0, 70.0).bolus(0.0, 50.0, "dose").missing_observation(1.0, "cp").missing_observation(3.0, "cp")
+        subs.append(b.build())
+    flat = m.flatten(Data(subs))
+    rng = np.random.default_rng(12)
+    if two:
+        th = np.stack([rng.uniform(0.5, 1.5, n_support), rng.uniform(0.5, 1.0, n_support), rng.uniform(0.5, 1.5, n_support),
+                       rng.uniform(10, 50, n_support)], axis=1)
+    else:
+        th = np.concatenate([synth.theta_c5(n_support)[:, 1:6], rng.uniform(10, 50, (n_support, 1))], axis=1)
+        th[:, 1] = rng.uniform(0.5, 1.0, n_support)
+    got, want = assert_parity(m, flat, th, TOL_ANALYTICAL)
+    _, wst = oracle.predict(m, flat, th)
+    failed = wst == _abi.PMX_PAIR_COMPLEX_ROOTS
+    assert failed.any() and not failed.all()
+    off = flat.subj_obs_off if hasattr(flat, "subj_obs_off") else None
+    # rows of the second occasion of a failed pair are finite (statuses were compared by assert_parity)
+    rows_per = 5
+    for s_i in range(0, 24, 2):
+        for p_i in np.nonzero(failed[s_i])[0][:3]:
+            blk = got[s_i * rows_per:(s_i + 1) * rows_per, p_i]
+            assert np.isnan(blk[:3]).any() and np.isfinite(blk[3:]).all()

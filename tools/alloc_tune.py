@@ -3,7 +3,7 @@ and spread chunk membership.  (The store-pattern probe shows two speeds of the s
 on the allocation; this is the real kernel.)"""
 import os, sys
 import numpy as np, torch
-from pharmsol_amd import runtime, synth
+from pharmsol_amd import _ffi, runtime, synth
 
 S, P = 100_000, 1000
 m, flat, theta = synth.config_c3(S, P)
@@ -11,6 +11,7 @@ d_theta = torch.as_tensor(theta, device="cuda")
 pops = {}
 for sp in (0, 1):
     os.environ["PMX_TUNE_SPREAD"] = str(sp)
+    _ffi.lib().pmx_debug_reload_env()  # (the library reads its switches once per process)
     pops[sp] = runtime.DevicePopulation(flat, 0)
     tmp = torch.empty((pops[sp].n_observations, 8), dtype=torch.float64, device="cuda")
     runtime.predict(m, pops[sp], d_theta[:8].contiguous(), pred=tmp)  # builds the class plan under this setting

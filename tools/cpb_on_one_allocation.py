@@ -2,7 +2,7 @@
 the sweep must not reallocate)."""
 import os
 import numpy as np, torch
-from pharmsol_amd import runtime, synth
+from pharmsol_amd import _ffi, runtime, synth
 m, flat, theta = synth.config_c3(100_000, 1000)
 pop = runtime.DevicePopulation(flat, 0)
 d_theta = torch.as_tensor(theta, device="cuda")
@@ -18,4 +18,5 @@ def t(n=10):
 for rep in range(2):
     for cpb in (1, 2, 3, 4, 6, 8, 12, 16, 24, 48):
         os.environ["PMX_TUNE_CPB"] = str(cpb)
+        _ffi.lib().pmx_debug_reload_env()  # (the library reads its switches once per process)
         print(f"rep{rep} cpb={cpb:3d}  {t():.4f} ms")
