@@ -112,7 +112,7 @@ def build_case(seed):
     n = len(subs) if batch else n_support
     th = [kernel_theta(name, n, rng), rng.uniform(10, 80, (n, 1))]
     if use_lag:
-        th.append(np.round(rng.uniform(0, 3, (n, 1)) * 2) / 2)
+        th.append(np.round(rng.uniform(-1, 3, (n, 1)) * 2) / 2)  # (negative: the bolus moves earlier, structs.rs:629-634)
     if use_fa:
         th.append(rng.uniform(0.3, 1.0, (n, 1)))
     if use_init:
@@ -205,7 +205,7 @@ def test_random_ode_configuration(seed):
                5: synth.theta_c5(n)[:, 1:6], 6: synth.theta_c5(n)[:, :6]}[nk]
         th = [src, rng.uniform(10, 80, (n, 1))]
     if use_lag:
-        th.append(np.round(rng.uniform(0, 3, (n, 1)) * 2) / 2)
+        th.append(np.round(rng.uniform(-1, 3, (n, 1)) * 2) / 2)  # (negative: the bolus moves earlier, structs.rs:629-634)
     if use_fa:
         th.append(rng.uniform(0.3, 1.0, (n, 1)))
     theta = np.concatenate(th, axis=1)
