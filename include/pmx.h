@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PMX_ABI_VERSION 2
+#define PMX_ABI_VERSION 3
 
 /* ---- limits (fixed-size descriptor arrays) ------------------------------- */
 #define PMX_MAX_STATES 8
@@ -37,6 +37,7 @@ extern "C" {
 #define PMX_MAX_OUT 4
 #define PMX_MAX_KPARAMS 8
 #define PMX_MAX_DERIVED 4
+#define PMX_MAX_USER_DERIVED 16 /* values a user `pmx_derive` may write (pmx_model_create_user) */
 #define PMX_MAX_FACTORS 2
 #define PMX_MAX_PARAMS 16
 #define PMX_MAX_COVARIATES 8
@@ -126,7 +127,8 @@ enum {
   PMX_K_THREE_COMPARTMENTS_CL = 9,                  /* p = [cl,q2,q3,vc,v2,v3]        three_compartment_cl_models.rs:16-31 */
   PMX_K_THREE_COMPARTMENTS_CL_WITH_ABSORPTION = 10, /* p = [ka,cl,q2,q3,vc,v2,v3]     three_compartment_cl_models.rs:46-67 */
   PMX_K_THREE_COMPARTMENTS_WITH_ABSORPTION = 11,    /* p = [ka,k10,k12,k13,k21,k31]   three_compartment_models.rs:126-240 */
-  PMX_K_ANALYTICAL_COUNT = 12
+  PMX_K_ANALYTICAL_COUNT = 12,
+  PMX_K_CUSTOM = 100                                /* the user's own propagator `pmx_eq` (pmx_model_create_user) */
 };
 
 /* Built-in `diffeq` bodies for the ODE back-end (device functor registry; the
@@ -357,6 +359,51 @@ typedef struct pmx_error_model {
  * pmx_last_error() on a compile error) and runs through the same walkers, RK4 stepper, lag/fa handling and fused
  * log-likelihood as the built-in bodies. */
 int32_t pmx_model_create_custom(const pmx_model_desc* desc, const char* source, int32_t has_init, pmx_model** out);
+
+/* ---- user closures for either back-end --------------------------------------------------------------------------
+ * `Analytical::new(eq, seq_eq, lag, fa, init, out)` and `ODE::new(diffeq, lag, fa, init, out)` take arbitrary
+ * functions of (theta, t, covariates) (src/simulator/mod.rs:41-197; analytical/mod.rs:102-118; ode/mod.rs:115-132).
+ * `source` defines the ones named in `functions` (PMX_FN_* bits), all with the argument order of the reference's
+ * compiled kernels (src/dsl/native.rs:45-53; symbol roles src/dsl/compiled_backend_abi.rs:13-27):
+ *
+ *   PMX_DEVICE void pmx_<role>(double t, const double* x, const double* p, const double* cov,
+ *                              const double* rateiv, const double* derived, double* out);
+ *
+ *   role                     t                        out (pre-set)                    reference closure
+ *   derive                   see below                derived[n_derived] (zeros)       `derive:` block of analytical!/ode!
+ *   route_lag                the bolus' recorded time lag[ndrugs] (zeros)              Lag,  structs.rs:611-643
+ *   route_bioavailability    its time AFTER the lag   fa[ndrugs] (ones)                Fa,   structs.rs:645-666
+ *   init                     0.0                      x[nstates] (zeros)               Init, analytical/mod.rs:409-426
+ *   outputs                  the observation time     y[nout] (zeros)                  Out,  analytical/mod.rs:373-407
+ *   seq_eq  (analytical)     the sub-segment's end    the solve's parameter vector,    SecEq, analytical/mod.rs:331,360
+ *                                                     modified in place (p = theta)
+ *   eq      (analytical,     the sub-segment LENGTH   x_next[nstates] (copy of x)      AnalyticalEq, analytical/mod.rs:363-364
+ *            kernel = PMX_K_CUSTOM)                   p = the solve's vector, rateiv[ndrugs]
+ *   dynamics (ODE)           stage time               dx[nstates] (zeros)              DiffEq
+ *
+ * `cov[c]` = covariate c of the subject's current occasion interpolated AT THAT t on the device (fetch_cov!(cov, t, ..));
+ * `derived` = pmx_derive evaluated at the same t first, the way every macro-lowered closure starts
+ * (pharmsol-macros/src/expand/analytical.rs:333-420), NULL without PMX_FN_DERIVE; pointers that have no meaning for a
+ * role are NULL.  Analytical models: `kernel` is a built-in structure (its parameters bound through desc->bind[] to
+ * theta / derived values; its derive runs at the segment length dt or, PMX_COV_TIME_SEGMENT_END_ABS, at the absolute
+ * segment end) or PMX_K_CUSTOM + PMX_FN_EQ.  A closure left out of `functions` falls back to the descriptor's closed
+ * form (lag_param / fa_param / init_param / out[]); desc->derived[] is ignored, n_derived <= PMX_MAX_USER_DERIVED.
+ * ODE models: PMX_FN_DYNAMICS | PMX_FN_OUTPUTS (| PMX_FN_INIT) == pmx_model_create_custom.
+ * The reference fixture tests/analytical_macro_lowering.rs:225-260 (covariate-dependent lag, clamped fa, init and
+ * volume) is written this way in tests/test_user_analytical.py. */
+enum {
+  PMX_FN_DYNAMICS = 1,
+  PMX_FN_OUTPUTS = 2,
+  PMX_FN_INIT = 4,
+  PMX_FN_DERIVE = 8,
+  PMX_FN_ROUTE_LAG = 16,
+  PMX_FN_ROUTE_BIOAVAILABILITY = 32,
+  PMX_FN_SEQ_EQ = 64,
+  PMX_FN_EQ = 128
+};
+int32_t pmx_model_create_user(const pmx_model_desc* desc, const char* source, uint32_t functions, pmx_model** out);
+/* The translation unit handed to hiprtc for such a model; free with pmx_free_text. */
+int32_t pmx_debug_jit_source_user(const pmx_model_desc* desc, const char* source, uint32_t functions, char** out_text);
 /* The translation unit that was (or would be) handed to hiprtc for this source; free with pmx_free_text. */
 int32_t pmx_debug_jit_source(const pmx_model_desc* desc, const char* source, int32_t has_init, char** out_text);
 void pmx_free_text(char* text);

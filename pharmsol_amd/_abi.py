@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-PMX_ABI_VERSION = 2
+PMX_ABI_VERSION = 3
 PMX_CENSOR_NONE, PMX_CENSOR_BLOQ, PMX_CENSOR_ALOQ = 0, 1, -1
 
 PMX_MAX_STATES = 8

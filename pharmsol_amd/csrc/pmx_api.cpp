@@ -130,6 +130,7 @@ struct DeviceStream {
   std::vector<void*> allocs;
   int32_t max_input_used = -1;
   int64_t n_ops = 0, n_prop = 0;
+  int64_t max_lagb_per_list = 0;
   ~DeviceStream() {
     for (void* p : allocs) (void)hipFree(p);
     for (auto& c : ll_cache)
@@ -185,6 +186,8 @@ struct pmx_model {
   bool has_init = false;
   // custom (hiprtc) models: the code object and its per-device modules
   bool custom = false;
+  uint32_t user_fns = 0;  // PMX_FN_* the user's source defines (pmx_model_create_user)
+  bool user_lag = false, user_eq = false;  // analytical user model: any lag closure (user's or descriptor's) / own propagator
   std::vector<char> jit_code;
   mutable std::mutex jit_mu;
   mutable std::map<int, pmx::JitModule> jit_modules;
@@ -266,6 +269,8 @@ int32_t pmx_model_create(const pmx_model_desc* d, pmx_model** out) {
   *out = nullptr;
   if (d->eq_kind == PMX_EQ_ODE && d->kernel == PMX_ODE_CUSTOM)
     return fail(PMX_ERR_INVALID_ARGUMENT, "PMX_ODE_CUSTOM models are created with pmx_model_create_custom");
+  if (d->eq_kind == PMX_EQ_ANALYTICAL && d->kernel == PMX_K_CUSTOM)
+    return fail(PMX_ERR_INVALID_ARGUMENT, "PMX_K_CUSTOM models are created with pmx_model_create_user");
   if (d->nstates < 1 || d->nstates > PMX_MAX_STATES) return fail(PMX_ERR_INVALID_ARGUMENT, "nstates out of range");
   if (d->ndrugs < 0 || d->ndrugs > PMX_MAX_INPUTS) return fail(PMX_ERR_INVALID_ARGUMENT, "ndrugs out of range");
   if (d->nout < 1 || d->nout > PMX_MAX_OUT) return fail(PMX_ERR_INVALID_ARGUMENT, "nout out of range");
@@ -430,6 +435,110 @@ int32_t pmx_debug_jit_source(const pmx_model_desc* d, const char* source, int32_
 
 void pmx_free_text(char* text) { std::free(text); }
 
+}  // extern "C"
+
+namespace {
+// Analytical model with user closures: what of the descriptor must hold (pmx.h "user closures for either back-end")
+int32_t check_user_analytical(const pmx_model_desc* d, const char* source, uint32_t fns) {
+  if (!d || !source) return fail(PMX_ERR_INVALID_ARGUMENT, "null argument");
+  if (d->nstates < 1 || d->nstates > PMX_MAX_STATES) return fail(PMX_ERR_INVALID_ARGUMENT, "nstates out of range");
+  if (d->ndrugs < 1 || d->ndrugs > PMX_MAX_INPUTS) return fail(PMX_ERR_INVALID_ARGUMENT, "ndrugs out of range (1..8 for a model with user closures)");
+  if (d->nout < 1 || d->nout > PMX_MAX_OUT) return fail(PMX_ERR_INVALID_ARGUMENT, "nout out of range");
+  if (d->nparams < 1 || d->nparams > PMX_MAX_PARAMS) return fail(PMX_ERR_INVALID_ARGUMENT, "nparams out of range");
+  if (d->n_covariates < 0 || d->n_covariates > PMX_MAX_COVARIATES) return fail(PMX_ERR_INVALID_ARGUMENT, "n_covariates out of range");
+  if (d->n_derived < 0 || d->n_derived > PMX_MAX_USER_DERIVED) return fail(PMX_ERR_INVALID_ARGUMENT, "n_derived out of range");
+  if (d->n_derived > 0 && !(fns & PMX_FN_DERIVE)) return fail(PMX_ERR_INVALID_ARGUMENT, "n_derived > 0 needs PMX_FN_DERIVE (desc.derived[] is not read for user models)");
+  if (d->pmetrics_indexing) return fail(PMX_ERR_UNSUPPORTED, "pm_* indexing together with user closures is not supported");
+  if (fns & PMX_FN_DYNAMICS) return fail(PMX_ERR_INVALID_ARGUMENT, "PMX_FN_DYNAMICS belongs to ODE models");
+  if (d->kernel == PMX_K_CUSTOM) {
+    if (!(fns & PMX_FN_EQ)) return fail(PMX_ERR_INVALID_ARGUMENT, "kernel = PMX_K_CUSTOM needs PMX_FN_EQ");
+  } else {
+    if (fns & PMX_FN_EQ) return fail(PMX_ERR_INVALID_ARGUMENT, "PMX_FN_EQ needs kernel = PMX_K_CUSTOM");
+    if (d->kernel < 0 || d->kernel >= PMX_K_ANALYTICAL_COUNT) return fail(PMX_ERR_INVALID_ARGUMENT, "unknown analytical kernel");
+    static const int kNS[12] = {1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4};
+    if (d->nstates < kNS[d->kernel]) return fail(PMX_ERR_INVALID_ARGUMENT, "model has fewer states than its structure");
+    const int np = pmx::kernel_nparams(d->kernel);
+    if (d->n_bind == 0 && d->nparams < np) return fail(PMX_ERR_INVALID_ARGUMENT, "too few parameters for the structure");
+    if (d->n_bind != 0 && d->n_bind != np) return fail(PMX_ERR_INVALID_ARGUMENT, "n_bind must equal the structure's parameter count");
+    for (int j = 0; j < d->n_bind; ++j) {
+      const pmx_bind& b = d->bind[j];
+      if (b.src == PMX_SRC_PRIMARY ? (b.index < 0 || b.index >= d->nparams)
+                                   : (b.src != PMX_SRC_DERIVED || b.index < 0 || b.index >= d->n_derived))
+        return fail(PMX_ERR_INVALID_ARGUMENT, "bind entry out of range");
+    }
+  }
+  for (int i = 0; i < PMX_MAX_INPUTS; ++i)
+    if (d->lag_param[i] >= d->nparams || d->fa_param[i] >= d->nparams)
+      return fail(PMX_ERR_INVALID_ARGUMENT, "lag_param / fa_param out of range");
+  for (int i = 0; i < PMX_MAX_STATES; ++i)
+    if (d->init_param[i] >= d->nparams) return fail(PMX_ERR_INVALID_ARGUMENT, "init_param out of range");
+  if (!(fns & PMX_FN_OUTPUTS))
+    for (int o = 0; o < d->nout; ++o) {
+      const pmx_out& oo = d->out[o];
+      if (oo.state < 0 || oo.state >= d->nstates) return fail(PMX_ERR_INVALID_ARGUMENT, "out.state out of range");
+      if (oo.vol_src == PMX_SRC_PRIMARY && (oo.vol_index < 0 || oo.vol_index >= d->nparams))
+        return fail(PMX_ERR_INVALID_ARGUMENT, "out.vol_index out of range");
+      if (oo.vol_src == PMX_SRC_DERIVED && (oo.vol_index < 0 || oo.vol_index >= d->n_derived))
+        return fail(PMX_ERR_INVALID_ARGUMENT, "out.vol_index (derived) out of range");
+    }
+  return PMX_OK;
+}
+pmx::JitSpec user_spec_of(const pmx_model_desc* d, const char* source, uint32_t fns) {
+  pmx::JitSpec sp;
+  sp.analytical = true;
+  sp.fns = fns;
+  sp.desc = *d;
+  sp.source = source;
+  return sp;
+}
+}  // namespace
+
+extern "C" {
+
+int32_t pmx_model_create_user(const pmx_model_desc* d, const char* source, uint32_t functions, pmx_model** out) {
+  g_err.clear();
+  if (!out) return fail(PMX_ERR_INVALID_ARGUMENT, "out is null");
+  *out = nullptr;
+  if (!d) return fail(PMX_ERR_INVALID_ARGUMENT, "null argument");
+  if (d->eq_kind == PMX_EQ_ODE) {
+    if ((functions & ~static_cast<uint32_t>(PMX_FN_INIT)) != (PMX_FN_DYNAMICS | PMX_FN_OUTPUTS))
+      return fail(PMX_ERR_UNSUPPORTED, "ODE models take PMX_FN_DYNAMICS | PMX_FN_OUTPUTS (| PMX_FN_INIT); lag / fa are theta-indexed (lag_param / fa_param)");
+    return pmx_model_create_custom(d, source, (functions & PMX_FN_INIT) ? 1 : 0, out);
+  }
+  if (d->eq_kind != PMX_EQ_ANALYTICAL) return fail(PMX_ERR_INVALID_ARGUMENT, "unknown eq_kind");
+  const int32_t rc = check_user_analytical(d, source, functions);
+  if (rc != PMX_OK) return rc;
+  auto m = std::make_unique<pmx_model>();
+  m->d = *d;
+  m->custom = true;
+  m->user_fns = functions;
+  m->user_eq = d->kernel == PMX_K_CUSTOM;
+  m->user_lag = (functions & PMX_FN_ROUTE_LAG) != 0;
+  for (int i = 0; i < PMX_MAX_INPUTS; ++i) m->user_lag |= d->lag_param[i] >= 0;
+  m->has_init = true;  // (RESET ops always carry the occasion-index flag; the policy's init may be empty)
+  std::string log;
+  if (!pmx::jit_compile(user_spec_of(d, source, functions), &m->jit_code, &log))
+    return fail(PMX_ERR_INVALID_ARGUMENT, "hiprtc could not compile the model source:\n" + log);
+  *out = m.release();
+  return PMX_OK;
+}
+
+int32_t pmx_debug_jit_source_user(const pmx_model_desc* d, const char* source, uint32_t functions, char** out_text) {
+  g_err.clear();
+  if (!out_text) return fail(PMX_ERR_INVALID_ARGUMENT, "out_text is null");
+  *out_text = nullptr;
+  if (!d) return fail(PMX_ERR_INVALID_ARGUMENT, "null argument");
+  if (d->eq_kind == PMX_EQ_ODE) return pmx_debug_jit_source(d, source, (functions & PMX_FN_INIT) ? 1 : 0, out_text);
+  const int32_t rc = check_user_analytical(d, source, functions);
+  if (rc != PMX_OK) return rc;
+  const std::string tu = pmx::jit_translation_unit(user_spec_of(d, source, functions));
+  char* buf = static_cast<char*>(std::malloc(tu.size() + 1));
+  if (!buf) return fail(PMX_ERR_OUT_OF_MEMORY, "malloc");
+  std::memcpy(buf, tu.c_str(), tu.size() + 1);
+  *out_text = buf;
+  return PMX_OK;
+}
+
 void pmx_model_destroy(pmx_model* m) { delete m; }
 
 }  // extern "C"
@@ -439,7 +548,23 @@ namespace {
 pmx::CompileKey key_for(const pmx_model* m) {
   pmx::CompileKey k;
   k.eq_kind = m->d.eq_kind;
-  if (m->d.eq_kind == PMX_EQ_ANALYTICAL) {
+  if (m->d.eq_kind == PMX_EQ_ANALYTICAL && m->custom) {
+    // user closures (pmx_analytical.hpp): covariates are looked up on the device, so the stream carries no factors;
+    // absolute times on every PROP, solve marks for seq_eq, every input's rate for a user propagator, and - when the
+    // model has any lag closure - ALL boluses leave the stream into one list per occasion that each lane sorts itself
+    k.cov_time_mode = PMX_COV_TIME_SEGMENT_DT;  // (unused: no host-side covariate evaluation)
+    k.rk4_h_max = 0.0;
+    k.rate_input = 0;
+    k.full_rates = m->user_eq;
+    k.n_rate = m->user_eq ? (m->d.ndrugs > 0 ? m->d.ndrugs : 1) : 1;
+    k.want_times = true;
+    k.solve_marks = true;
+    k.user_cov = true;
+    if (m->user_lag) {
+      k.lag_merge = true;
+      for (int i = 0; i < m->d.ndrugs && i < PMX_MAX_INPUTS; ++i) k.lag_mask |= (1u << i);
+    }
+  } else if (m->d.eq_kind == PMX_EQ_ANALYTICAL) {
     k.cov_time_mode = m->d.cov_time_mode;
     k.rk4_h_max = 0.0;
     k.n_rate = 1;
@@ -539,9 +664,11 @@ int32_t get_stream(pmx_population* pop, const pmx::CompileKey& key, DeviceStream
   if ((rc = upload(os.lagb_off, &ds->dev.lagb_off, &ds->allocs)) != PMX_OK) return rc;
   if ((rc = upload(os.lagb_time, &ds->dev.lagb_time, &ds->allocs)) != PMX_OK) return rc;
   if ((rc = upload(os.lagb_amount, &ds->dev.lagb_amount, &ds->allocs)) != PMX_OK) return rc;
+  if (key.lag_merge && (rc = upload(os.lagb_input, &ds->dev.lagb_input, &ds->allocs)) != PMX_OK) return rc;
+  ds->max_lagb_per_list = os.max_lagb_per_list;
   ds->dev.n_rate = key.n_rate;
   ds->dev.n_cov = 0;
-  if (key.eq_kind == PMX_EQ_ODE && pop->hp.n_cov > 0) {  // covariate segments for bodies that read them at stage times
+  if ((key.eq_kind == PMX_EQ_ODE || key.user_cov) && pop->hp.n_cov > 0) {  // covariate segments for bodies that read them on the device
     const auto& hp = pop->hp;
     ds->dev.n_cov = hp.n_cov;
     if ((rc = upload(hp.cov_seg_off, &ds->dev.cov_seg_off, &ds->allocs)) != PMX_OK) return rc;
@@ -733,6 +860,9 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
   if (pop->hp.max_outeq >= d.nout)
     return fail(PMX_ERR_OUTEQ_OUT_OF_RANGE,
                 "outeq " + std::to_string(pop->hp.max_outeq) + " >= nout " + std::to_string(d.nout));
+  if (model->custom && d.eq_kind == PMX_EQ_ANALYTICAL && ds->max_lagb_per_list > 64)  // pmx_analytical.hpp kUserMaxLagPerOccasion
+    return fail(PMX_ERR_UNSUPPORTED, "an occasion holds " + std::to_string(ds->max_lagb_per_list) +
+                                         " boluses; a model with a lag closure sorts at most 64 per occasion on the device");
   if (pop->hp.n_subjects == 0) return PMX_OK;
 
   pmx::LaunchArgs a{};
@@ -847,18 +977,20 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
       auto it = model->jit_modules.find(pop->device);
       if (it == model->jit_modules.end()) {
         pmx::JitModule mod;
-        const hipError_t le = pmx::jit_load(model->jit_code, &mod);
+        const hipError_t le = pmx::jit_load(model->jit_code, &mod, d.eq_kind == PMX_EQ_ANALYTICAL);
         if (le != hipSuccess) return fail(PMX_ERR_HIP, std::string("loading the compiled model: ") + hipGetErrorString(le));
         it = model->jit_modules.emplace(pop->device, mod).first;
       }
       jm = &it->second;
     }
-    const int lag = a.m.n_lag_slots > 0 ? 1 : 0, ll = a.ops.ll_obs != nullptr ? 1 : 0, ad = a.adaptive ? 1 : 0;
+    const bool ua = d.eq_kind == PMX_EQ_ANALYTICAL;  // user analytical model: [mode][0][LL][0]
+    const int lag = (!ua && a.m.n_lag_slots > 0) ? 1 : 0, ll = a.ops.ll_obs != nullptr ? 1 : 0, ad = (!ua && a.adaptive) ? 1 : 0;
     const int mode = a.mode == pmx::MODE_GRID ? 0 : 1;
     static const char* const kNames[2][2][2] = {
         {{"pmx_jit_ode_rk4_grid", "pmx_jit_ode_rk4_grid<lag>"}, {"pmx_jit_ode_rk4_pair", "pmx_jit_ode_rk4_pair<lag>"}},
         {{"pmx_jit_ode_dopri5_grid", "pmx_jit_ode_dopri5_grid<lag>"}, {"pmx_jit_ode_dopri5_pair", "pmx_jit_ode_dopri5_pair<lag>"}}};
     name = kNames[ad][mode][lag];
+    if (ua) name = mode == 0 ? "pmx_jit_analytical_grid" : "pmx_jit_analytical_pair";
     if (a.S <= 0 || (a.P <= 0 && !a.batch)) {
       e = hipSuccess;
     } else if (mode == 0) {

@@ -200,13 +200,20 @@ int32_t compile_ops(const HostPopulation& hp, const CompileKey& key, OpStream* o
   os->lagb_off.clear();
   os->lagb_time.clear();
   os->lagb_amount.clear();
+  os->lagb_input.clear();
+  os->max_lagb_per_list = 0;
   os->n_prop = 0;
   const uint32_t lag_mask = key.lag_mask;
   int32_t slot_of_input[PMX_MAX_INPUTS];
   int32_t n_slots = 0;
-  for (int i = 0; i < PMX_MAX_INPUTS; ++i) slot_of_input[i] = ((lag_mask >> i) & 1u) ? n_slots++ : -1;
+  for (int i = 0; i < PMX_MAX_INPUTS; ++i) slot_of_input[i] = ((lag_mask >> i) & 1u) ? (key.lag_merge ? 0 : n_slots++) : -1;
+  if (key.lag_merge && lag_mask != 0) n_slots = 1;
   os->n_lag_slots = n_slots;
-  std::vector<std::vector<std::pair<double, double>>> lagb(n_slots > 0 ? n_slots : 1);  // per slot, this occasion
+  struct LagBolus {
+    double first, second;  // recorded time, amount
+    int32_t input;
+  };
+  std::vector<std::vector<LagBolus>> lagb(n_slots > 0 ? n_slots : 1);  // per slot, this occasion
   if (n_slots > 0) os->lagb_off.push_back(0);
   const bool times = n_slots > 0 || key.want_times;  // PROP ops carry their absolute [t0, t1)
 
@@ -223,11 +230,10 @@ int32_t compile_ops(const HostPopulation& hp, const CompileKey& key, OpStream* o
       os->op_t0.push_back(0.0);
       os->op_t1.push_back(0.0);
     }
-    if (ode) {
-      os->op_n.push_back(n);
+    if (ode) os->op_n.push_back(n);
+    if (ode || key.full_rates)
       for (int32_t r = 0; r < n_rate; ++r) os->op_rate.push_back(rates ? rates[r] : 0.0);
-    }
-    if (nc > 0) {
+    if (nc > 0 && !key.user_cov) {
       for (int32_t c = 0; c < nc; ++c) {
         double v = 0.0;
         if (want_cov && !hp.interpolate(occ, c, t_cov, &v)) cov_missing = true;
@@ -269,7 +275,7 @@ int32_t compile_ops(const HostPopulation& hp, const CompileKey& key, OpStream* o
           const bool lagged = hp.ev_kind[e] == PMX_EV_BOLUS && hp.ev_io[e] < PMX_MAX_INPUTS && slot_of_input[hp.ev_io[e]] >= 0;
           if (lagged) {
             max_input_used = std::max<int32_t>(max_input_used, hp.ev_io[e]);
-            lagb[slot_of_input[hp.ev_io[e]]].emplace_back(hp.ev_time[e], hp.ev_value[e]);
+            lagb[slot_of_input[hp.ev_io[e]]].push_back({hp.ev_time[e], hp.ev_value[e], static_cast<int32_t>(hp.ev_io[e])});
           } else if (t_first == std::numeric_limits<double>::infinity()) {
             t_first = hp.ev_time[e];
           }
@@ -279,7 +285,9 @@ int32_t compile_ops(const HostPopulation& hp, const CompileKey& key, OpStream* o
           for (const auto& tb : lagb[k]) {
             os->lagb_time.push_back(tb.first);
             os->lagb_amount.push_back(tb.second);
+            os->lagb_input.push_back(tb.input);
           }
+          os->max_lagb_per_list = std::max<int64_t>(os->max_lagb_per_list, static_cast<int64_t>(lagb[k].size()));
           os->lagb_off.push_back(static_cast<int64_t>(os->lagb_time.size()));
         }
       }
@@ -291,7 +299,7 @@ int32_t compile_ops(const HostPopulation& hp, const CompileKey& key, OpStream* o
           (void)prev;
           if (k == PMX_EV_BOLUS) {
             max_input_used = std::max<int32_t>(max_input_used, hp.ev_io[e]);
-            push(OP_BOLUS, hp.ev_io[e], hp.ev_value[e], 0.0, 0, nullptr, oc, 0.0, false);
+            push(OP_BOLUS, hp.ev_io[e], hp.ev_value[e], hp.ev_time[e], 0, nullptr, oc, 0.0, false);  // (op_b: its time, for a user fa)
           } else if (k == PMX_EV_INFUSION) {
             inf.push_back({hp.ev_time[e], hp.ev_value[e], hp.ev_dur[e], static_cast<int32_t>(hp.ev_io[e])});
           } else {
@@ -324,16 +332,19 @@ int32_t compile_ops(const HostPopulation& hp, const CompileKey& key, OpStream* o
             for (size_t i = 1; i < ts.size(); ++i) {  // :334-367
               const double nxt = ts[i];
               double r0 = 0.0;  // rateiv[0]: the only slot the closed forms read
+              if (key.full_rates) std::fill(rate.begin(), rate.end(), 0.0);
               for (const auto& f : inf) {
                 const double st = f.time, en = st + f.duration;
                 if (cur >= st && nxt <= en) {
                   max_input_used = std::max(max_input_used, f.input);
                   if (f.input == key.rate_input) r0 += f.amount / f.duration;  // :355
+                  if (key.full_rates && f.input < n_rate) rate[f.input] += f.amount / f.duration;
                 }
               }
               const double dt = nxt - cur;
               const double t_cov = key.cov_time_mode == PMX_COV_TIME_SEGMENT_END_ABS ? nxt : dt;
-              push(OP_PROP, 0, dt, r0, 0, nullptr, oc, t_cov, true);
+              push(OP_PROP, 0, dt, r0, 0, key.full_rates ? rate.data() : nullptr, oc, t_cov, true);
+              if (key.solve_marks && i > 1) os->op_meta.back() |= (1u << 24);  // a later sub-segment of the same solve
               if (times) {
                 os->op_t0.back() = cur;
                 os->op_t1.back() = nxt;

@@ -73,12 +73,20 @@ struct CompileKey {
   int32_t n_derived = 0;
   pmx_derived derived[PMX_MAX_DERIVED] = {};
   bool want_times = false; // PROP ops carry absolute [t0, t1) even without lag (custom ODE bodies may read the time)
+  // user (hiprtc) analytical models, pmx_analytical.hpp:
+  bool lag_merge = false;   // every input of lag_mask shares ONE list per occasion (lagb_input says which); the lane
+                            // sorts it by its own landing times (a user lag may differ from bolus to bolus)
+  bool solve_marks = false; // bit 24 of a PROP op = it continues the previous PROP's solve (seq_eq's parameter vector
+                            // lives for one solve, analytical/mod.rs:331)
+  bool full_rates = false;  // analytical: op_rate carries rateiv of EVERY input (a user `eq` may read any of them)
+  bool user_cov = false;    // covariates are looked up on the device (segment tables uploaded; no op_cov / op_fac)
   bool ladder = false;     // analytical, theta-only coefficients, no lag: PROP ops carry the exponential-ladder code
                            // (bits 27-29 of op_meta, pmx_structures.hpp ladder_pow)
   bool operator==(const CompileKey& o) const {
     return eq_kind == o.eq_kind && cov_time_mode == o.cov_time_mode && rk4_h_max == o.rk4_h_max &&
            n_rate == o.n_rate && rate_input == o.rate_input && class_g == o.class_g && lag_mask == o.lag_mask &&
-           ladder == o.ladder && want_times == o.want_times && n_derived == o.n_derived &&
+           ladder == o.ladder && want_times == o.want_times && lag_merge == o.lag_merge && solve_marks == o.solve_marks &&
+           full_rates == o.full_rates && user_cov == o.user_cov && n_derived == o.n_derived &&
            std::memcmp(derived, o.derived, sizeof(derived)) == 0;
   }
 };
@@ -101,6 +109,8 @@ struct OpStream {
   std::vector<int64_t> lagb_off;     // [(n_occasions * n_lag_slots) + 1] lagged boluses per (occasion, slot)
   std::vector<double> lagb_time;     // original (un-lagged) bolus time, sorted per (occasion, slot)
   std::vector<double> lagb_amount;
+  std::vector<int32_t> lagb_input;   // the bolus' input (lag_merge lists mix inputs)
+  int64_t max_lagb_per_list = 0;     // longest (occasion, slot) list
   std::vector<int32_t> subj_order;   // subjects sorted by op count (desc), for the lane-per-pair kernels
   int32_t max_ops_per_subject = 0;
   int64_t n_prop = 0;

@@ -51,6 +51,24 @@ __device__ __forceinline__ double select_state(const double (&x)[N], int idx) {
   return v;
 }
 
+// Covariate c of occasion `occ` at time t: first segment with from <= t < to (linear: slope * t + intercept, two
+// roundings like the reference; carry-forward: the stored value); before the first observation its value; the last
+// segment is open-ended.  NaN when nothing matches (the reference's MissingSegments error).
+__device__ __forceinline__ double cov_at(const DevOps& ops, int64_t occ, int c, double t) {
+  const int64_t cell = occ * ops.n_cov + c;
+  const int64_t s0 = ops.cov_seg_off[cell], s1 = ops.cov_seg_off[cell + 1];
+  if (t < ops.cov_first_t[cell]) return ops.cov_first_v[cell];
+  double v = __longlong_as_double(0x7ff8000000000000LL);
+  for (int64_t sg = s0; sg < s1; ++sg) {
+    if (ops.seg_from[sg] <= t && t < ops.seg_to[sg]) {
+      const double sl = ops.seg_slope[sg], ic = ops.seg_icpt[sg];
+      v = (sl != sl) ? ic : __dadd_rn(__dmul_rn(sl, t), ic);
+      break;
+    }
+  }
+  return v;
+}
+
 // ------------------------------------------------------------------------------------
 // theta-dependent event rewrite on the device: lag time and bioavailability
 // (Occasion::add_lagtime / add_bioavailability, src/data/structs.rs:611-666).

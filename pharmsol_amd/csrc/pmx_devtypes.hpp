@@ -73,6 +73,7 @@ struct DevOps {
   const double* seg_icpt;
   const double* cov_first_t;    // [n_occasions*n_cov]
   const double* cov_first_v;
+  const int32_t* lagb_input;    // user analytical models: the input of each listed bolus (one merged list per occasion)
 };
 
 }  // namespace pmx

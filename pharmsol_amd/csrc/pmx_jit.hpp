@@ -7,15 +7,23 @@
 #include <string>
 #include <vector>
 
+#include "../../include/pmx.h"
+
 namespace pmx {
 
 struct JitSpec {
   int32_t nstates = 1, nparams = 1, nout = 1, ninputs = 1, ncov = 0;
   bool has_init = false;
   std::string source;  // definitions of pmx_dynamics / pmx_outputs (/ pmx_init), see include/pmx.h
+  // user ANALYTICAL models (pmx_analytical.hpp): which closures `source` defines (PMX_FN_*), and the descriptor the
+  // generator turns into code for the closures it leaves out
+  bool analytical = false;
+  uint32_t fns = 0;
+  pmx_model_desc desc{};
 };
 
-// The translation unit handed to hiprtc (user source + policy + the 8 kernel wrappers).
+// The translation unit handed to hiprtc (user source + policy + the kernel wrappers: 16 for an ODE model - GRID/PAIR x
+// lag x log-likelihood x solver -, 4 for an analytical one - GRID/PAIR x log-likelihood).
 std::string jit_translation_unit(const JitSpec& spec);
 
 // Compile for gfx950 (needs no device).  Returns true and fills *code (an AMDGPU code object); on failure *log has
@@ -27,7 +35,7 @@ struct JitModule {
   hipFunction_t fn[2][2][2][2] = {};  // [mode: 0 GRID, 1 PAIR][LAG][LL][ADAPT]
 };
 // Load a compiled code object on the CURRENT device and resolve the kernel entry points.
-hipError_t jit_load(const std::vector<char>& code, JitModule* out);
+hipError_t jit_load(const std::vector<char>& code, JitModule* out, bool analytical = false);
 void jit_unload(JitModule* m);
 
 }  // namespace pmx

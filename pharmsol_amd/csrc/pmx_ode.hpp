@@ -22,24 +22,6 @@ struct OdeLane {
   int64_t occ;  // global occasion index of the occasion being walked
 };
 
-// Covariate c of occasion `occ` at time t: first segment with from <= t < to (linear: slope * t + intercept, two
-// roundings like the reference; carry-forward: the stored value); before the first observation its value; the last
-// segment is open-ended.  NaN when nothing matches (the reference's MissingSegments error).
-__device__ __forceinline__ double cov_at(const DevOps& ops, int64_t occ, int c, double t) {
-  const int64_t cell = occ * ops.n_cov + c;
-  const int64_t s0 = ops.cov_seg_off[cell], s1 = ops.cov_seg_off[cell + 1];
-  if (t < ops.cov_first_t[cell]) return ops.cov_first_v[cell];
-  double v = __longlong_as_double(0x7ff8000000000000LL);
-  for (int64_t sg = s0; sg < s1; ++sg) {
-    if (ops.seg_from[sg] <= t && t < ops.seg_to[sg]) {
-      const double sl = ops.seg_slope[sg], ic = ops.seg_icpt[sg];
-      v = (sl != sl) ? ic : __dadd_rn(__dmul_rn(sl, t), ic);
-      break;
-    }
-  }
-  return v;
-}
-
 // Model policy M (a built-in diffeq body below, or the wrapper pmx_jit.cpp generates around a user's source):
 //   NS, NP, CENTRAL, CUSTOM, NR (length of the rate vector: NS per-state rates for built-ins, the model's inputs
 //   for custom bodies, which add rateiv themselves like a hand-written ODE::new closure)

@@ -25,9 +25,11 @@
 // (parity budget 1e-6 relative, tests/test_gpu_parity.py).
 #pragma once
 
+#if !defined(__HIPCC_RTC__)  // (also embedded into the sources hiprtc compiles for user analytical models)
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#endif
 
 namespace pmx {
 

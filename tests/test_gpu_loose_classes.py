@@ -202,16 +202,20 @@ def test_lag_time_models_on_a_shared_design_are_classed(structure, loglik):
     check(model, flat, theta, "pmx_analytical_classed<ll,lag>" if loglik else "pmx_analytical_classed<lag>", loglik)
     plan = runtime.class_plan(model, flat)
     assert plan["classed_subjects"] == 45 and plan["chunks_loose"] == 0 and plan["generic_subjects"] == 1
-    if not loglik:  # the device's own guard (the reference has none): a negative or NaN lag flags the pair, rows NaN
+    if not loglik:
         import torch
 
+        # a negative lag is a shift to an earlier time, like the reference (structs.rs:629-634); only NaN is flagged
+        neg = theta.copy()
+        neg[5, nk + 1], neg[9, nk + 1] = -1.0, -30.0
+        check(model, flat, neg, "pmx_analytical_classed<lag>")
         bad = theta.copy()
-        bad[5, nk + 1], bad[6, nk + 1] = -1.0, np.nan
+        bad[6, nk + 1] = np.nan
         pred, st = runtime.predict(model, runtime.DevicePopulation(flat, 0), np.ascontiguousarray(bad))
         torch.cuda.synchronize()
         pred, st = pred.cpu().numpy(), st.cpu().numpy()
-        assert (st[:, 5:7] == _abi.PMX_PAIR_BAD_LAG).all() and np.isnan(pred[:, 5:7]).all()
-        assert (np.delete(st, [5, 6], axis=1) == 0).all() and np.isfinite(np.delete(pred, [5, 6], axis=1)).all()
+        assert (st[:, 6] == _abi.PMX_PAIR_BAD_LAG).all() and np.isnan(pred[:, 6]).all()
+        assert (np.delete(st, 6, axis=1) == 0).all() and np.isfinite(np.delete(pred, 6, axis=1)).all()
 
 
 def test_censored_observations_in_loose_classes():

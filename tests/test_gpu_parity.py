@@ -402,8 +402,8 @@ def test_negative_lag_shifts_the_bolus_earlier_like_the_reference(n_support):
     assert_parity(m, m.flatten(Data(subs)), th2, TOL_ANALYTICAL)
     shared = [Subject.builder(f"c{i}").bolus(2.0, 10.0 + i, 0).missing_observation(1.0, 0).bolus(6.0, 5.0, 0)
               .missing_observation(4.0, 0).missing_observation(8.0, 0).build() for i in range(33)]
-    assert_parity(m, m.flatten(Data(shared)), th2, TOL_ANALYTICAL,
-                  expect_kernel="pmx_analytical_classed<lag>" if n_support >= 32 else "pmx_analytical_pair<lag>")
+    assert_parity(m, m.flatten(Data(shared)), th2, TOL_ANALYTICAL, expect_kernel="pmx_analytical_classed<lag>")
+    assert_parity(m, m.flatten(Data(shared)), th2[:5], TOL_ANALYTICAL, expect_kernel="pmx_analytical_pair<lag>")
     th[7, 2] = np.nan
     got, st = gpu_predict(m, m.flatten(s), th)
     assert st[0, 7] == _abi.PMX_PAIR_BAD_LAG and np.isnan(got[:, 7]).all()
