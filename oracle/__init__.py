@@ -19,8 +19,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "libpmx_oracle.so")
 _lib = None
 
-K_TEST_SEQ_ACCUM = 100
-K_TEST_RATEIV3 = 101
+K_TEST_SEQ_ACCUM = 1000
+K_TEST_RATEIV3 = 1001
 
 
 def build(force: bool = False) -> str:
@@ -97,6 +97,45 @@ def compile_custom(source: str, has_init: bool = False) -> None:
 
 
 _custom_lib = None
+_user_lib = None
+_user_key = None
+
+
+def _register_user(model) -> None:
+    """Analytical user closures: build the model's source with g++ (the SAME text the device compiles) and register
+    its bodies (pmx_oracle_set_user); a descriptor model clears the registration.  One model at a time: tests only."""
+    import hashlib
+    import tempfile
+
+    global _user_lib, _user_key
+    L = lib()
+    L.pmx_oracle_set_user.argtypes = [C.c_uint32, C.c_void_p]
+    L.pmx_oracle_set_user.restype = None
+    mask = int(getattr(model, "user_fns", 0) or 0)
+    if not mask or getattr(model, "eq_kind", None) != _abi.PMX_EQ_ANALYTICAL:
+        if _user_key is not None:
+            L.pmx_oracle_set_user(0, None)
+            _user_key = None
+        return
+    source = model.source
+    key = hashlib.sha1(source.encode()).hexdigest()[:16]
+    if key == _user_key:
+        return
+    d = os.path.join(tempfile.gettempdir(), "pmx_oracle_custom")
+    os.makedirs(d, exist_ok=True)
+    so = os.path.join(d, f"u{key}.so")
+    if not os.path.exists(so):
+        src = os.path.join(d, f"u{key}.cpp")
+        with open(src, "w") as f:
+            f.write('#include <cmath>\nusing namespace std;\n#define PMX_DEVICE extern "C"\n#line 1 "model"\n' + source)
+        subprocess.run(["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-o", so, src], check=True)
+    cl = C.CDLL(so)
+    fns = (C.c_void_p * 8)()
+    for name, bit in _abi.USER_FUNCTION_BITS.items():
+        if mask & bit:
+            fns[bit.bit_length() - 1] = C.cast(getattr(cl, name), C.c_void_p)
+    L.pmx_oracle_set_user(mask, fns)
+    _user_lib, _user_key = cl, key
 
 
 def max_threads() -> int:
@@ -111,6 +150,7 @@ def predict(model, flat, theta: np.ndarray, nthreads: int = 0, allow_pair_failur
             ) -> Tuple[np.ndarray, np.ndarray]:
     """Oracle twin of ``pmx_predict``: returns ``(pred[n_obs, P], status[S, P])``."""
     L = lib()
+    _register_user(model)
     theta = np.ascontiguousarray(theta, dtype=np.float64)
     if theta.ndim == 1:
         theta = theta.reshape(1, -1)
@@ -130,6 +170,7 @@ def predict(model, flat, theta: np.ndarray, nthreads: int = 0, allow_pair_failur
 def predict_batch(model, flat, theta: np.ndarray, nthreads: int = 0) -> Tuple[np.ndarray, np.ndarray]:
     """Oracle twin of ``pmx_predict_batch`` (subject s with theta row s)."""
     L = lib()
+    _register_user(model)
     theta = np.ascontiguousarray(theta, dtype=np.float64)
     md = _model_desc(model)
     assert theta.shape == (flat.n_subjects, md.nparams)
@@ -172,6 +213,7 @@ def loglik(model, flat, error_models, theta: np.ndarray, nthreads: int = 0, allo
            ) -> Tuple[np.ndarray, np.ndarray]:
     """Oracle twin of ``pmx_loglik``: returns ``(ll[S, P], status[S, P])``."""
     L = lib()
+    _register_user(model)
     theta = np.ascontiguousarray(theta, dtype=np.float64)
     if theta.ndim == 1:
         theta = theta.reshape(1, -1)

@@ -485,12 +485,44 @@ typedef struct {
 typedef struct {
   const pmx_model_desc* m;
   const cov_track* cov; /* [n_covariates] for the current occasion */
+  const double* theta;  /* the support point as given (a user seq_eq sees it beside the solve's working vector) */
 } ctx_t;
+
+/* User closures of an Analytical model (Analytical::new(eq, seq_eq, lag, fa, init, out), analytical/mod.rs:102-118;
+ * argument order of the reference's compiled kernels, src/dsl/native.rs:45-53).  Registered by the test harness,
+ * which builds the very source text the device compiles with gcc (oracle/__init__.py compile_user).  g_user_mask =
+ * PMX_FN_* bits of the registered closures; 0 = descriptor model. */
+typedef void (*pmx_user_fn)(double t, const double* x, const double* p, const double* cov, const double* rateiv,
+                            const double* derived, double* out);
+static uint32_t g_user_mask = 0;
+static pmx_user_fn g_user_outputs = 0, g_user_init = 0, g_user_derive = 0, g_user_lag = 0, g_user_fa = 0, g_user_seq = 0,
+                   g_user_eq = 0;
+void pmx_oracle_set_user(uint32_t mask, void** fns) {
+  g_user_mask = mask;
+  g_user_outputs = (mask & PMX_FN_OUTPUTS) ? (pmx_user_fn)fns[1] : 0;
+  g_user_init = (mask & PMX_FN_INIT) ? (pmx_user_fn)fns[2] : 0;
+  g_user_derive = (mask & PMX_FN_DERIVE) ? (pmx_user_fn)fns[3] : 0;
+  g_user_lag = (mask & PMX_FN_ROUTE_LAG) ? (pmx_user_fn)fns[4] : 0;
+  g_user_fa = (mask & PMX_FN_ROUTE_BIOAVAILABILITY) ? (pmx_user_fn)fns[5] : 0;
+  g_user_seq = (mask & PMX_FN_SEQ_EQ) ? (pmx_user_fn)fns[6] : 0;
+  g_user_eq = (mask & PMX_FN_EQ) ? (pmx_user_fn)fns[7] : 0;
+}
+static void cov_values(const ctx_t* c, double t, double* cv);
+static int is_user_analytical(const pmx_model_desc* m) { return m->eq_kind == PMX_EQ_ANALYTICAL && g_user_mask != 0; }
 
 /* the `derive:` block: derived[d] = theta[src] * f0 * f1, covariates at `t`
  * (bindings.rs:98-117 -> fetch_cov!(cov, t, ...) src/lib.rs:433-443) */
 static int eval_derived(const ctx_t* c, const double* theta, double t, double* derived) {
   const pmx_model_desc* m = c->m;
+  if (is_user_analytical(m)) { /* the user's derive closure at t (every macro-lowered closure starts with it) */
+    double cv[PMX_MAX_COVARIATES];
+    for (int d = 0; d < m->n_derived; d++) derived[d] = 0.0;
+    if (g_user_derive) {
+      cov_values(c, t, cv);
+      g_user_derive(t, 0, theta, m->n_covariates ? cv : 0, 0, 0, derived);
+    }
+    return 0;
+  }
   for (int d = 0; d < m->n_derived; d++) {
     const pmx_derived* dd = &m->derived[d];
     double v = theta[dd->src_param];
@@ -523,9 +555,18 @@ static int model_eq(const ctx_t* c, const double* x, const double* pv, double dt
     xo[0] = x[0] + rateiv[3] * dt;
     return 0;
   }
-  double derived[PMX_MAX_DERIVED];
+  double derived[PMX_MAX_USER_DERIVED];
   double kp[PMX_MAX_KPARAMS];
   const double* p = pv;
+  if (m->kernel == PMX_K_CUSTOM) { /* the user's own propagator: eq(x, p, dt, rateiv, cov) (analytical/mod.rs:363-364) */
+    double cv[PMX_MAX_COVARIATES];
+    if (!g_user_eq) return -2;
+    cov_values(c, t_cov, cv);
+    eval_derived(c, pv, t_cov, derived);
+    for (int i = 0; i < m->nstates; i++) xo[i] = x[i];
+    g_user_eq(dt, x, pv, m->n_covariates ? cv : 0, rateiv, (g_user_mask & PMX_FN_DERIVE) ? derived : 0, xo);
+    return 0;
+  }
   if (m->n_bind > 0) {
     if (m->n_derived > 0 && eval_derived(c, pv, t_cov, derived)) return -2;
     for (int j = 0; j < m->n_bind; j++)
@@ -537,9 +578,14 @@ static int model_eq(const ctx_t* c, const double* x, const double* pv, double dt
 }
 
 /* `seq_eq` — empty for every macro model (expand/analytical.rs:121). */
+static void cov_values(const ctx_t* c, double t, double* cv);
 static void model_seq_eq(const ctx_t* c, double* pv, double t) {
-  (void)t;
   if (c->m->kernel == PMX_ORACLE_K_TEST_SEQ_ACCUM) pv[0] += 1.0; /* analytical/mod.rs:499-501 */
+  if (is_user_analytical(c->m) && g_user_seq) { /* (self.seq_eq)(&mut parameters_v, next_t, covariates) :360 */
+    double cv[PMX_MAX_COVARIATES];
+    cov_values(c, t, cv);
+    g_user_seq(t, 0, c->theta, c->m->n_covariates ? cv : 0, 0, 0, pv);
+  }
 }
 
 /* covariates of the current occasion at time t (fetch_cov!, src/lib.rs:433-443); NaN where interpolation fails */
@@ -570,7 +616,14 @@ static int model_out(const ctx_t* c, const double* x, const double* theta, doubl
     g_custom_outputs(t_obs, x, theta, m->n_covariates ? cv : 0, 0, 0, y); /* y zeroed by the caller */
     return 0;
   }
-  double derived[PMX_MAX_DERIVED];
+  double derived[PMX_MAX_USER_DERIVED];
+  if (is_user_analytical(m) && g_user_outputs) { /* out(x, p, t_obs, cov, y), derive first (expand/analytical.rs:320-326) */
+    double cv[PMX_MAX_COVARIATES];
+    cov_values(c, t_obs, cv);
+    eval_derived(c, theta, t_obs, derived);
+    g_user_outputs(t_obs, x, theta, m->n_covariates ? cv : 0, 0, (g_user_mask & PMX_FN_DERIVE) ? derived : 0, y);
+    return 0;
+  }
   int need = 0;
   for (int o = 0; o < m->nout; o++) need |= (m->out[o].vol_src == PMX_SRC_DERIVED);
   if (need && eval_derived(c, theta, t_obs, derived)) return -2;
@@ -843,6 +896,8 @@ static int simulate_pair(const pmx_model_desc* m, const pmx_population_desc* pop
   adapt_t adapt = {m->rk4_h_max, 0}; /* adaptive solver: the proposal restarts with every subject */
   ctx_t ctx;
   ctx.m = m;
+  ctx.theta = theta;
+  const int user = is_user_analytical(m);
   for (int64_t oc = occ0; oc < occ1; oc++) { /* for occasion in subject.occasions() :494 */
     ctx.cov = sc->cov + (oc - occ0) * ncov;
     int occ_index = pop->occ_index ? pop->occ_index[oc] : (int)(oc - occ0);
@@ -857,6 +912,13 @@ static int simulate_pair(const pmx_model_desc* m, const pmx_population_desc* pop
         double cv[PMX_MAX_COVARIATES];
         cov_values(&ctx, 0.0, cv);
         g_custom_init(0.0, x, theta, m->n_covariates ? cv : 0, 0, 0, x);
+      }
+      if (user && g_user_init) { /* init(p, 0.0, cov, x), analytical/mod.rs:417-423 */
+        double cv[PMX_MAX_COVARIATES], der[PMX_MAX_USER_DERIVED];
+        cov_values(&ctx, 0.0, cv);
+        eval_derived(&ctx, theta, 0.0, der);
+        for (int i = 0; i < m->nstates; i++) x[i] = 0.0;
+        g_user_init(0.0, x, theta, m->n_covariates ? cv : 0, 0, (g_user_mask & PMX_FN_DERIVE) ? der : 0, x);
       }
     }
     /* resolve_occasion_events: clone + process_events (equation/mod.rs:247-273, structs.rs:681-690) */
@@ -877,7 +939,18 @@ static int simulate_pair(const pmx_model_desc* m, const pmx_population_desc* pop
       for (int64_t i = 0; i < n; i++) {
         if (ev[i].kind != PMX_EV_BOLUS) continue;
         int input = ev[i].io;
-        if (input < PMX_MAX_INPUTS && m->lag_param[input] >= 0) {
+        if (user && g_user_lag) { /* fn_lag(&parameters, bolus.time(), covariates), structs.rs:629 */
+          double cv[PMX_MAX_COVARIATES], der[PMX_MAX_USER_DERIVED], lagv[PMX_MAX_INPUTS];
+          cov_values(&ctx, ev[i].time, cv);
+          eval_derived(&ctx, theta, ev[i].time, der);
+          for (int k = 0; k < PMX_MAX_INPUTS; k++) lagv[k] = 0.0;
+          g_user_lag(ev[i].time, 0, theta, m->n_covariates ? cv : 0, 0, (g_user_mask & PMX_FN_DERIVE) ? der : 0, lagv);
+          double l = input < PMX_MAX_INPUTS ? lagv[input] : 0.0;
+          if (l != 0.0) {
+            ev[i].time += l;
+            shifted = 1;
+          }
+        } else if (input < PMX_MAX_INPUTS && m->lag_param[input] >= 0) {
           double l = theta[m->lag_param[input]];
           if (l != 0.0) {
             ev[i].time += l;
@@ -891,7 +964,14 @@ static int simulate_pair(const pmx_model_desc* m, const pmx_population_desc* pop
     for (int64_t i = 0; i < n; i++) {
       if (ev[i].kind != PMX_EV_BOLUS) continue;
       int input = ev[i].io;
-      if (input < PMX_MAX_INPUTS && m->fa_param[input] >= 0) ev[i].value = ev[i].value * theta[m->fa_param[input]];
+      if (user && g_user_fa) { /* fn_fa(&parameters, bolus.time() [already shifted], covariates), structs.rs:661 */
+        double cv[PMX_MAX_COVARIATES], der[PMX_MAX_USER_DERIVED], fav[PMX_MAX_INPUTS];
+        cov_values(&ctx, ev[i].time, cv);
+        eval_derived(&ctx, theta, ev[i].time, der);
+        for (int k = 0; k < PMX_MAX_INPUTS; k++) fav[k] = 1.0;
+        g_user_fa(ev[i].time, 0, theta, m->n_covariates ? cv : 0, 0, (g_user_mask & PMX_FN_DERIVE) ? der : 0, fav);
+        if (input < PMX_MAX_INPUTS) ev[i].value = ev[i].value * fav[input];
+      } else if (input < PMX_MAX_INPUTS && m->fa_param[input] >= 0) ev[i].value = ev[i].value * theta[m->fa_param[input]];
     }
 
     if (m->eq_kind == PMX_EQ_ANALYTICAL) {
@@ -1016,7 +1096,9 @@ static int validate(const pmx_model_desc* m, const pmx_population_desc* pop) {
     FAIL(PMX_ERR_INVALID_ARGUMENT, "model declares %d covariates, population carries %d", m->n_covariates,
          pop->n_covariates);
   if (m->eq_kind == PMX_EQ_ANALYTICAL) {
-    if (m->kernel < PMX_ORACLE_K_TEST_SEQ_ACCUM) {
+    if (m->kernel == PMX_K_CUSTOM) {
+      if (!g_user_eq) FAIL(PMX_ERR_INVALID_ARGUMENT, "PMX_K_CUSTOM: no user eq registered (pmx_oracle_set_user)");
+    } else if (m->kernel < PMX_ORACLE_K_TEST_SEQ_ACCUM) {
       int ns = kernel_nstates(m->kernel);
       if (ns < 0) FAIL(PMX_ERR_INVALID_ARGUMENT, "unknown analytical kernel %d", m->kernel);
       if (m->nstates < ns + (m->pmetrics_indexing ? 1 : 0))

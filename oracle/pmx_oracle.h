@@ -26,11 +26,12 @@ extern "C" {
 
 /* Oracle-only analytical "kernels" that reproduce the closures of the
  * reference's known-answer tests (not pharmacometric models):
- *  100: eq x0 += p0*dt, seq_eq p0 += 1      analytical/mod.rs:493-527  (expects 2.5)
- *  101: eq x0 += rateiv[3]*dt               analytical/mod.rs:530-560  (expects 4.0)
+ *  1000: eq x0 += p0*dt, seq_eq p0 += 1      analytical/mod.rs:493-527  (expects 2.5)
+ *  1001: eq x0 += rateiv[3]*dt               analytical/mod.rs:530-560  (expects 4.0)
+ * (the same two models run on the DEVICE as user closures: tests/test_user_analytical.py)
  */
-#define PMX_ORACLE_K_TEST_SEQ_ACCUM 100
-#define PMX_ORACLE_K_TEST_RATEIV3 101
+#define PMX_ORACLE_K_TEST_SEQ_ACCUM 1000
+#define PMX_ORACLE_K_TEST_RATEIV3 1001
 
 /* Same contract as pmx_predict (include/pmx.h), computed on the CPU.
  * Loop nest = log_likelihood_matrix (likelihood/matrix.rs:79-98): parallel over
@@ -52,6 +53,9 @@ int32_t pmx_oracle_loglik(const pmx_model_desc* model, const pmx_population_desc
 int32_t pmx_oracle_sigma(const pmx_error_model* em, double observation, double* sigma);
 /* PMX_ODE_CUSTOM: the three user bodies (any may be NULL except dynamics/outputs), see oracle/__init__.py */
 void pmx_oracle_set_custom(void* dynamics, void* outputs, void* init);
+/* User closures of an ANALYTICAL model (pmx_model_create_user): mask = PMX_FN_* bits, fns[bit position] = the gcc-built
+ * bodies of the same source the device compiles.  mask = 0 clears the registration (descriptor models). */
+void pmx_oracle_set_user(uint32_t mask, void** fns);
 
 /* lognormpdf (likelihood/distributions.rs:31-34) */
 double pmx_oracle_lognormpdf(double obs, double pred, double sigma);

@@ -16,6 +16,7 @@ PMX_MAX_INPUTS = 8
 PMX_MAX_OUT = 4
 PMX_MAX_KPARAMS = 8
 PMX_MAX_DERIVED = 4
+PMX_MAX_USER_DERIVED = 16
 PMX_MAX_FACTORS = 2
 PMX_MAX_PARAMS = 16
 PMX_MAX_COVARIATES = 8
@@ -237,3 +238,24 @@ class PmxError(RuntimeError):
         self.status = status
         self.status_name = STATUS_NAMES.get(status, str(status))
         super().__init__(f"{self.status_name}: {message}")
+
+
+# ---- user closures (pmx_model_create_user) ----------------------------------------------------------------------
+PMX_K_CUSTOM = 100
+PMX_FN_DYNAMICS, PMX_FN_OUTPUTS, PMX_FN_INIT, PMX_FN_DERIVE = 1, 2, 4, 8
+PMX_FN_ROUTE_LAG, PMX_FN_ROUTE_BIOAVAILABILITY, PMX_FN_SEQ_EQ, PMX_FN_EQ = 16, 32, 64, 128
+USER_FUNCTION_BITS = {"pmx_dynamics": PMX_FN_DYNAMICS, "pmx_outputs": PMX_FN_OUTPUTS, "pmx_init": PMX_FN_INIT,
+                      "pmx_derive": PMX_FN_DERIVE, "pmx_route_lag": PMX_FN_ROUTE_LAG,
+                      "pmx_route_bioavailability": PMX_FN_ROUTE_BIOAVAILABILITY, "pmx_seq_eq": PMX_FN_SEQ_EQ,
+                      "pmx_eq": PMX_FN_EQ}
+
+
+def user_functions_of(source: str) -> int:
+    """PMX_FN_* mask of the ``PMX_DEVICE void pmx_<role>(`` definitions a source text holds."""
+    import re
+
+    mask = 0
+    for name, bit in USER_FUNCTION_BITS.items():
+        if re.search(r"PMX_DEVICE\s+void\s+" + name + r"\s*\(", source):
+            mask |= bit
+    return mask

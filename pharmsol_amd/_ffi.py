@@ -33,6 +33,8 @@ SYMBOLS = [
     ("pmx_model_create", C.c_int32, [_MD, C.POINTER(C.c_void_p)]),
     ("pmx_model_create_custom", C.c_int32, [_MD, C.c_char_p, C.c_int32, C.POINTER(C.c_void_p)]),
     ("pmx_debug_jit_source", C.c_int32, [_MD, C.c_char_p, C.c_int32, C.POINTER(C.c_void_p)]),
+    ("pmx_model_create_user", C.c_int32, [_MD, C.c_char_p, C.c_uint32, C.POINTER(C.c_void_p)]),
+    ("pmx_debug_jit_source_user", C.c_int32, [_MD, C.c_char_p, C.c_uint32, C.POINTER(C.c_void_p)]),
     ("pmx_free_text", None, [C.c_void_p]),
     ("pmx_model_destroy", None, [C.c_void_p]),
     ("pmx_predict", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),

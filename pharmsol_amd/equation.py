@@ -114,6 +114,9 @@ class Equation:
         self.pmetrics = False
         self.rk4_h_max = 0.02
         self._handle = None  # lazily created pmx_model*
+        # user closures (Analytical.user / analytical(..., source=...)): C/HIP source text + which pmx_<role> it defines
+        self.user_fns = 0
+        self.user_derived: List[str] = []
 
     # -- builder methods (analytical/mod.rs:120-138) ---------------------------
     def with_nstates(self, n: int):
@@ -198,6 +201,8 @@ class Equation:
             return (_abi.PMX_SRC_PRIMARY, self.params.index(name))
         if name in self.derived:
             return (_abi.PMX_SRC_DERIVED, list(self.derived).index(name))
+        if name in self.user_derived:
+            return (_abi.PMX_SRC_DERIVED, self.user_derived.index(name))
         raise KeyError(f"'{name}' is neither a parameter nor a derived value")
 
     def _required_names(self) -> List[str]:
@@ -214,6 +219,10 @@ class Equation:
         if len(self.derived) > _abi.PMX_MAX_DERIVED:
             raise ValueError("too many derived values")
         d.n_derived = len(self.derived)
+        if self.user_fns:  # the user's pmx_derive writes them; no descriptors
+            if len(self.user_derived) > _abi.PMX_MAX_USER_DERIVED:
+                raise ValueError("too many derived values")
+            d.n_derived = len(self.user_derived)
         for i, (name, sc) in enumerate(self.derived.items()):
             dd = d.derived[i]
             dd.src_param = self.params.index(sc.param)
@@ -336,10 +345,66 @@ class Analytical(Equation):
         m.fa = {str(k): v for k, v in (fa or {}).items()}
         return m
 
+    source: Optional[str] = None  # user closures (Analytical.user / analytical(..., source=...))
+
+    @staticmethod
+    def user(source: str, *, eq: Optional[str] = None, nstates: int, nparams: int, ndrugs: int = 1, nout: int = 1,
+             covariates: Optional[Sequence[str]] = None, n_derived: int = 0, bind: Optional[Sequence] = None,
+             out: Optional[Dict[int, Ratio]] = None, init: Optional[Dict[int, int]] = None,
+             lag: Optional[Dict[int, int]] = None, fa: Optional[Dict[int, int]] = None,
+             cov_time: str = "segment_dt") -> "Analytical":
+        """``Analytical::new(eq, seq_eq, lag, fa, init, out)`` with USER closures (analytical/mod.rs:102-118), index
+        based like the reference's hand-written form.  ``source`` is C/HIP text defining any of ``pmx_derive``,
+        ``pmx_route_lag``, ``pmx_route_bioavailability``, ``pmx_init``, ``pmx_outputs``, ``pmx_seq_eq``, ``pmx_eq``
+        (include/pmx.h "user closures"); the library compiles it for gfx950 with hiprtc.  ``eq`` names a built-in
+        structure, or is None when the source brings its own propagator ``pmx_eq``.  ``bind``: kernel-order parameter
+        j <- ``("p", k)`` theta[k] or ``("d", k)`` derived[k] (default: the leading parameters).  Closures the source
+        leaves out fall back to the index forms (``out`` / ``init`` / ``lag`` / ``fa``) of ``Analytical.new``."""
+        m = Analytical()
+        m.kernel_name = eq or "custom"
+        if eq is not None and eq not in _abi.ANALYTICAL_KERNELS:
+            raise KeyError(f"unknown analytical structure '{eq}'")
+        m.covariates = list(covariates or [])
+        m._set_user_source(source)
+        m.user_derived = [f"d{i}" for i in range(int(n_derived))]
+        m.user_bind = [tuple(b) for b in (bind or [])]
+        m.out = dict(out or {})
+        m.nparams = int(nparams)
+        m.init = dict(init or {})
+        m.lag = {str(k): v for k, v in (lag or {}).items()}
+        m.fa = {str(k): v for k, v in (fa or {}).items()}
+        m.cov_time = cov_time
+        return m.with_nstates(nstates).with_ndrugs(ndrugs).with_nout(nout)
+
+    user_bind: Sequence = ()
+
+    def _set_user_source(self, source: str):
+        fns = _abi.user_functions_of(source)
+        if not fns:
+            raise ValueError("the source defines none of pmx_derive / pmx_route_lag / pmx_route_bioavailability / pmx_init / "
+                             "pmx_outputs / pmx_seq_eq / pmx_eq")
+        if (fns & _abi.PMX_FN_EQ) and self.kernel_name != "custom":
+            raise ValueError("pmx_eq replaces the structure: declare no built-in structure with it")
+        if self.kernel_name == "custom" and not (fns & _abi.PMX_FN_EQ):
+            raise ValueError("no structure named and no pmx_eq in the source")
+        self.source, self.user_fns = str(source), fns
+        self._handle = None
+
+    def desc(self) -> _abi.pmx_model_desc:
+        d = super().desc()
+        if self.user_fns and self.user_bind:  # index-based binding of Analytical.user
+            d.n_bind = len(self.user_bind)
+            for j, (src, idx) in enumerate(self.user_bind):
+                d.bind[j].src = _abi.PMX_SRC_DERIVED if src == "d" else _abi.PMX_SRC_PRIMARY
+                d.bind[j].index = int(idx)
+        return d
+
     def _kernel_id(self) -> int:
-        return _abi.ANALYTICAL_KERNELS[self.kernel_name]
+        return _abi.PMX_K_CUSTOM if self.kernel_name == "custom" else _abi.ANALYTICAL_KERNELS[self.kernel_name]
 
     def _required_names(self) -> List[str]:
+        if self.kernel_name == "custom":
+            return []
         return _abi.KERNEL_PARAMETER_NAMES[self.kernel_name] if self.has_metadata else []
 
 
@@ -440,21 +505,47 @@ def _declare(m: Equation, name, params, derived, covariates, states, outputs, ro
     return m
 
 
-def analytical(*, name: str, params: Sequence[str], structure: str, states: Sequence[str], outputs: Sequence[str],
-               routes: Sequence[Route], out: Dict[str, Ratio], derived: Optional[Dict[str, Scaled]] = None,
+def analytical(*, name: str, params: Sequence[str], structure: Optional[str], states: Sequence[str], outputs: Sequence[str],
+               routes: Sequence[Route], out: Optional[Dict[str, Ratio]] = None, derived=None,
                covariates: Optional[Sequence[str]] = None, init=None, lag=None, fa=None,
-               cov_time: str = "segment_dt") -> Analytical:
-    """The ``analytical!`` declaration (e.g. examples/analytical_readme.rs:7-24)."""
+               cov_time: str = "segment_dt", source: Optional[str] = None) -> Analytical:
+    """The ``analytical!`` declaration (e.g. examples/analytical_readme.rs:7-24).
+
+    Closures come in two forms.  Declarative (``derived={name: Scaled(..)}``, ``out={..: Ratio(..)}``, ``lag`` / ``fa`` /
+    ``init`` = parameter names): the closed forms the library's own kernels know.  Or ``source=``: C/HIP text with the
+    bodies of the macro's ``derive:`` / ``lag:`` / ``fa:`` / ``init:`` / ``out:`` blocks as ``pmx_derive`` / ``pmx_route_lag`` /
+    ``pmx_route_bioavailability`` / ``pmx_init`` / ``pmx_outputs`` (+ ``pmx_seq_eq``, ``pmx_eq``), compiled for gfx950 at run time
+    (include/pmx.h "user closures"); then ``derived`` is the LIST of names ``pmx_derive`` writes, and the source may use
+    the generated index constants ``P_<param>``, ``D_<derived>``, ``COV_<covariate>``, ``X_<state>``, ``Y_<output>``,
+    ``R_<route>`` the way the macro binds names (tests/test_user_analytical.py re-creates
+    tests/analytical_macro_lowering.rs:225-260 with it)."""
     m = Analytical()
-    if structure not in _abi.ANALYTICAL_KERNELS:
+    if structure is not None and structure not in _abi.ANALYTICAL_KERNELS:
         raise KeyError(f"unknown analytical structure '{structure}'")
-    m.kernel_name = structure
+    m.kernel_name = structure or "custom"
+    user_derived: List[str] = []
+    if source is not None:
+        user_derived = list(derived or [])
+        derived = None
     _declare(m, name, params, derived, covariates, states, outputs, routes, out, init, lag, fa)
+    if source is not None:
+        m.user_derived = user_derived
+        consts = ([f"P_{n} = {i}" for i, n in enumerate(m.params)] + [f"D_{n} = {i}" for i, n in enumerate(user_derived)] +
+                  [f"COV_{n} = {i}" for i, n in enumerate(m.covariates)] + [f"X_{n} = {i}" for i, n in enumerate(m.states)] +
+                  [f"Y_{n} = {i}" for i, n in enumerate(m.outputs)] +
+                  [f"R_{n} = {i}" for n, i in dict((r.name, i) for r, i in m._route_inputs()).items()])
+        prelude = "enum { " + ", ".join(consts) + " };\n"
+        m._set_user_source(prelude + source)
+    if structure is None:
+        if source is None:
+            raise ValueError("no structure and no source")
+        m.cov_time = cov_time
+        return m
     if len(m.states) != _abi.KERNEL_STATE_COUNT[structure]:
         raise ValueError(f"structure {structure} has {_abi.KERNEL_STATE_COUNT[structure]} states, "
                          f"{len(m.states)} declared")
     for n in _abi.KERNEL_PARAMETER_NAMES[structure]:
-        if n not in m.params and n not in m.derived:
+        if n not in m.params and n not in m.derived and n not in m.user_derived:
             raise KeyError(f"structure {structure} requires '{n}' in params or derived")
     if cov_time not in ("segment_dt", "segment_end_abs"):
         raise ValueError("cov_time must be 'segment_dt' or 'segment_end_abs'")

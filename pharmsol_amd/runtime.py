@@ -26,7 +26,9 @@ class DeviceModel:
         self.desc = model.desc() if not isinstance(model, _abi.pmx_model_desc) else model
         h = C.c_void_p()
         src = getattr(model, "source", None)
-        if src is not None:  # user ODE body: compiled for gfx950 with hiprtc inside the library
+        if src is not None and getattr(model, "user_fns", 0):  # user closures of an analytical model (hiprtc)
+            _ffi.check(_ffi.lib().pmx_model_create_user(C.byref(self.desc), src.encode(), int(model.user_fns), C.byref(h)))
+        elif src is not None:  # user ODE body: compiled for gfx950 with hiprtc inside the library
             _ffi.check(_ffi.lib().pmx_model_create_custom(C.byref(self.desc), src.encode(), 1 if model.has_init else 0,
                                                           C.byref(h)))
         else:
@@ -178,7 +180,10 @@ def jit_translation_unit(model) -> str:
     L = _ffi.lib()
     d = model.desc()
     out = C.c_void_p()
-    _ffi.check(L.pmx_debug_jit_source(C.byref(d), model.source.encode(), 1 if model.has_init else 0, C.byref(out)))
+    if getattr(model, "user_fns", 0):
+        _ffi.check(L.pmx_debug_jit_source_user(C.byref(d), model.source.encode(), int(model.user_fns), C.byref(out)))
+    else:
+        _ffi.check(L.pmx_debug_jit_source(C.byref(d), model.source.encode(), 1 if model.has_init else 0, C.byref(out)))
     try:
         return C.cast(out, C.c_char_p).value.decode()
     finally:
