@@ -98,3 +98,27 @@ def test_subject_slices_concatenate_to_the_whole():
         p, _ = oracle.predict(m, sh.local, theta, nthreads=1)
         parts.append(p)
     np.testing.assert_array_equal(np.concatenate(parts, axis=0), want)
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_launches_its_own_ranks_from_the_plain_command_line(scaling):
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts torch.distributed.run itself (before
+    anything touches a GPU) and passes the children's exit code on.  --dry-run = the plumbing without kernels (this box
+    has no GPU): process group, subject sharding, step-count / time reductions, the one JSON line from rank 0."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--scaling", scaling,
+                        "--subjects", "1000", "--support", "8", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dry_run"] is True and d["value"] is None and d["scaling"] == scaling
+    total_subjects = 1000 if scaling == "strong" else 2000
+    assert d["config"]["steps_per_pass"] == total_subjects * 8 * 8  # all ranks' subject-event-steps per pass
+    assert d["config"]["subjects_per_gpu"] == (500 if scaling == "strong" else 1000)
