@@ -244,6 +244,9 @@ int32_t pmx_abi_version(void);
 /* sizeof() of the descriptor structs as the library was built (binding layout check). */
 int64_t pmx_sizeof_model_desc(void);
 int64_t pmx_sizeof_population_desc(void);
+/* sizeof() of any public struct of this header by name ("pmx_model_desc", "pmx_factor", ...); -1 for an unknown name.
+ * Generated bindings (bindings/rust/pmx_sys.rs, pharmsol_amd/_abi.py) are checked against it. */
+int64_t pmx_sizeof_struct(const char* name);
 
 /* Number of visible HIP devices (0 when none). */
 int32_t pmx_device_count(void);
@@ -328,12 +331,24 @@ int32_t pmx_predict_batch_device(const pmx_model* model, const pmx_population* p
  * It does not depend on the support point, so the library evaluates it once per observation on the host;
  * the device folds each prediction into its subject's sum instead of storing it (output S x P doubles
  * instead of S x O x P).  Censored observations (BLOQ/ALOQ) are not in the flattened descriptor yet. */
-enum { PMX_EM_NONE = 0, PMX_EM_ADDITIVE = 1, PMX_EM_PROPORTIONAL = 2 };
+enum {
+  PMX_EM_NONE = 0,
+  PMX_EM_ADDITIVE = 1,      /* AssayErrorModel::additive:     sigma = sqrt(alpha(obs)^2 + lambda^2) */
+  PMX_EM_PROPORTIONAL = 2,  /* AssayErrorModel::proportional: sigma = gamma * alpha(obs) */
+  /* ResidualErrorModel (src/data/residual_error.rs:69-136): sigma from the PREDICTION f, floored at sqrt(f64::EPSILON)
+   * (:178-191); term = -0.5 (ln 2 pi + 2 ln sigma + ((y - f) / sigma)^2) (:265-271); no censoring, no per-observation
+   * polynomial.  What log_likelihood_batch takes (likelihood/mod.rs:119-124).  scalar = a | b | a | sigma, c[0] = b
+   * of the combined model. */
+  PMX_EM_RES_CONSTANT = 3,     /* sigma = a */
+  PMX_EM_RES_PROPORTIONAL = 4, /* sigma = b |f| */
+  PMX_EM_RES_COMBINED = 5,     /* sigma = sqrt(a^2 + b^2 f^2) */
+  PMX_EM_RES_EXPONENTIAL = 6   /* sigma = sigma_exp */
+};
 typedef struct pmx_error_model {
   int32_t kind;   /* PMX_EM_* ; NONE + an observation on that outeq = MissingErrorModel error */
   int32_t reserved;
-  double c[4];    /* ErrorPoly c0..c3 */
-  double scalar;  /* lambda (additive) | gamma (proportional) */
+  double c[4];    /* ErrorPoly c0..c3 (assay models); c[0] = b of PMX_EM_RES_COMBINED */
+  double scalar;  /* lambda (additive) | gamma (proportional) | a / b / sigma of the residual models */
 } pmx_error_model;
 
 /* ---- user ODE models compiled at run time (hiprtc) ---------------------------
@@ -423,6 +438,23 @@ int32_t pmx_loglik(const pmx_model* model, const pmx_population* pop, const pmx_
 int32_t pmx_loglik_device(const pmx_model* model, const pmx_population* pop, const pmx_error_model* em,
                           const double* d_theta, int64_t n_support, double* d_ll, int64_t ld_ll,
                           uint8_t* d_status, void* stream);
+
+/* log_likelihood_batch(eq, &data, &parameters, &error_models) (likelihood/mod.rs:119-177): subject s under ITS OWN
+ * parameter row theta[s] (n_subjects rows); ll[n_subjects], status[n_subjects].  Like the reference, a subject whose
+ * simulation or likelihood fails does not fail the call: its entry is -inf (`Err(_) => f64::NEG_INFINITY`,
+ * likelihood/mod.rs:137-140) and its status byte says why.  The device form leaves NaN in the failed entries (nothing
+ * can be rewritten after the fact on a stream); map status != PMX_PAIR_OK to -inf on the caller's side. */
+int32_t pmx_loglik_batch(const pmx_model* model, const pmx_population* pop, const pmx_error_model* em,
+                         const double* theta, double* ll, uint8_t* status);
+int32_t pmx_loglik_batch_device(const pmx_model* model, const pmx_population* pop, const pmx_error_model* em,
+                                const double* d_theta, double* d_ll, uint8_t* d_status, void* stream);
+
+/* Page-locked host memory for the outputs of the HOST-pointer entry points (pmx_predict, pmx_loglik, ...).  Those entry
+ * points keep their device buffers, streams and staging areas on the population handle between calls; an output array
+ * in page-locked memory (this allocator, hipHostMalloc or hipHostRegister) is filled by one DMA at link rate, a
+ * pageable one goes through pinned bounce buffers (the DMA overlapping the CPU copy; about a quarter of the rate). */
+int32_t pmx_host_alloc(int64_t bytes, void** out);
+void pmx_host_free(void* p);
 
 /* Name of the device kernel family the last pmx_predict* call on this thread launched
  * (for matching rocprofv3 rows). */

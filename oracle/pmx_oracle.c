@@ -1395,6 +1395,15 @@ int32_t pmx_oracle_loglik(const pmx_model_desc* model, const pmx_population_desc
             r = PMX_ERR_ERROR_MODEL;
             break;
           }
+          if (em[q].kind >= PMX_EM_RES_CONSTANT) { /* ResidualErrorModel::log_likelihood, residual_error.rs:178-191,265-271 */
+            double f = pr[k], raw = em[q].scalar;
+            if (em[q].kind == PMX_EM_RES_PROPORTIONAL) raw = em[q].scalar * fabs(f);
+            if (em[q].kind == PMX_EM_RES_COMBINED) raw = sqrt(em[q].scalar * em[q].scalar + (em[q].c[0] * em[q].c[0]) * (f * f));
+            double sg = fmax(raw, sqrt(2.220446049250313e-16));
+            double nr = (y - f) / sg;
+            total += -0.5 * (log(6.283185307179586) + 2.0 * log(sg) + nr * nr);
+            continue;
+          }
           pmx_error_model e = em[q]; /* the observation's own ErrorPoly wins, error_model.rs:1051-1054 */
           if (pop->ev_errorpoly && !isnan(pop->ev_errorpoly[osrc[off[s] + k] * 4]))
             for (int c = 0; c < 4; c++) e.c[c] = pop->ev_errorpoly[osrc[off[s] + k] * 4 + c];

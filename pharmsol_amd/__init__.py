@@ -11,15 +11,16 @@ from .data import (Bolus, Censor, Covariates, Data, Event, Infusion, Observation
                    interpolate)
 from .equation import (ODE, Analytical, Equation, LabelError, Lin, Pow, Ratio, Route, Scaled, analytical, bolus,
                        infusion, ode)
-from .error_model import AssayErrorModel, AssayErrorModels, ErrorPoly
+from .error_model import AssayErrorModel, AssayErrorModels, ErrorPoly, ResidualErrorModel, ResidualErrorModels
 from .flatten import FlatPopulation, flatten
-from .parameters import Parameters
+from .parameters import ParameterError, ParameterOrder, Parameters
 from .pmetrics import DataError, DataRow, build_data, read_pmetrics
-from .predictions import Prediction, SubjectPredictions
+from .predictions import PopulationPredictions, Prediction, SubjectPredictions
 from ._abi import PmxError
 
 __all__ = [
     "Bolus", "Censor", "Covariates", "Data", "DataError", "DataRow", "build_data", "read_pmetrics", "interpolate", "Event", "Infusion", "Observation", "Occasion", "Subject", "SubjectBuilder",
     "ODE", "Analytical", "Equation", "LabelError", "Lin", "Pow", "Ratio", "Route", "Scaled", "analytical", "bolus",
-    "infusion", "ode", "AssayErrorModel", "AssayErrorModels", "ErrorPoly", "FlatPopulation", "flatten", "Parameters", "Prediction", "SubjectPredictions", "PmxError",
+    "infusion", "ode", "AssayErrorModel", "AssayErrorModels", "ErrorPoly", "ResidualErrorModel", "ResidualErrorModels", "FlatPopulation", "flatten",
+    "Parameters", "ParameterOrder", "ParameterError", "Prediction", "SubjectPredictions", "PopulationPredictions", "PmxError",
 ]

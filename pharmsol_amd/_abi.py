@@ -205,6 +205,7 @@ class pmx_model_desc(C.Structure):
 
 
 PMX_EM_NONE, PMX_EM_ADDITIVE, PMX_EM_PROPORTIONAL = 0, 1, 2
+PMX_EM_RES_CONSTANT, PMX_EM_RES_PROPORTIONAL, PMX_EM_RES_COMBINED, PMX_EM_RES_EXPONENTIAL = 3, 4, 5, 6
 
 
 class pmx_error_model(C.Structure):

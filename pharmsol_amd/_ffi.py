@@ -22,6 +22,7 @@ SYMBOLS = [
     ("pmx_abi_version", C.c_int32, []),
     ("pmx_sizeof_model_desc", C.c_int64, []),
     ("pmx_sizeof_population_desc", C.c_int64, []),
+    ("pmx_sizeof_struct", C.c_int64, [C.c_char_p]),
     ("pmx_device_count", C.c_int32, []),
     ("pmx_population_create", C.c_int32, [_PD, C.c_int32, C.POINTER(C.c_void_p)]),
     ("pmx_population_destroy", None, [C.c_void_p]),
@@ -53,6 +54,11 @@ SYMBOLS = [
      [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     ("pmx_loglik_device", C.c_int32,
      [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    ("pmx_loglik_batch", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("pmx_loglik_batch_device", C.c_int32,
+     [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("pmx_host_alloc", C.c_int32, [C.c_int64, C.POINTER(C.c_void_p)]),
+    ("pmx_host_free", None, [C.c_void_p]),
     ("pmx_last_kernel_name", C.c_char_p, []),
     ("pmx_last_error", C.c_char_p, []),
     ("pmx_debug_compile", C.c_int32, [_PD, _MD, C.POINTER(_abi.pmx_op_stream_view)]),

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <limits>
 #include <memory>
 #include <map>
 #include <mutex>
@@ -161,10 +162,42 @@ int ode_nparams(int model) {
 
 }  // namespace
 
+// What the HOST-pointer entry points (pmx_predict, pmx_predict_batch, pmx_loglik, pmx_loglik_batch) keep between
+// calls, per population: device buffers for theta / output / status (grown, never shrunk), a private stream pair and
+// two pinned bounce buffers.  An NPAG loop calls these entry points thousands of times; allocating, page-locking and
+// freeing per call cost ~700x the kernel (profiles/r01_pcie_inclusive.txt).  Calls on one population take turns.
+struct HostWorkspace {
+  std::mutex mu;
+  hipStream_t compute = nullptr, copy = nullptr;
+  void* d_theta = nullptr;
+  void* d_out = nullptr;
+  void* d_status = nullptr;
+  int32_t* d_flag = nullptr;  // "any pair failed" (pmx_status_any)
+  size_t theta_cap = 0, out_cap = 0, status_cap = 0;
+  static constexpr size_t kBounce = 32u << 20;
+  void* bounce[2] = {nullptr, nullptr};
+  hipEvent_t bev[2] = {nullptr, nullptr};
+  int32_t* h_flag = nullptr;  // pinned
+  ~HostWorkspace() {
+    if (d_theta) (void)hipFree(d_theta);
+    if (d_out) (void)hipFree(d_out);
+    if (d_status) (void)hipFree(d_status);
+    if (d_flag) (void)hipFree(d_flag);
+    for (int i = 0; i < 2; ++i) {
+      if (bounce[i]) (void)hipHostFree(bounce[i]);
+      if (bev[i]) (void)hipEventDestroy(bev[i]);
+    }
+    if (h_flag) (void)hipHostFree(h_flag);
+    if (compute) (void)hipStreamDestroy(compute);
+    if (copy) (void)hipStreamDestroy(copy);
+  }
+};
+
 struct pmx_population {
   int device = 0;
   pmx::HostPopulation hp;
   std::mutex mu;
+  std::unique_ptr<HostWorkspace> ws;  // created by the first host-pointer call
   // what the log-likelihood tables are computed from, uploaded at the first pmx_loglik* call
   bool ll_ready = false;
   const double* d_obs_y = nullptr;
@@ -201,6 +234,21 @@ extern "C" {
 int32_t pmx_abi_version(void) { return PMX_ABI_VERSION; }
 int64_t pmx_sizeof_model_desc(void) { return static_cast<int64_t>(sizeof(pmx_model_desc)); }
 int64_t pmx_sizeof_population_desc(void) { return static_cast<int64_t>(sizeof(pmx_population_desc)); }
+int64_t pmx_sizeof_struct(const char* name) {
+  if (!name) return -1;
+#define PMX_SZ(T) \
+  if (std::strcmp(name, #T) == 0) return static_cast<int64_t>(sizeof(T));
+  PMX_SZ(pmx_population_desc)
+  PMX_SZ(pmx_factor)
+  PMX_SZ(pmx_derived)
+  PMX_SZ(pmx_bind)
+  PMX_SZ(pmx_out)
+  PMX_SZ(pmx_model_desc)
+  PMX_SZ(pmx_error_model)
+  PMX_SZ(pmx_op_stream_view)
+#undef PMX_SZ
+  return -1;
+}
 
 int32_t pmx_device_count(void) {
   int n = 0;
@@ -240,6 +288,7 @@ void pmx_population_destroy(pmx_population* pop) {
     DeviceGuard g;
     (void)g.enter(pop->device);
     pop->streams.clear();
+    pop->ws.reset();
   }
   delete pop;
 }
@@ -760,7 +809,7 @@ int32_t acquire_ll_slot(const pmx_model* model, pmx_population* pop, DeviceStrea
   for (int q = 0; q < 32; ++q) {
     if (!((pop->valued_outeq_mask >> q) & 1u)) continue;
     if (q >= nout) return fail(PMX_ERR_OUTEQ_OUT_OF_RANGE, "observation outeq >= nout");
-    if (em[q].kind != PMX_EM_ADDITIVE && em[q].kind != PMX_EM_PROPORTIONAL)
+    if (em[q].kind < PMX_EM_ADDITIVE || em[q].kind > PMX_EM_RES_EXPONENTIAL)
       return fail(PMX_ERR_ERROR_MODEL, "MissingErrorModel: output " + std::to_string(q) + " has observations but no error model");
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -934,6 +983,8 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
     a.cls.chunk_obs_off = ds->d_chunk_obs_off;
     if (llreq->d_sigma_err) *llreq->d_sigma_err = slot->d_err;
     a.ll_censored = pop->any_censored ? 1 : 0;  // (known once the population's observation arrays are on the device)
+    for (int q = 0; q < d.nout && q < PMX_MAX_OUT; ++q)
+      if (llreq->em[q].kind >= PMX_EM_RES_CONSTANT) a.ll_censored = 1;  // residual models fold from the full records too
   }
   // GRID (lane = support point, wave-uniform op stream) vs PAIR (lane = pair, divergent streams): measured crossovers
   // (tools/pairgrid_sweep.sh) are 8 support points when the classed kernel serves most subjects, ~48 when every
@@ -1013,6 +1064,110 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
   return PMX_OK;
 }
 
+// ---- host-pointer forms -------------------------------------------------------------------------------------------
+int32_t ws_get(pmx_population* pop, HostWorkspace** out) {
+  std::lock_guard<std::mutex> lock(pop->mu);
+  if (!pop->ws) {
+    auto ws = std::make_unique<HostWorkspace>();
+    PMX_HIP(hipStreamCreateWithFlags(&ws->compute, hipStreamNonBlocking));
+    PMX_HIP(hipStreamCreateWithFlags(&ws->copy, hipStreamNonBlocking));
+    PMX_HIP(hipMalloc(reinterpret_cast<void**>(&ws->d_flag), sizeof(int32_t)));
+    PMX_HIP(hipHostMalloc(reinterpret_cast<void**>(&ws->h_flag), sizeof(int32_t), hipHostMallocDefault));
+    for (int i = 0; i < 2; ++i) {
+      PMX_HIP(hipHostMalloc(&ws->bounce[i], HostWorkspace::kBounce, hipHostMallocDefault));
+      PMX_HIP(hipEventCreateWithFlags(&ws->bev[i], hipEventDisableTiming));
+    }
+    pop->ws = std::move(ws);
+  }
+  *out = pop->ws.get();
+  return PMX_OK;
+}
+
+int32_t ws_reserve(void** p, size_t* cap, size_t need) {
+  if (need <= *cap && *p) return PMX_OK;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr;
+  *cap = 0;
+  const size_t want = need > 0 ? ((need + (1u << 20) - 1) >> 20) << 20 : (1u << 20);  // whole MiB
+  PMX_HIP(hipMalloc(p, want));
+  *cap = want;
+  return PMX_OK;
+}
+
+bool is_pinned_host(const void* p) {
+  hipPointerAttribute_t a{};
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();  // (an ordinary malloc'ed pointer: "invalid value", not an error of ours)
+    return false;
+  }
+  return a.type == hipMemoryTypeHost;
+}
+
+// rows x row_bytes from a dense device buffer to host rows `dst_pitch` apart, after everything enqueued on ws->compute.
+// Page-locked destinations (pmx_host_alloc, hipHostMalloc, hipHostRegister) take ONE DMA at link rate; pageable ones go
+// through the two pinned bounce buffers, the DMA of one piece overlapping the CPU copy of the previous one.
+int32_t ws_copy_out(HostWorkspace* ws, void* dst, size_t dst_pitch, const void* src, size_t row_bytes, size_t rows) {
+  if (rows == 0 || row_bytes == 0) {
+    PMX_HIP(hipStreamSynchronize(ws->compute));
+    return PMX_OK;
+  }
+  if (is_pinned_host(dst)) {
+    if (dst_pitch == row_bytes)
+      PMX_HIP(hipMemcpyAsync(dst, src, row_bytes * rows, hipMemcpyDeviceToHost, ws->compute));
+    else
+      PMX_HIP(hipMemcpy2DAsync(dst, dst_pitch, src, row_bytes, row_bytes, rows, hipMemcpyDeviceToHost, ws->compute));
+    PMX_HIP(hipStreamSynchronize(ws->compute));
+    return PMX_OK;
+  }
+  PMX_HIP(hipStreamSynchronize(ws->compute));
+  const size_t total = row_bytes * rows;
+  const size_t piece = HostWorkspace::kBounce;
+  const size_t n_pieces = (total + piece - 1) / piece;
+  auto land = [&](size_t k) {  // bounce[k % 2] -> the caller's rows
+    const size_t off = k * piece, len = (off + piece <= total) ? piece : total - off;
+    const char* b = static_cast<const char*>(ws->bounce[k % 2]);
+    if (dst_pitch == row_bytes) {
+      std::memcpy(static_cast<char*>(dst) + off, b, len);
+      return;
+    }
+    size_t done = 0;
+    while (done < len) {  // split at row ends
+      const size_t at = off + done, r = at / row_bytes, c = at % row_bytes;
+      const size_t n = (row_bytes - c < len - done) ? row_bytes - c : len - done;
+      std::memcpy(static_cast<char*>(dst) + r * dst_pitch + c, b + done, n);
+      done += n;
+    }
+  };
+  for (size_t k = 0; k < n_pieces; ++k) {
+    const size_t off = k * piece, len = (off + piece <= total) ? piece : total - off;
+    PMX_HIP(hipMemcpyAsync(ws->bounce[k % 2], static_cast<const char*>(src) + off, len, hipMemcpyDeviceToHost, ws->copy));
+    PMX_HIP(hipEventRecord(ws->bev[k % 2], ws->copy));
+    if (k > 0) {
+      PMX_HIP(hipEventSynchronize(ws->bev[(k - 1) % 2]));
+      land(k - 1);
+    }
+  }
+  PMX_HIP(hipEventSynchronize(ws->bev[(n_pieces - 1) % 2]));
+  land(n_pieces - 1);
+  return PMX_OK;
+}
+
+// the per-pair status bytes: "did any pair fail" comes back as ONE flag reduced on the device (the array itself is only
+// copied when the caller asked for it: 100 MB for C3)
+int32_t ws_finish_status(HostWorkspace* ws, uint8_t* status, size_t n_status, bool* any_failed) {
+  PMX_HIP(hipMemsetAsync(ws->d_flag, 0, sizeof(int32_t), ws->compute));
+  PMX_HIP(pmx::launch_status_any(static_cast<const uint8_t*>(ws->d_status), static_cast<int64_t>(n_status), ws->d_flag, ws->compute));
+  PMX_HIP(hipMemcpyAsync(ws->h_flag, ws->d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, ws->compute));
+  if (status) {
+    const int32_t rc = ws_copy_out(ws, status, n_status, ws->d_status, n_status, 1);
+    if (rc != PMX_OK) return rc;
+  } else {
+    PMX_HIP(hipStreamSynchronize(ws->compute));
+  }
+  *any_failed = *ws->h_flag != 0;
+  return PMX_OK;
+}
+
 int32_t predict_host(const pmx_model* model, const pmx_population* cpop, const double* theta, int64_t P, int batch,
                      double* pred, int64_t ld, uint8_t* status) {
   g_err.clear();
@@ -1022,37 +1177,82 @@ int32_t predict_host(const pmx_model* model, const pmx_population* cpop, const d
   if (!batch && (P <= 0 || ld < P)) return fail(PMX_ERR_INVALID_ARGUMENT, "n_support must be > 0 and ld_pred >= n_support");
   DeviceGuard g;
   PMX_HIP(g.enter(pop->device));
-  const int64_t rows_theta = batch ? S : P;
-  const int64_t ldp = batch ? 1 : ld;
-  const int64_t n_status = batch ? S : S * P;
-  double *d_theta = nullptr, *d_pred = nullptr;
-  uint8_t* d_status = nullptr;
-  struct Free {
-    void** p;
-    ~Free() {
-      if (*p) (void)hipFree(*p);
-    }
-  };
-  Free f1{reinterpret_cast<void**>(&d_theta)}, f2{reinterpret_cast<void**>(&d_pred)},
-      f3{reinterpret_cast<void**>(&d_status)};
-  const size_t theta_bytes = static_cast<size_t>(rows_theta) * model->d.nparams * sizeof(double);
-  const size_t pred_bytes = static_cast<size_t>(NO) * ldp * sizeof(double);
-  PMX_HIP(hipMalloc(reinterpret_cast<void**>(&d_theta), theta_bytes > 0 ? theta_bytes : 8));
-  PMX_HIP(hipMalloc(reinterpret_cast<void**>(&d_pred), pred_bytes > 0 ? pred_bytes : 8));
-  PMX_HIP(hipMalloc(reinterpret_cast<void**>(&d_status), n_status > 0 ? n_status : 8));
-  PMX_HIP(hipMemcpy(d_theta, theta, theta_bytes, hipMemcpyHostToDevice));
-  if (ldp != P && !batch) PMX_HIP(hipMemcpy(d_pred, pred, pred_bytes, hipMemcpyHostToDevice));  // keep the caller's padding
-  PMX_HIP(hipMemset(d_status, 0, n_status > 0 ? n_status : 1));
-  int32_t rc = enqueue(model, pop, d_theta, P, batch, d_pred, ldp, d_status, nullptr);
+  HostWorkspace* ws = nullptr;
+  int32_t rc = ws_get(pop, &ws);
   if (rc != PMX_OK) return rc;
-  PMX_HIP(hipDeviceSynchronize());
-  PMX_HIP(hipMemcpy(pred, d_pred, pred_bytes, hipMemcpyDeviceToHost));
-  std::vector<uint8_t> hst(static_cast<size_t>(n_status));
-  PMX_HIP(hipMemcpy(hst.data(), d_status, static_cast<size_t>(n_status), hipMemcpyDeviceToHost));
-  if (status) std::memcpy(status, hst.data(), hst.size());
-  for (uint8_t s : hst)
-    if (s != PMX_PAIR_OK)
-      return fail(PMX_ERR_PAIR_FAILED, "at least one (subject, support point) pair failed; see the status array");
+  std::lock_guard<std::mutex> turn(ws->mu);
+  const int64_t rows_theta = batch ? S : P;
+  const int64_t Pd = batch ? 1 : P;  // the device matrix is dense; the caller's padding columns are never touched
+  const size_t n_status = static_cast<size_t>(batch ? S : S * P);
+  const size_t theta_bytes = static_cast<size_t>(rows_theta) * model->d.nparams * sizeof(double);
+  const size_t pred_bytes = static_cast<size_t>(NO) * Pd * sizeof(double);
+  if ((rc = ws_reserve(&ws->d_theta, &ws->theta_cap, theta_bytes)) != PMX_OK) return rc;
+  if ((rc = ws_reserve(&ws->d_out, &ws->out_cap, pred_bytes)) != PMX_OK) return rc;
+  if ((rc = ws_reserve(&ws->d_status, &ws->status_cap, n_status)) != PMX_OK) return rc;
+  PMX_HIP(hipMemcpyAsync(ws->d_theta, theta, theta_bytes, hipMemcpyHostToDevice, ws->compute));
+  if (n_status > 0) PMX_HIP(hipMemsetAsync(ws->d_status, 0, n_status, ws->compute));
+  rc = enqueue(model, pop, static_cast<const double*>(ws->d_theta), P, batch, static_cast<double*>(ws->d_out), Pd,
+               static_cast<uint8_t*>(ws->d_status), ws->compute);
+  if (rc != PMX_OK) return rc;
+  bool any_failed = false;
+  if ((rc = ws_finish_status(ws, status, n_status, &any_failed)) != PMX_OK) return rc;
+  if ((rc = ws_copy_out(ws, pred, static_cast<size_t>(batch ? 1 : ld) * sizeof(double), ws->d_out,
+                        static_cast<size_t>(Pd) * sizeof(double), static_cast<size_t>(NO))) != PMX_OK)
+    return rc;
+  if (any_failed)
+    return fail(PMX_ERR_PAIR_FAILED, "at least one (subject, support point) pair failed; see the status array");
+  return PMX_OK;
+}
+
+// ll[s][p] (matrix shape) or ll[s] (batch shape: subject s with theta row s, likelihood/mod.rs:119-177)
+int32_t loglik_host(const pmx_model* model, const pmx_population* cpop, const pmx_error_model* em, const double* theta,
+                    int64_t P, int batch, double* ll, int64_t ld_ll, uint8_t* status) {
+  pmx_population* pop = const_cast<pmx_population*>(cpop);
+  const int64_t S = pop->hp.n_subjects;
+  DeviceGuard g;
+  PMX_HIP(g.enter(pop->device));
+  HostWorkspace* ws = nullptr;
+  int32_t rc = ws_get(pop, &ws);
+  if (rc != PMX_OK) return rc;
+  std::lock_guard<std::mutex> turn(ws->mu);
+  const int64_t Pd = batch ? 1 : P;
+  const size_t theta_bytes = static_cast<size_t>(batch ? S : P) * model->d.nparams * sizeof(double);
+  const size_t ll_bytes = static_cast<size_t>(S) * Pd * sizeof(double);
+  const size_t n_status = static_cast<size_t>(S) * Pd;
+  if ((rc = ws_reserve(&ws->d_theta, &ws->theta_cap, theta_bytes)) != PMX_OK) return rc;
+  if ((rc = ws_reserve(&ws->d_out, &ws->out_cap, ll_bytes)) != PMX_OK) return rc;
+  if ((rc = ws_reserve(&ws->d_status, &ws->status_cap, n_status)) != PMX_OK) return rc;
+  PMX_HIP(hipMemcpyAsync(ws->d_theta, theta, theta_bytes, hipMemcpyHostToDevice, ws->compute));
+  if (n_status > 0) PMX_HIP(hipMemsetAsync(ws->d_status, 0, n_status, ws->compute));
+  const int32_t* d_sigma_err = nullptr;
+  LLRequest req{em, static_cast<double*>(ws->d_out), Pd, &d_sigma_err};
+  rc = enqueue(model, pop, static_cast<const double*>(ws->d_theta), P, batch, static_cast<double*>(ws->d_out), Pd,
+               static_cast<uint8_t*>(ws->d_status), ws->compute, &req);
+  if (rc != PMX_OK) return rc;
+  if (d_sigma_err) {  // ErrorModelError::NegativeSigma / NonFiniteSigma (error_model.rs:1073-1077), found on the device
+    PMX_HIP(hipMemcpyAsync(ws->h_flag, d_sigma_err, sizeof(int32_t), hipMemcpyDeviceToHost, ws->compute));
+    PMX_HIP(hipStreamSynchronize(ws->compute));
+    const int32_t n_bad = *ws->h_flag;
+    if (n_bad > 0)
+      return fail(PMX_ERR_ERROR_MODEL, "NegativeSigma / NonFiniteSigma for " + std::to_string(n_bad) + " observation(s)");
+  }
+  bool any_failed = false;
+  if ((rc = ws_finish_status(ws, status, n_status, &any_failed)) != PMX_OK) return rc;
+  if ((rc = ws_copy_out(ws, ll, static_cast<size_t>(batch ? 1 : ld_ll) * sizeof(double), ws->d_out,
+                        static_cast<size_t>(Pd) * sizeof(double), static_cast<size_t>(S))) != PMX_OK)
+    return rc;
+  if (any_failed) {
+    if (batch) {
+      // log_likelihood_batch maps a failed subject to -inf instead of failing the call (likelihood/mod.rs:137-140):
+      // the status array names them, the caller's row is overwritten here
+      std::vector<uint8_t> hst(n_status);
+      PMX_HIP(hipMemcpy(hst.data(), ws->d_status, n_status, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < n_status; ++i)
+        if (hst[i] != PMX_PAIR_OK) ll[i] = -std::numeric_limits<double>::infinity();
+      return PMX_OK;
+    }
+    return fail(PMX_ERR_PAIR_FAILED, "at least one (subject, support point) pair failed; see the status array");
+  }
   return PMX_OK;
 }
 
@@ -1239,45 +1439,39 @@ int32_t pmx_loglik(const pmx_model* model, const pmx_population* cpop, const pmx
   g_err.clear();
   if (!model || !cpop || !em || !theta || !ll) return fail(PMX_ERR_INVALID_ARGUMENT, "null argument");
   if (n_support <= 0 || ld_ll < n_support) return fail(PMX_ERR_INVALID_ARGUMENT, "n_support must be > 0 and ld_ll >= n_support");
+  return loglik_host(model, cpop, em, theta, n_support, 0, ll, ld_ll, status);
+}
+
+int32_t pmx_loglik_batch(const pmx_model* model, const pmx_population* cpop, const pmx_error_model* em, const double* theta,
+                         double* ll, uint8_t* status) {
+  g_err.clear();
+  if (!model || !cpop || !em || !theta || !ll) return fail(PMX_ERR_INVALID_ARGUMENT, "null argument");
+  return loglik_host(model, cpop, em, theta, 1, 1, ll, 1, status);
+}
+
+int32_t pmx_loglik_batch_device(const pmx_model* model, const pmx_population* cpop, const pmx_error_model* em,
+                                const double* d_theta, double* d_ll, uint8_t* d_status, void* stream) {
+  g_err.clear();
+  if (!model || !cpop || !em || !d_theta || !d_ll) return fail(PMX_ERR_INVALID_ARGUMENT, "null argument");
   pmx_population* pop = const_cast<pmx_population*>(cpop);
-  const int64_t S = pop->hp.n_subjects;
   DeviceGuard g;
   PMX_HIP(g.enter(pop->device));
-  double *d_theta = nullptr, *d_ll = nullptr;
-  uint8_t* d_status = nullptr;
-  struct Free {
-    void** p;
-    ~Free() {
-      if (*p) (void)hipFree(*p);
-    }
-  };
-  Free f1{reinterpret_cast<void**>(&d_theta)}, f2{reinterpret_cast<void**>(&d_ll)}, f3{reinterpret_cast<void**>(&d_status)};
-  const size_t theta_bytes = static_cast<size_t>(n_support) * model->d.nparams * sizeof(double);
-  const size_t ll_bytes = static_cast<size_t>(S) * ld_ll * sizeof(double);
-  const size_t st_bytes = static_cast<size_t>(S) * n_support;
-  PMX_HIP(hipMalloc(reinterpret_cast<void**>(&d_theta), theta_bytes > 0 ? theta_bytes : 8));
-  PMX_HIP(hipMalloc(reinterpret_cast<void**>(&d_ll), ll_bytes > 0 ? ll_bytes : 8));
-  PMX_HIP(hipMalloc(reinterpret_cast<void**>(&d_status), st_bytes > 0 ? st_bytes : 8));
-  PMX_HIP(hipMemcpy(d_theta, theta, theta_bytes, hipMemcpyHostToDevice));
-  PMX_HIP(hipMemcpy(d_ll, ll, ll_bytes, hipMemcpyHostToDevice));  // keeps the caller's padding columns
-  const int32_t* d_sigma_err = nullptr;
-  LLRequest req{em, d_ll, ld_ll, &d_sigma_err};
-  int32_t rc = enqueue(model, pop, d_theta, n_support, 0, d_ll, ld_ll, d_status, nullptr, &req);
-  if (rc != PMX_OK) return rc;
-  PMX_HIP(hipDeviceSynchronize());
-  if (d_sigma_err) {  // ErrorModelError::NegativeSigma / NonFiniteSigma (error_model.rs:1073-1077), found on the device
-    int32_t n_bad = 0;
-    PMX_HIP(hipMemcpy(&n_bad, d_sigma_err, sizeof n_bad, hipMemcpyDeviceToHost));
-    if (n_bad > 0)
-      return fail(PMX_ERR_ERROR_MODEL, "NegativeSigma / NonFiniteSigma for " + std::to_string(n_bad) + " observation(s)");
-  }
-  PMX_HIP(hipMemcpy(ll, d_ll, ll_bytes, hipMemcpyDeviceToHost));
-  std::vector<uint8_t> hst(st_bytes);
-  PMX_HIP(hipMemcpy(hst.data(), d_status, st_bytes, hipMemcpyDeviceToHost));
-  if (status) std::memcpy(status, hst.data(), hst.size());
-  for (uint8_t s : hst)
-    if (s != PMX_PAIR_OK) return fail(PMX_ERR_PAIR_FAILED, "at least one (subject, support point) pair failed; see the status array");
+  LLRequest req{em, d_ll, 1};
+  return enqueue(model, pop, d_theta, 1, 1, d_ll, 1, d_status, stream, &req);
+}
+
+int32_t pmx_host_alloc(int64_t bytes, void** out) {
+  g_err.clear();
+  if (!out || bytes < 0) return fail(PMX_ERR_INVALID_ARGUMENT, "bad argument");
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(PMX_ERR_NO_DEVICE, "no HIP device visible");
+  PMX_HIP(hipHostMalloc(out, static_cast<size_t>(bytes > 0 ? bytes : 1), hipHostMallocDefault));
   return PMX_OK;
+}
+
+void pmx_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
 }
 
 }  // extern "C"

@@ -160,11 +160,25 @@ __device__ __noinline__ double ll_censored_term(double obs, double y, double pdf
   return (sf > 0.0) ? log(sf) : ((z > 37.0) ? pdf - log(z) : nanv);
 }
 
+// ResidualErrorModel::log_likelihood (src/data/residual_error.rs:178-191,265-271): sigma from the PREDICTION, floored at
+// sqrt(f64::EPSILON).  Out of line like the censored term (rare: parametric-algorithm callers, log_likelihood_batch).
+// kind = PMX_EM_RES_*; a = `scalar`, b = c[0].
+__device__ __noinline__ double ll_residual_term(double obs, double y, double a, double b, int kind) {
+  double raw = a;                                                     // constant | exponential
+  if (kind == PMX_EM_RES_PROPORTIONAL) raw = a * fabs(y);             // b |f|  (b travels in `a`)
+  if (kind == PMX_EM_RES_COMBINED) raw = sqrt(a * a + (b * b) * (y * y));
+  const double sigma = fmax(raw, 1.4901161193847656e-08);
+  const double z = (obs - y) / sigma;
+  return -0.5 * (1.8378770664093453 + 2.0 * log(sigma) + z * z);
+}
+
 // (Q = const double* for per-lane rows, cptr<double> where the row is wave-uniform: scalar fetches)
 template <class Q>
 __device__ __forceinline__ void ll_accumulate(Q q, double y, double& acc) {
   const double w = q[2];
-  if (w != 0.0) {  // weight 0 = missing observation: contributes 0 whatever the prediction (prediction.rs:107-111)
+  if (w < 0.0) {  // residual (prediction-based) error model: {obs, a, -kind, b}
+    acc += ll_residual_term(q[0], y, q[1], q[3], static_cast<int>(-w));
+  } else if (w != 0.0) {  // weight 0 = missing observation: contributes 0 whatever the prediction (prediction.rs:107-111)
     const double d = q[0] - y;
     const double pdf = q[1] - (d * d) * w;
     const double cs = q[3];

@@ -1146,6 +1146,13 @@ __global__ __launch_bounds__(256) void pmx_ll_prepare_obs(LLPrepareArgs a) {
         c3 = a.obs_poly[r * 4 + 3];
       }
     }
+    if (e.kind >= PMX_EM_RES_CONSTANT) {  // residual models: the fold derives sigma from the prediction (ll_residual_term)
+      a.obs4[r * 4 + 0] = y;
+      a.obs4[r * 4 + 1] = e.scalar;
+      a.obs4[r * 4 + 2] = -static_cast<double>(e.kind);
+      a.obs4[r * 4 + 3] = e.c[0];
+      return;
+    }
     const double alpha = c0 + c1 * y + c2 * (y * y) + c3 * (y * y * y);
     const double sigma = (e.kind == PMX_EM_ADDITIVE) ? sqrt(alpha * alpha + e.scalar * e.scalar) : e.scalar * alpha;
     const int cz = a.obs_cens != nullptr ? a.obs_cens[r] : 0;
@@ -1181,7 +1188,7 @@ __global__ __launch_bounds__(256) void pmx_ll_prepare_chunks(LLPrepareArgs a) {
       v = rec[f];
       // a censored row (BLOQ / ALOQ): its weight slot carries -1 as a marker, the kernel then takes the row's full
       // record {value, const, weight, censor scale} from obs4 (rare, out of the main path)
-      if (f == 2 && rec[3] != 0.0 && v == v) v = -1.0;
+      if (f == 2 && (rec[3] != 0.0 || rec[2] < 0.0) && v == v) v = -1.0;  // (or a residual-model row: same detour)
     }
     a.cobs[base + i] = v;
   }
@@ -1198,6 +1205,31 @@ hipError_t launch_ll_prepare(const LLPrepareArgs& a) {
   if (a.n_chunks > 0) {
     hipLaunchKernelGGL(pmx_ll_prepare_chunks, dim3(static_cast<uint32_t>(a.n_chunks)), dim3(256), 0, st, a);
   }
+  return hipGetLastError();
+}
+
+namespace {
+// any non-zero status byte -> *flag = 1 (16 bytes per lane per trip; n is tens of MB at most)
+__global__ __launch_bounds__(256) void pmx_status_any(const uint8_t* __restrict__ st, int64_t n, int32_t* __restrict__ flag) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * 256 * 16;
+  uint32_t acc = 0;
+  for (int64_t i = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) * 16; i < n; i += stride) {
+    if (i + 16 <= n && (reinterpret_cast<uintptr_t>(st + i) & 15u) == 0) {
+      const uint4 v = *reinterpret_cast<const uint4*>(st + i);
+      acc |= v.x | v.y | v.z | v.w;
+    } else {
+      for (int64_t j = i; j < n && j < i + 16; ++j) acc |= st[j];
+    }
+  }
+  if (__any(acc != 0u ? 1 : 0) && (threadIdx.x & 63u) == 0u) atomicOr(flag, 1);
+}
+}  // namespace
+
+hipError_t launch_status_any(const uint8_t* d_status, int64_t n, int32_t* d_flag, void* stream) {
+  if (n <= 0) return hipSuccess;
+  int64_t blocks = (n + 256 * 16 - 1) / (256 * 16);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(pmx_status_any, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream), d_status, n, d_flag);
   return hipGetLastError();
 }
 

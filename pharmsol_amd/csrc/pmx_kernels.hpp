@@ -90,6 +90,9 @@ struct LLPrepareArgs {
 };
 hipError_t launch_ll_prepare(const LLPrepareArgs& a);
 
+// *d_flag |= 1 iff any of the n status bytes is non-zero (the host forms' "did any pair fail", without copying the array)
+hipError_t launch_status_any(const uint8_t* d_status, int64_t n, int32_t* d_flag, void* stream);
+
 // Enqueue the prediction kernel; *name receives a static string naming the kernel family.
 hipError_t launch_predict(const LaunchArgs& a, const char** name);
 

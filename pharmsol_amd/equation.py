@@ -292,14 +292,59 @@ class Equation:
     def flatten(self, data) -> FlatPopulation:
         return flatten(self, data)
 
-    def estimate_predictions(self, subject: Subject, parameters) -> SubjectPredictions:
+    def estimate_predictions(self, subject: Subject, parameters, with_state: bool = False) -> SubjectPredictions:
         """``Equation::estimate_predictions`` (equation/mod.rs:526-532) for one subject and one
-        support point, on the GPU."""
+        support point, on the GPU.  ``with_state``: also fill ``Prediction.state`` (the reference records the state
+        vector beside every prediction, analytical/mod.rs:401; here one extra device pass per state)."""
         theta = parameters.as_slice() if isinstance(parameters, Parameters) else np.asarray(parameters, dtype=np.float64)
         flat = self.flatten(subject)
         from . import runtime
         pred, status = runtime.predict_host(self, flat, theta.reshape(1, -1))
-        return SubjectPredictions.from_flat(subject, self, pred[:, 0])
+        states = None
+        if with_state:
+            pop = runtime.DevicePopulation(flat, 0)
+            states = runtime.predict_states(self, pop, theta.reshape(1, -1))[:, :, 0].cpu().numpy()
+        return SubjectPredictions.from_flat(subject, self, pred[:, 0], states)
+
+    def estimate_log_likelihood(self, subject: Subject, parameters, error_models) -> float:
+        """``Equation::estimate_log_likelihood`` (equation/mod.rs:468-477, 534-547): the subject's summed log-likelihood
+        under one support point (fused on the device: the predictions are never stored).  A failed pair raises, like the
+        reference's ``Err``."""
+        theta = parameters.as_slice() if isinstance(parameters, Parameters) else np.asarray(parameters, dtype=np.float64)
+        from . import runtime
+        ll, _ = runtime.loglik_host(self, self.flatten(subject), error_models, theta.reshape(1, -1), raise_on_pair_failure=True)
+        return float(ll[0, 0])
+
+    def simulate_subject(self, subject: Subject, parameters, error_models=None):
+        """``Equation::simulate_subject`` (equation/mod.rs:569-576): ``(predictions, Some(likelihood) | None)`` - the
+        likelihood is the PRODUCT of the observations' likelihoods (equation/mod.rs:514, analytical/mod.rs:403-405)."""
+        import math
+
+        preds = self.estimate_predictions(subject, parameters)
+        if error_models is None:
+            return preds, None
+        return preds, math.exp(self.estimate_log_likelihood(subject, parameters, error_models))
+
+    def population_predictions(self, data, theta: np.ndarray):
+        """Every subject x every support point as the reference's ``PopulationPredictions`` (subject.rs:140-165), from one
+        device pass."""
+        from .predictions import PopulationPredictions
+
+        flat = self.flatten(data)
+        pred, _ = self.estimate_predictions_matrix(flat, theta)
+        return PopulationPredictions.from_matrix(data, self, pred, flat.observation_offsets())
+
+    def log_likelihood_batch(self, data, parameters: np.ndarray, residual_error_models) -> np.ndarray:
+        """``log_likelihood_batch(&eq, &data, &parameters, &residual_error_models)`` (likelihood/mod.rs:119-177): subject
+        i under parameter row i, sigma from the prediction; a subject that fails scores ``-inf`` (:137-140)."""
+        flat = data if isinstance(data, FlatPopulation) else self.flatten(data)
+        parameters = np.ascontiguousarray(parameters, dtype=np.float64)
+        if parameters.ndim != 2 or parameters.shape[0] != flat.n_subjects:
+            raise ValueError(f"parameters has {parameters.shape[0] if parameters.ndim == 2 else '?'} rows but there are "
+                             f"{flat.n_subjects} subjects")
+        from . import runtime
+        ll, _ = runtime.loglik_batch_host(self, flat, residual_error_models, parameters)
+        return ll
 
     def estimate_predictions_matrix(self, data, theta: np.ndarray):
         """All subjects x all support points (likelihood/matrix.rs:79-98 loop nest).

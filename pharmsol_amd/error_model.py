@@ -70,3 +70,69 @@ class AssayErrorModels:
             arr[idx].c[0], arr[idx].c[1], arr[idx].c[2], arr[idx].c[3] = em.poly.c0, em.poly.c1, em.poly.c2, em.poly.c3
             arr[idx].scalar = em.scalar
         return arr
+
+
+@dataclass(frozen=True)
+class ResidualErrorModel:
+    """``ResidualErrorModel`` (src/data/residual_error.rs:69-136): sigma from the PREDICTION ``f`` - what the parametric
+    algorithms and ``log_likelihood_batch`` (likelihood/mod.rs:119-177) use.  The library evaluates
+    ``sigma(f)`` (:178-191, floored at sqrt(f64::EPSILON)) and ``log_likelihood`` (:265-271) inside the fused kernel."""
+    kind: int
+    a: float
+    b: float = 0.0
+
+    @staticmethod
+    def constant(a: float) -> "ResidualErrorModel":
+        """sigma = a"""
+        return ResidualErrorModel(_abi.PMX_EM_RES_CONSTANT, float(a))
+
+    @staticmethod
+    def proportional(b: float) -> "ResidualErrorModel":
+        """sigma = b |f|"""
+        return ResidualErrorModel(_abi.PMX_EM_RES_PROPORTIONAL, float(b))
+
+    @staticmethod
+    def combined(a: float, b: float) -> "ResidualErrorModel":
+        """sigma = sqrt(a^2 + b^2 f^2)"""
+        return ResidualErrorModel(_abi.PMX_EM_RES_COMBINED, float(a), float(b))
+
+    @staticmethod
+    def exponential(sigma: float) -> "ResidualErrorModel":
+        """sigma = sigma_exp"""
+        return ResidualErrorModel(_abi.PMX_EM_RES_EXPONENTIAL, float(sigma))
+
+    def sigma(self, prediction: float) -> float:
+        import math
+
+        raw = {_abi.PMX_EM_RES_CONSTANT: self.a, _abi.PMX_EM_RES_PROPORTIONAL: self.a * abs(prediction),
+               _abi.PMX_EM_RES_COMBINED: math.sqrt(self.a ** 2 + self.b ** 2 * prediction ** 2),
+               _abi.PMX_EM_RES_EXPONENTIAL: self.a}[self.kind]
+        return max(raw, math.sqrt(2.220446049250313e-16))
+
+
+class ResidualErrorModels:
+    """``ResidualErrorModels::new().add(outeq, model)`` (residual_error.rs:341-359)."""
+
+    def __init__(self):
+        self._m: Dict[int, ResidualErrorModel] = {}
+
+    @staticmethod
+    def new() -> "ResidualErrorModels":
+        return ResidualErrorModels()
+
+    def add(self, outeq: int, model: ResidualErrorModel) -> "ResidualErrorModels":
+        self._m[int(outeq)] = model
+        return self
+
+    def to_c(self, equation):
+        nout = equation.desc().nout
+        arr = (_abi.pmx_error_model * max(nout, 1))()
+        for i in range(nout):
+            arr[i].kind = _abi.PMX_EM_NONE
+        for idx, em in self._m.items():
+            if idx >= nout:
+                raise _abi.PmxError(_abi.PMX_ERR_OUTEQ_OUT_OF_RANGE, f"error model for outeq {idx} >= nout {nout}")
+            arr[idx].kind = em.kind
+            arr[idx].scalar = em.a
+            arr[idx].c[0] = em.b
+        return arr

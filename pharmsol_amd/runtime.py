@@ -280,6 +280,38 @@ def loglik_host(model, flat: FlatPopulation, error_models, theta: np.ndarray, de
     return ll, status
 
 
+def loglik_batch_host(model, flat: FlatPopulation, error_models, theta: np.ndarray, device: int = 0
+                      ) -> Tuple[np.ndarray, np.ndarray]:
+    """Host-pointer batch form (``pmx_loglik_batch``): subject s under theta row s; ``(ll[S], status[S])``, failed
+    subjects = -inf (likelihood/mod.rs:137-140)."""
+    L = _ffi.lib()
+    dm = _as_model(model)
+    pop = DevicePopulation(flat, device)
+    theta = np.ascontiguousarray(theta, dtype=np.float64)
+    assert theta.shape == (pop.n_subjects, dm.desc.nparams)
+    em = error_models.to_c(model)
+    ll = np.full((pop.n_subjects,), np.nan)
+    status = np.zeros((pop.n_subjects,), dtype=np.uint8)
+    _ffi.check(L.pmx_loglik_batch(dm.handle, pop.handle, C.cast(em, C.c_void_p), theta.ctypes.data, ll.ctypes.data,
+                                  status.ctypes.data))
+    return ll, status
+
+
+def host_empty(shape, dtype=np.float64) -> np.ndarray:
+    """A numpy array in page-locked host memory (``pmx_host_alloc``): outputs of the host-pointer entry points land in
+    it by one DMA at link rate instead of going through bounce buffers.  The memory lives as long as the array."""
+    import weakref
+
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape)) * dtype.itemsize
+    p = C.c_void_p()
+    _ffi.check(_ffi.lib().pmx_host_alloc(n, C.byref(p)))
+    buf = (C.c_char * max(n, 1)).from_address(p.value)
+    arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+    weakref.finalize(buf, _ffi.lib().pmx_host_free, p.value)
+    return arr
+
+
 def loglik(model, pop: DevicePopulation, error_models, theta, ll=None, status=None, want_status: bool = True):
     """Device-pointer form (``pmx_loglik_device``): torch CUDA tensors on torch's current stream, not
     synchronised.  Returns ``(ll[S, P], status[S, P])`` — the matrix ``log_likelihood_matrix`` returns
