@@ -188,6 +188,8 @@ def test_host_pointer_entry_points_reuse_their_workspace_and_take_pinned_or_page
     np.testing.assert_allclose(out[-w2.shape[0]:, :128], w2, rtol=1e-9)
     # failures: the flag comes from a device-side reduction, the status array is optional
     bad = theta.copy()
-    bad[3, 1] = -5.0
-    rc = L.pmx_predict(dm.handle, pop.handle, bad.ctypes.data, 96, np.empty((NO, 96)).ctypes.data, 96, None)
-    assert rc in (_abi.PMX_OK, _abi.PMX_ERR_PAIR_FAILED)
+    bad[3, 1] = -1.5
+    bad[3, 0], bad[3, 2] = 1.0, 1.0  # (ke + kcp + kpc)^2 < 4 ke kpc: complex eigenvalues
+    sink = np.empty((NO, 96))
+    rc = L.pmx_predict(dm.handle, pop.handle, bad.ctypes.data, 96, sink.ctypes.data, 96, None)
+    assert rc == _abi.PMX_ERR_PAIR_FAILED and np.isnan(sink[:, 3]).all() and np.isfinite(np.delete(sink, 3, axis=1)).all()
