@@ -38,6 +38,7 @@ struct Tunables {
   bool disable_ladder = false, disable_classing = false;
   int32_t steps_per_trip = 0, grid_min_p = 0, min_class = 0, cpb = 0;
   int32_t spread = -1, loose = -1;  // -1 = library default
+  int32_t prop_slots = -1, dyn_tile = 0;
   void load() {
     auto flag = [](const char* n) {
       const char* e = std::getenv(n);
@@ -58,6 +59,11 @@ struct Tunables {
     grid_min_p = num("PMX_TUNE_GRID_MIN_P");
     min_class = num("PMX_TUNE_MIN_CLASS");
     cpb = num("PMX_TUNE_CPB");
+    {
+      const char* e = std::getenv("PMX_TUNE_PROP_SLOTS");
+      prop_slots = e ? std::atoi(e) : -1;
+    }
+    dyn_tile = num("PMX_TUNE_DYN_TILE");
     spread = tri("PMX_TUNE_SPREAD");
     loose = tri("PMX_TUNE_LOOSE");
   }
@@ -132,6 +138,8 @@ struct DeviceStream {
   int32_t max_input_used = -1;
   int64_t n_ops = 0, n_prop = 0;
   int64_t max_lagb_per_list = 0;
+  int32_t prop_cache_used = 0;        // LDS slots the stream's propagator-cache codes use
+  double prop_reuse_fraction = 0.0;   // share of PROP ops that take a kept propagator
   ~DeviceStream() {
     for (void* p : allocs) (void)hipFree(p);
     for (auto& c : ll_cache)
@@ -644,6 +652,9 @@ pmx::CompileKey key_for(const pmx_model* m) {
     if (!disabled && !reads_pad && lag_ok && (plain || dyn_ok)) {
       k.class_g = (st == pmx::S_ONE || st == pmx::S_ONE_ABS || st == pmx::S_TWO) ? 8 : 4;  // == ClassBatch<KID>::G
     }
+    // covariate models that take the generic walker: equal (length, factors) PROPs of an occasion share a propagator
+    if (m->dyn && k.lag_mask == 0 && k.class_g == 0) k.prop_cache_slots = tun.prop_slots >= 0 ? (tun.prop_slots > 3 ? 3 : tun.prop_slots) : 1;  // (one slot: a second costs more occupancy
+    // than its extra reuse returns - C5: 1 slot 16.8 ms, 2 slots 19.4 ms, none 20.2 ms; tools/c5 notes in DESIGN.md)
   } else {
     k.cov_time_mode = PMX_COV_TIME_SEGMENT_END_ABS;
     k.rk4_h_max = m->d.rk4_h_max;
@@ -715,6 +726,8 @@ int32_t get_stream(pmx_population* pop, const pmx::CompileKey& key, DeviceStream
   if ((rc = upload(os.lagb_amount, &ds->dev.lagb_amount, &ds->allocs)) != PMX_OK) return rc;
   if (key.lag_merge && (rc = upload(os.lagb_input, &ds->dev.lagb_input, &ds->allocs)) != PMX_OK) return rc;
   ds->max_lagb_per_list = os.max_lagb_per_list;
+  ds->prop_cache_used = os.prop_cache_used;
+  ds->prop_reuse_fraction = os.n_prop > 0 ? static_cast<double>(os.n_prop_reused) / static_cast<double>(os.n_prop) : 0.0;
   ds->dev.n_rate = key.n_rate;
   ds->dev.n_cov = 0;
   if ((key.eq_kind == PMX_EQ_ODE || key.user_cov) && pop->hp.n_cov > 0) {  // covariate segments for bodies that read them on the device
@@ -964,6 +977,9 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
   a.stream = stream;
   a.cls = ds->cls;
   a.use_classes = ds->cls.n_chunks > 0 ? 1 : 0;
+  // the stream's codes were written for key.prop_cache_slots slots; the kernel decodes them with the same number
+  a.prop_slots = ds->prop_cache_used > 0 ? ds->key.prop_cache_slots : 0;
+  a.dyn_tile = tunables().dyn_tile;  // (0 = the default tile; 64 and 256 measured the same with one slot)
   DeviceStream::LLCache* slot = nullptr;
   struct SlotGuard {  // the slot is released (event recorded on the stream) however this function leaves
     pmx_population* pop;

@@ -202,6 +202,8 @@ int32_t compile_ops(const HostPopulation& hp, const CompileKey& key, OpStream* o
   os->lagb_amount.clear();
   os->lagb_input.clear();
   os->max_lagb_per_list = 0;
+  os->prop_cache_used = 0;
+  os->n_prop_reused = 0;
   os->n_prop = 0;
   const uint32_t lag_mask = key.lag_mask;
   int32_t slot_of_input[PMX_MAX_INPUTS];
@@ -426,6 +428,72 @@ int32_t compile_ops(const HostPopulation& hp, const CompileKey& key, OpStream* o
       }
     }
     os->subj_op_off[s + 1] = static_cast<int64_t>(os->op_meta.size());
+    if (key.prop_cache_slots > 0 && !ode && !os->op_fac.empty()) {
+      // Propagator reuse for covariate-derived rate constants.  The macro lowering evaluates `derive` at the segment
+      // LENGTH (expand/analytical.rs:254,286), so two PROPs of equal length see equal covariates, hence equal rate
+      // constants and the same transition matrix (a subject-constant covariate gives the same under either rule).
+      // Per occasion: key = (dt, factor row) bitwise; a key with a later use gets a slot (furthest-next-use eviction);
+      // code 1 + k = build and keep in slot k, 1 + S + k = take slot k (S = prop_cache_slots), 0 = build.
+      const int32_t NS_ = key.prop_cache_slots;
+      const size_t nfac = static_cast<size_t>(key.n_derived) * PMX_MAX_FACTORS;
+      const int64_t o0 = os->subj_op_off[s], o1 = os->subj_op_off[s + 1];
+      auto same = [&](int64_t a, int64_t b) {
+        return std::memcmp(&os->op_a[a], &os->op_a[b], 8) == 0 && (os->op_b[a] != 0.0) == (os->op_b[b] != 0.0) &&  // (rate-free
+               // segments keep the transition part only: they share among themselves, segments under an infusion likewise)
+               std::memcmp(&os->op_fac[static_cast<size_t>(a) * nfac], &os->op_fac[static_cast<size_t>(b) * nfac], nfac * 8) == 0;
+      };
+      int64_t seg0 = o0;
+      while (seg0 < o1) {  // one occasion at a time (a RESET re-derives the lane's failure state)
+        int64_t seg1 = seg0 + 1;
+        while (seg1 < o1 && (os->op_meta[seg1] & 0xffu) != OP_RESET) ++seg1;
+        std::vector<int64_t> props;
+        for (int64_t o = seg0; o < seg1; ++o)
+          if ((os->op_meta[o] & 0xffu) == OP_PROP) props.push_back(o);
+        const size_t n = props.size();
+        std::vector<int64_t> next(n, -1);  // index (into props) of the next PROP with the same key
+        for (size_t i = 0; i < n; ++i)
+          for (size_t j = i + 1; j < n; ++j)
+            if (same(props[i], props[j])) {
+              next[i] = static_cast<int64_t>(j);
+              break;
+            }
+        std::vector<int64_t> holder(static_cast<size_t>(NS_), -1);  // slot -> index of the PROP whose propagator it holds
+        std::vector<int32_t> slot_of(n, -1);
+        for (size_t i = 0; i < n; ++i) {
+          int32_t from = -1;
+          for (int32_t k = 0; k < NS_; ++k)
+            if (holder[static_cast<size_t>(k)] >= 0 && next[static_cast<size_t>(holder[static_cast<size_t>(k)])] == static_cast<int64_t>(i)) from = k;
+          uint32_t code = 0;
+          if (from >= 0) {  // take it; the slot now stands for this PROP (same key, next use continues the chain)
+            code = static_cast<uint32_t>(1 + NS_ + from);
+            holder[static_cast<size_t>(from)] = next[i] >= 0 ? static_cast<int64_t>(i) : -1;
+            os->n_prop_reused++;
+            os->prop_cache_used = std::max(os->prop_cache_used, from + 1);
+          } else if (next[i] >= 0) {  // first of several: keep it if a slot is free or holds something needed later than this
+            int32_t pick = -1;
+            int64_t worst = -1;
+            for (int32_t k = 0; k < NS_; ++k) {
+              const int64_t h = holder[static_cast<size_t>(k)];
+              if (h < 0) {
+                pick = k;
+                worst = std::numeric_limits<int64_t>::max();
+                break;
+              }
+              if (next[static_cast<size_t>(h)] > worst) {
+                worst = next[static_cast<size_t>(h)];
+                pick = k;
+              }
+            }
+            if (pick >= 0 && (holder[static_cast<size_t>(pick)] < 0 || worst > next[i])) {
+              holder[static_cast<size_t>(pick)] = static_cast<int64_t>(i);
+              code = static_cast<uint32_t>(1 + pick);
+            }
+          }
+          os->op_meta[props[i]] |= code << 24;
+        }
+        seg0 = seg1;
+      }
+    }
     if (key.ladder && !ode) {  // exponential ladder along the subject's PROP ops (the lane's rate constants never change)
       double prev = 0.0, span = 1.0;
       for (int64_t o = os->subj_op_off[s]; o < os->subj_op_off[s + 1]; ++o)

@@ -80,13 +80,17 @@ struct CompileKey {
                             // lives for one solve, analytical/mod.rs:331)
   bool full_rates = false;  // analytical: op_rate carries rateiv of EVERY input (a user `eq` may read any of them)
   bool user_cov = false;    // covariates are looked up on the device (segment tables uploaded; no op_cov / op_fac)
+  int32_t prop_cache_slots = 0;  // covariate-derived rate constants: PROP ops of one occasion with the same (length,
+                                 // covariate factors) have the same propagator; bits 24-26 of such ops say
+                                 // "compute and keep in slot k" / "take slot k" (prop_cache_codes, pmx_compile.cpp)
   bool ladder = false;     // analytical, theta-only coefficients, no lag: PROP ops carry the exponential-ladder code
                            // (bits 27-29 of op_meta, pmx_structures.hpp ladder_pow)
   bool operator==(const CompileKey& o) const {
     return eq_kind == o.eq_kind && cov_time_mode == o.cov_time_mode && rk4_h_max == o.rk4_h_max &&
            n_rate == o.n_rate && rate_input == o.rate_input && class_g == o.class_g && lag_mask == o.lag_mask &&
            ladder == o.ladder && want_times == o.want_times && lag_merge == o.lag_merge && solve_marks == o.solve_marks &&
-           full_rates == o.full_rates && user_cov == o.user_cov && n_derived == o.n_derived &&
+           full_rates == o.full_rates && user_cov == o.user_cov && prop_cache_slots == o.prop_cache_slots &&
+           n_derived == o.n_derived &&
            std::memcmp(derived, o.derived, sizeof(derived)) == 0;
   }
 };
@@ -111,6 +115,8 @@ struct OpStream {
   std::vector<double> lagb_amount;
   std::vector<int32_t> lagb_input;   // the bolus' input (lag_merge lists mix inputs)
   int64_t max_lagb_per_list = 0;     // longest (occasion, slot) list
+  int32_t prop_cache_used = 0;       // slots the stream's cache codes actually use (0: no reuse anywhere)
+  int64_t n_prop_reused = 0;         // PROP ops that take a kept propagator instead of rebuilding it
   std::vector<int32_t> subj_order;   // subjects sorted by op count (desc), for the lane-per-pair kernels
   int32_t max_ops_per_subject = 0;
   int64_t n_prop = 0;

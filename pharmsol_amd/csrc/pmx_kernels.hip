@@ -115,15 +115,23 @@ __device__ __forceinline__ void lane_params_dyn(const DevModel& m, const LaneMod
   to_native_params<KID>(kp, q);
 }
 // ... and the segment's propagator applied (fused prepare + make, pmx_structures.hpp make_prop_dyn)
-template <int KID>
+// UNIFORM_R: the rate is wave-uniform (GRID / classed kernels), so a segment without an active infusion can skip the
+// response J altogether (a scalar branch); the PAIR kernels' lanes carry their own rates and always build it
+template <int KID, bool UNIFORM_R = false>
 __device__ __forceinline__ bool lane_advance_dyn(const DevModel& m, const LaneModel<KID>& L, const double* cov,
                                                  double (&x)[LaneModel<KID>::NS], double dt, double r) {
   using LM = LaneModel<KID>;
   double q[LM::NKP];
   lane_params_dyn<KID>(m, L, cov, q);
   typename LM::S::Prop pr;
-  const bool ok = make_prop_dyn<LM::ST>(q, dt, pr);
-  LM::S::apply(pr, x, r);
+  bool ok;
+  if (UNIFORM_R && r == 0.0) {
+    ok = make_prop_dyn<LM::ST, false>(q, dt, pr);
+    LM::S::apply0(pr, x);
+  } else {
+    ok = make_prop_dyn<LM::ST, true>(q, dt, pr);
+    LM::S::apply(pr, x, r);
+  }
   return ok;
 }
 
@@ -207,20 +215,31 @@ __device__ __forceinline__ void lag_prop(const DevModel& m, const DevOps& ops, L
 // GRID kernel (analytical)
 // ------------------------------------------------------------------------------------
 template <int KID, bool DYN, bool LAG, bool LL>
-__global__ __launch_bounds__(kBlock, (!LAG && LaneModel<KID>::NS <= 2) ? 4 : ((!LAG && DYN) ? 4 : 1)) void pmx_analytical_grid(DevModel m, DevOps ops, const double* __restrict__ theta,
+// (covariate walkers: 3 waves per SIMD = 168 VGPRs; at 4 the three-compartment rebuild spilled 324 bytes per lane to scratch.
+// C5, same box: 4 -> 16.9 ms, 3 -> 16.0 ms, 2 -> 19.8 ms)
+#ifndef PMX_DYN_WAVES
+#define PMX_DYN_WAVES 3
+#endif
+__global__ __launch_bounds__(kBlock, (!LAG && LaneModel<KID>::NS <= 2) ? 4 : ((!LAG && DYN) ? PMX_DYN_WAVES : 1)) void pmx_analytical_grid(DevModel m, DevOps ops, const double* __restrict__ theta,
                                                               int64_t P, int64_t S, int32_t s_chunk, int32_t n_ptiles,
                                                               double* __restrict__ pred, int64_t ld,
                                                               uint8_t* __restrict__ status,
-                                                              const int32_t* __restrict__ subj_list, int32_t zero_status) {
+                                                              const int32_t* __restrict__ subj_list, int32_t zero_status,
+                                                              int32_t prop_slots) {
   using LM = LaneModel<KID>;
   constexpr int NS = LM::NS;
   const int64_t b = blockIdx.x;
   const int32_t ptile = static_cast<int32_t>(b % n_ptiles);
   const int64_t chunk = b / n_ptiles;
-  const int64_t p = static_cast<int64_t>(ptile) * kBlock + threadIdx.x;
+  const uint32_t tile = blockDim.x;  // support points per block (64 / 128 / 256: launch_analytical)
+  const int64_t p = static_cast<int64_t>(ptile) * tile + threadIdx.x;
   const bool lane_ok = p < P;
   const int64_t pc = lane_ok ? p : (P - 1);  // idle lanes shadow the last support point; their stores are masked
   const double* __restrict__ th = theta + pc * m.nparams;
+  // DYN: propagators the host marked for reuse wait in LDS, [slot][component][lane] (pmx_compile.cpp, prop cache codes)
+  extern __shared__ double prop_cache[];
+  constexpr int NPD = static_cast<int>(sizeof(typename LM::S::Prop) / sizeof(double));
+  (void)prop_cache;
 
   LM L;
   lane_setup<KID, DYN>(m, th, L);
@@ -272,7 +291,7 @@ __global__ __launch_bounds__(kBlock, (!LAG && LaneModel<KID>::NS <= 2) ? 4 : ((!
     // subject's 64 bytes with 8 lanes x 8 bytes and only failures are written later; mode 2: every pair's byte is written.
     if (zero_status == 1 && status != nullptr) {
       const uint32_t zl = threadIdx.x & 63u;
-      const int64_t zp = static_cast<int64_t>(ptile) * kBlock + (threadIdx.x & ~63u) + 8 * zl;
+      const int64_t zp = static_cast<int64_t>(ptile) * tile + (threadIdx.x & ~63u) + 8 * zl;
       if (zl < 8u && zp < P) *reinterpret_cast<uint64_t*>(status + s * P + zp) = 0ull;
     }
     for (int64_t o = o0; o < o1; ++o) {
@@ -286,7 +305,30 @@ __global__ __launch_bounds__(kBlock, (!LAG && LaneModel<KID>::NS <= 2) ? 4 : ((!
         if constexpr (LAG) {
           lag_prop<LM::ST, NS>(m, ops, ls, c_op_t0[o], c_op_t1[o], r, L.coef, th, x);
         } else if constexpr (DYN) {
-          if (!lane_advance_dyn<KID>(m, L, cov, x, a, r)) st = PMX_PAIR_COMPLEX_ROOTS;
+          // bits 24-26: 0 = build; 1 + k = build and keep in slot k; 1 + S + k = take slot k (same length, same
+          // covariate factors earlier in this occasion: the same transition matrix).  Wave-uniform: scalar branches.
+          const uint32_t rc = (meta >> 24) & 7u;
+          const uint32_t n_slots = static_cast<uint32_t>(prop_slots);
+          typename LM::S::Prop pr;
+          if (rc > n_slots) {  // (kept by a segment of the same kind: with a rate -> F and J, without -> F only)
+            double tmp[NPD];
+#pragma unroll
+            for (int k = 0; k < NPD; ++k) tmp[k] = prop_cache[((rc - 1u - n_slots) * NPD + k) * tile + threadIdx.x];
+            __builtin_memcpy(&pr, tmp, sizeof(pr));
+          } else {
+            double q[LM::NKP];
+            lane_params_dyn<KID>(m, L, cov, q);
+            const bool ok = (r != 0.0) ? make_prop_dyn<LM::ST, true>(q, a, pr) : make_prop_dyn<LM::ST, false>(q, a, pr);
+            if (!ok) st = PMX_PAIR_COMPLEX_ROOTS;
+            if (rc != 0u) {
+              double tmp[NPD];
+              __builtin_memcpy(tmp, &pr, sizeof(pr));
+#pragma unroll
+              for (int k = 0; k < NPD; ++k) prop_cache[((rc - 1u) * NPD + k) * tile + threadIdx.x] = tmp[k];
+            }
+          }
+          if (r != 0.0) LM::S::apply(pr, x, r);
+          else LM::S::apply0(pr, x);
         } else {
           // exponential ladder (pmx_compile.cpp ladder_code): bits 27-29 relate this PROP's length to the previous one's
           const uint32_t rung = (meta >> 27) & 7u;
@@ -295,9 +337,7 @@ __global__ __launch_bounds__(kBlock, (!LAG && LaneModel<KID>::NS <= 2) ? 4 : ((!
           } else if (rung != 1u) {
             ladder_pow<LM::S::NE>(ex, rung);
           }
-          typename LM::S::Prop pr;
-          LM::S::from_exps(L.coef, ex, pr);
-          LM::S::apply(pr, x, r);
+          step_from_exps<LM::ST>(L.coef, ex, x, r);
         }
         xpad = 0.0;  // pm_* wrappers re-pad slot 0 with 0 after every kernel call (analytical/mod.rs:70-75)
       } else if (kind == OP_OBS) {
@@ -608,7 +648,7 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
           const int64_t nf = cp.n_fac;
 #pragma unroll
           for (int j = 0; j < G; ++j) {
-            if (!lane_advance_dyn<KID>(m, Ld, cp.facp + (voff + j) * nf, x[j], dtv[voff + j], val[voff + j])) cplx |= (1u << j);
+            if (!lane_advance_dyn<KID, true>(m, Ld, cp.facp + (voff + j) * nf, x[j], dtv[voff + j], val[voff + j])) cplx |= (1u << j);
             if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
           }
         } else if constexpr (PERDT) {
@@ -616,10 +656,8 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
           // the walk through the program (one scalar decode per step instead of G) and the paired stores
 #pragma unroll
           for (int j = 0; j < G; ++j) {
-            typename LM::S::Prop pr;
             LM::S::exps(coef, dtv[voff + j], ex);
-            LM::S::from_exps(coef, ex, pr);
-            LM::S::apply(pr, x[j], val[voff + j]);
+            step_from_exps<LM::ST>(coef, ex, x[j], val[voff + j]);  // (the member's rate is a scalar: no infusion, no J)
             if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
           }
         } else {
@@ -630,7 +668,7 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
             ladder_pow<LM::S::NE>(ex, rung);
           }
           typename LM::S::Prop pr;
-          LM::S::from_exps(coef, ex, pr);
+          LM::S::from_exps(coef, ex, pr);  // (one propagator per step for G members: splitting off J does not pay here)
 #pragma unroll
           for (int j = 0; j < G; ++j) {
             LM::S::apply(pr, x[j], val[voff + j]);
@@ -1064,14 +1102,26 @@ hipError_t launch_analytical(const LaunchArgs& a, const char** name) {
       int64_t ch = (n_walk * a.n_ptiles) / 8192;
       s_chunk = static_cast<int32_t>(ch < 1 ? 1 : (ch > 64 ? 64 : ch));
     }
+    // tile = support points per block.  With kept propagators (DYN) the LDS cache is sized per lane, so the tile also
+    // sets the occupancy: a.dyn_tile (64 / 128 / 256, pmx_api.cpp) was picked for that.
+    uint32_t threads = grid_threads(a.P);
+    int32_t n_ptiles = a.n_ptiles;
+    size_t lds = 0;
+    if (DYN && a.prop_slots > 0) {
+      if (a.dyn_tile > 0 && static_cast<uint32_t>(a.dyn_tile) < threads) threads = static_cast<uint32_t>(a.dyn_tile);
+      n_ptiles = static_cast<int32_t>((a.P + threads - 1) / threads);
+      lds = static_cast<size_t>(a.prop_slots) * sizeof(typename LaneModel<KID>::S::Prop) * threads;
+    }
     const int64_t n_chunks = (n_walk + s_chunk - 1) / s_chunk;
-    const int64_t blocks = n_chunks * a.n_ptiles;
+    const int64_t blocks = n_chunks * n_ptiles;
     if (a.ops.ll_obs != nullptr)
-      hipLaunchKernelGGL((pmx_analytical_grid<KID, DYN, LAG, true>), dim3(static_cast<uint32_t>(blocks)), dim3(grid_threads(a.P)), 0, st,
-                         a.m, a.ops, a.theta, a.P, n_walk, s_chunk, a.n_ptiles, a.pred, a.ld, a.status, list, a.cls.zero_status);
+      hipLaunchKernelGGL((pmx_analytical_grid<KID, DYN, LAG, true>), dim3(static_cast<uint32_t>(blocks)), dim3(threads), lds, st,
+                         a.m, a.ops, a.theta, a.P, n_walk, s_chunk, n_ptiles, a.pred, a.ld, a.status, list, a.cls.zero_status,
+                         a.prop_slots);
     else
-      hipLaunchKernelGGL((pmx_analytical_grid<KID, DYN, LAG, false>), dim3(static_cast<uint32_t>(blocks)), dim3(grid_threads(a.P)), 0, st,
-                         a.m, a.ops, a.theta, a.P, n_walk, s_chunk, a.n_ptiles, a.pred, a.ld, a.status, list, a.cls.zero_status);
+      hipLaunchKernelGGL((pmx_analytical_grid<KID, DYN, LAG, false>), dim3(static_cast<uint32_t>(blocks)), dim3(threads), lds, st,
+                         a.m, a.ops, a.theta, a.P, n_walk, s_chunk, n_ptiles, a.pred, a.ld, a.status, list, a.cls.zero_status,
+                         a.prop_slots);
   } else {
     *name = kNamePair;
     const int64_t n_pairs = a.batch ? a.S : a.S * a.P;

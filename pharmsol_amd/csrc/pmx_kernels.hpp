@@ -57,6 +57,8 @@ struct LaunchArgs {
   int32_t adaptive;     // ODE: PMX_SOLVER_DOPRI5
   int32_t ll_censored;  // log-likelihood mode: the population holds censored observations (classed kernel's CENS variant)
   int32_t use_classes;  // GRID analytical: run the classed kernel on cls.n_chunks, the generic one on the rest
+  int32_t prop_slots;   // DYN GRID: LDS slots for kept propagators (OpStream::prop_cache_used; 0 = none)
+  int32_t dyn_tile;     // DYN GRID with kept propagators: support points per block (0 = the default tile)
   int32_t tune_cpb;     // > 0: chunks per block of the classed kernel forced by PMX_TUNE_CPB (tuning experiments)
   DevClassPlan cls;
   const int32_t* subj_list;  // GRID: walk these subjects instead of 0..S-1 (nullptr = all)

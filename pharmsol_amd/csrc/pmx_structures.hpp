@@ -153,13 +153,18 @@ struct Structure<S_ONE> {
   }
   static constexpr int NE = 1;
   __device__ __forceinline__ static void exps(const Coef& c, double dt, double (&e)[NE]) { e[0] = pmx_exp(-c.ke * dt); }
+  // from_exps = from_exps_f (the transition part F) + from_exps_j (the response J to a unit infusion rate); a segment
+  // without an active infusion (rate 0: wave-uniform in the GRID kernels) needs F only and advances with apply0
+  __device__ __forceinline__ static void from_exps_f(const Coef&, const double (&e)[NE], Prop& p) { p.e = e[0]; }
+  __device__ __forceinline__ static void from_exps_j(const Coef& c, const double (&e)[NE], Prop& p) { p.j = c.inv_ke * (1.0 - e[0]); }
   __device__ __forceinline__ static void from_exps(const Coef& c, const double (&e)[NE], Prop& p) {
-    p.e = e[0];
-    p.j = c.inv_ke * (1.0 - p.e);
+    from_exps_f(c, e, p);
+    from_exps_j(c, e, p);
   }
   __device__ __forceinline__ static void apply(const Prop& p, double (&x)[NS], double r) {
     x[0] = x[0] * p.e + p.j * r;
   }
+  __device__ __forceinline__ static void apply0(const Prop& p, double (&x)[NS]) { x[0] = x[0] * p.e; }
 };
 
 template <>
@@ -184,27 +189,38 @@ struct Structure<S_ONE_ABS> {
     e[0] = pmx_exp(-c.ka * dt);
     e[1] = pmx_exp(-c.ke * dt);
   }
-  __device__ __forceinline__ static void from_exps(const Coef& c, const double (&e)[NE], Prop& p) {
+  __device__ __forceinline__ static void from_exps_f(const Coef& c, const double (&e)[NE], Prop& p) {
     p.ea = e[0];
     p.ee = e[1];
-    p.j = c.inv_ke * (1.0 - p.ee);
     p.g = c.ka_over * (p.ee - p.ea);
+  }
+  __device__ __forceinline__ static void from_exps_j(const Coef& c, const double (&e)[NE], Prop& p) { p.j = c.inv_ke * (1.0 - e[1]); }
+  __device__ __forceinline__ static void from_exps(const Coef& c, const double (&e)[NE], Prop& p) {
+    from_exps_f(c, e, p);
+    from_exps_j(c, e, p);
   }
   __device__ __forceinline__ static void apply(const Prop& p, double (&x)[NS], double r) {
     const double g = x[0];
     x[0] = g * p.ea;
     x[1] = x[1] * p.ee + p.j * r + p.g * g;
   }
+  __device__ __forceinline__ static void apply0(const Prop& p, double (&x)[NS]) {
+    const double g = x[0];
+    x[0] = g * p.ea;
+    x[1] = x[1] * p.ee + p.g * g;
+  }
 };
 
 // ---------------------------------------------------------------- two compartments
 struct TwoCore {
   double l1, l2, inv_d;       // inv_d = 1/(l1-l2)
+  // every coefficient below already carries the 1/(l1-l2) of the reference's final division (two_compartment_models.rs:35-44)
   double a11, b11, kpc, kcp;  // M11 = a11 E1 + b11 E2 ; M12 = kpc (E2-E1) ; M21 = kcp (E2-E1)
   double a22, b22;            // M22 = a22 E1 + b22 E2
   double i0a, i0b, i1a, i1b;  // infusion vector: I0 = i0a(1-E1)+i0b(1-E2), I1 = i1a(1-E1)+i1b(1-E2)
+  // `un` receives the UNscaled (l1-kpc, kpc-l2, kcp) for the absorption quotients of the 3-state structure
   template <bool FAST = false>
-  __device__ __forceinline__ bool prepare(double ke, double kcp_, double kpc_) {
+  __device__ __forceinline__ bool prepare(double ke, double kcp_, double kpc_, double (&un)[3]) {
     const double s = ke + kcp_ + kpc_;
     double disc = s * s - 4.0 * ke * kpc_;
     const bool ok = !(disc < 0.0);  // reference panics on disc < 0 (two_compartment_models.rs:20-22)
@@ -212,38 +228,48 @@ struct TwoCore {
     l1 = (s + disc) / 2.0;
     l2 = (s - disc) / 2.0;
     inv_d = rcp_of<FAST>(l1 - l2);
-    a11 = l1 - kpc_;
-    b11 = kpc_ - l2;
-    kpc = kpc_;
-    kcp = kcp_;
-    a22 = l1 - ke - kcp_;
-    b22 = ke + kcp_ - l2;
+    const double ua11 = l1 - kpc_, ub11 = kpc_ - l2;
+    un[0] = ua11;
+    un[1] = ub11;
+    un[2] = kcp_;
+    a11 = ua11 * inv_d;
+    b11 = ub11 * inv_d;
+    kpc = kpc_ * inv_d;
+    kcp = kcp_ * inv_d;
+    a22 = (l1 - ke - kcp_) * inv_d;
+    b22 = (ke + kcp_ - l2) * inv_d;
+    double r1, r2;
     if constexpr (FAST) {
-      const double r1 = pmx_rcp(l1), r2 = pmx_rcp(l2);
-      i0a = a11 * r1;
-      i0b = b11 * r2;
-      i1a = -kcp_ * r1;
-      i1b = kcp_ * r2;
+      r1 = pmx_rcp(l1);
+      r2 = pmx_rcp(l2);
     } else {
-      i0a = a11 / l1;
-      i0b = b11 / l2;
-      i1a = -kcp_ / l1;
-      i1b = kcp_ / l2;
+      r1 = 1.0 / l1;
+      r2 = 1.0 / l2;
     }
+    i0a = a11 * r1;
+    i0b = b11 * r2;
+    i1a = -(kcp * r1);
+    i1b = kcp * r2;
     return ok;
   }
 };
 struct TwoProp {
   double f00, f01, f10, f11, j0, j1;
-  __device__ __forceinline__ void make(const TwoCore& t, double e1, double e2) {
-    const double de = (e2 - e1) * t.inv_d;
-    f00 = (t.a11 * e1 + t.b11 * e2) * t.inv_d;
+  __device__ __forceinline__ void make_f(const TwoCore& t, double e1, double e2) {
+    const double de = e2 - e1;
+    f00 = t.a11 * e1 + t.b11 * e2;
     f01 = t.kpc * de;
     f10 = t.kcp * de;
-    f11 = (t.a22 * e1 + t.b22 * e2) * t.inv_d;
+    f11 = t.a22 * e1 + t.b22 * e2;
+  }
+  __device__ __forceinline__ void make_j(const TwoCore& t, double e1, double e2) {
     const double o1 = 1.0 - e1, o2 = 1.0 - e2;
-    j0 = (t.i0a * o1 + t.i0b * o2) * t.inv_d;
-    j1 = (t.i1a * o1 + t.i1b * o2) * t.inv_d;
+    j0 = t.i0a * o1 + t.i0b * o2;
+    j1 = t.i1a * o1 + t.i1b * o2;
+  }
+  __device__ __forceinline__ void make(const TwoCore& t, double e1, double e2) {
+    make_f(t, e1, e2);
+    make_j(t, e1, e2);
   }
 };
 
@@ -258,13 +284,16 @@ struct Structure<S_TWO> {
   };
   template <bool FAST = false>
   __device__ __forceinline__ static bool prepare(const double* kp, Coef& c) {
-    return c.t.template prepare<FAST>(kp[0], kp[1], kp[2]);
+    double un[3];
+    return c.t.template prepare<FAST>(kp[0], kp[1], kp[2], un);
   }
   static constexpr int NE = 2;
   __device__ __forceinline__ static void exps(const Coef& c, double dt, double (&e)[NE]) {
     e[0] = pmx_exp(-c.t.l1 * dt);
     e[1] = pmx_exp(-c.t.l2 * dt);
   }
+  __device__ __forceinline__ static void from_exps_f(const Coef& c, const double (&e)[NE], Prop& p) { p.p.make_f(c.t, e[0], e[1]); }
+  __device__ __forceinline__ static void from_exps_j(const Coef& c, const double (&e)[NE], Prop& p) { p.p.make_j(c.t, e[0], e[1]); }
   __device__ __forceinline__ static void from_exps(const Coef& c, const double (&e)[NE], Prop& p) {
     p.p.make(c.t, e[0], e[1]);
   }
@@ -275,6 +304,13 @@ struct Structure<S_TWO> {
     x[0] = n0;
     x[1] = n1;
   }
+  __device__ __forceinline__ static void apply0(const Prop& q, double (&x)[NS]) {
+    const TwoProp& p = q.p;
+    const double n0 = p.f00 * x[0] + p.f01 * x[1];
+    const double n1 = p.f10 * x[0] + p.f11 * x[1];
+    x[0] = n0;
+    x[1] = n1;
+  }
 };
 
 template <>
@@ -282,7 +318,7 @@ struct Structure<S_TWO_ABS> {
   static constexpr int NS = 3;
   struct Coef {
     TwoCore t;
-    double ka, a0a, a0b, a1a, a1b;  // absorption vector quotients: (l1-kpc)/(ka-l1) ...
+    double ka, a0a, a0b, a1a, a1b;  // absorption vector quotients (l1-kpc)/(ka-l1) ... times ka/(l1-l2)  (:97-103)
   };
   struct Prop {
     TwoProp p;
@@ -291,13 +327,15 @@ struct Structure<S_TWO_ABS> {
   template <bool FAST = false>
   __device__ __forceinline__ static bool prepare(const double* kp, Coef& c) {
     // native order [ke, ka, kcp, kpc] (two_compartment_models.rs:62-65)
-    const bool ok = c.t.template prepare<FAST>(kp[0], kp[2], kp[3]);
+    double un[3];
+    const bool ok = c.t.template prepare<FAST>(kp[0], kp[2], kp[3], un);
     c.ka = kp[1];
-    const double r1 = rcp_of<FAST>(c.ka - c.t.l1), r2 = rcp_of<FAST>(c.ka - c.t.l2);
-    c.a0a = c.t.a11 * r1;
-    c.a0b = c.t.b11 * r2;
-    c.a1a = -c.t.kcp * r1;
-    c.a1b = c.t.kcp * r2;
+    const double h = c.ka * c.t.inv_d;  // ka * x[0] / (l1 - l2)  (:103)
+    const double r1 = rcp_of<FAST>(c.ka - c.t.l1) * h, r2 = rcp_of<FAST>(c.ka - c.t.l2) * h;
+    c.a0a = un[0] * r1;
+    c.a0b = un[1] * r2;
+    c.a1a = -(un[2] * r1);
+    c.a1b = un[2] * r2;
     return ok;
   }
   static constexpr int NE = 3;
@@ -306,21 +344,34 @@ struct Structure<S_TWO_ABS> {
     e[1] = pmx_exp(-c.t.l2 * dt);
     e[2] = pmx_exp(-c.ka * dt);
   }
-  __device__ __forceinline__ static void from_exps(const Coef& c, const double (&e)[NE], Prop& p) {
+  __device__ __forceinline__ static void from_exps_f(const Coef& c, const double (&e)[NE], Prop& p) {
     const double e1 = e[0];
     const double e2 = e[1];
     p.ea = e[2];
-    p.p.make(c.t, e1, e2);
-    const double h = c.ka * c.t.inv_d;  // ka * x[0] / (l1 - l2)  (:103)
+    p.p.make_f(c.t, e1, e2);
     const double d1 = e1 - p.ea, d2 = e2 - p.ea;
-    p.g0 = (c.a0a * d1 + c.a0b * d2) * h;
-    p.g1 = (c.a1a * d1 + c.a1b * d2) * h;
+    p.g0 = c.a0a * d1 + c.a0b * d2;
+    p.g1 = c.a1a * d1 + c.a1b * d2;
+  }
+  __device__ __forceinline__ static void from_exps_j(const Coef& c, const double (&e)[NE], Prop& p) { p.p.make_j(c.t, e[0], e[1]); }
+  __device__ __forceinline__ static void from_exps(const Coef& c, const double (&e)[NE], Prop& p) {
+    from_exps_f(c, e, p);
+    from_exps_j(c, e, p);
   }
   __device__ __forceinline__ static void apply(const Prop& q, double (&x)[NS], double r) {
     const TwoProp& p = q.p;
     const double g = x[0];
     const double n0 = p.f00 * x[1] + p.f01 * x[2] + p.j0 * r + q.g0 * g;
     const double n1 = p.f10 * x[1] + p.f11 * x[2] + p.j1 * r + q.g1 * g;
+    x[0] = g * q.ea;
+    x[1] = n0;
+    x[2] = n1;
+  }
+  __device__ __forceinline__ static void apply0(const Prop& q, double (&x)[NS]) {
+    const TwoProp& p = q.p;
+    const double g = x[0];
+    const double n0 = p.f00 * x[1] + p.f01 * x[2] + q.g0 * g;
+    const double n1 = p.f10 * x[1] + p.f11 * x[2] + q.g1 * g;
     x[0] = g * q.ea;
     x[1] = n0;
     x[2] = n1;
@@ -346,7 +397,7 @@ struct ThreeCore {
     const double beta = -0.5 * n;
     // The reference takes gamma = |beta + i alpha|, theta = atan2(alpha, beta), gamma^(1/3) and cos/sin(theta/3)
     // (:36-45), i.e. the principal cube root z = cr (cs + i sn) of w = beta + i alpha.  Three f64 transcendentals
-    // per segment dominate a covariate model's cost, so z is seeded in single precision and polished with three
+    // per segment dominate a covariate model's cost, so z is seeded in single precision and polished with two
     // Newton steps z <- (2 z + w / z^2) / 3 in f64 (quadratic: 2e-6 -> 4e-12 -> rounding).  The seed needs no
     // library call: gamma^2 = -m^3/27, so gamma^(1/3) = sqrt(-m/3); atan2 on alpha >= 0 is a degree-8 polynomial in
     // min/max (Abramowitz & Stegun 4.4.49, 2e-8) plus two reflections; theta/3 <= pi/3 goes straight to the hardware
@@ -374,8 +425,13 @@ struct ThreeCore {
       const float crf = __builtin_amdgcn_sqrtf(static_cast<float>(p3));
       zr = static_cast<double>(crf * __cosf(ph));
       zi = static_cast<double>(crf * __sinf(ph));
+// (two steps: the seed is good to ~1e-6 and each step squares the relative error - 1e-12, then rounding level; a third
+// step bought nothing measurable, max rel err vs the oracle on C5 stays 1.5e-11, and cost 4 % of the kernel)
+#ifndef PMX_EIGEN_NEWTON
+#define PMX_EIGEN_NEWTON 2
+#endif
 #pragma unroll
-      for (int it = 0; it < 3; ++it) {
+      for (int it = 0; it < PMX_EIGEN_NEWTON; ++it) {
         const double z2r = zr * zr - zi * zi, z2i = 2.0 * zr * zi;
         const double inv = pmx_rcp(z2r * z2r + z2i * z2i);
         const double qr = (beta * z2r + alpha * z2i) * inv, qi = (alpha * z2r - beta * z2i) * inv;
@@ -430,12 +486,18 @@ struct ThreeCore {
 };
 struct ThreeProp {
   double m[9], j[3];
-  __device__ __forceinline__ void make(const ThreeCore& t, const double (&e)[3]) {
+  __device__ __forceinline__ void make_f(const ThreeCore& t, const double (&e)[3]) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) m[k] = t.c[3 * k] * e[0] + t.c[3 * k + 1] * e[1] + t.c[3 * k + 2] * e[2];
+  }
+  __device__ __forceinline__ void make_j(const ThreeCore& t, const double (&e)[3]) {
     const double o0 = 1.0 - e[0], o1 = 1.0 - e[1], o2 = 1.0 - e[2];
 #pragma unroll
     for (int k = 0; k < 3; ++k) j[k] = o0 * t.d[3 * k] + o1 * t.d[3 * k + 1] + o2 * t.d[3 * k + 2];
+  }
+  __device__ __forceinline__ void make(const ThreeCore& t, const double (&e)[3]) {
+    make_f(t, e);
+    make_j(t, e);
   }
 };
 
@@ -444,7 +506,8 @@ struct ThreeProp {
 // absorption vector directly, never holding the 27 + 9 (+ 9) coefficient tables (the tabled form needs 255 VGPRs
 // and runs one wave per SIMD).  Same terms as ThreeCore::prepare_tables + ThreeProp::make, summed in the same
 // eigenvalue order.
-template <bool ABS>
+// WITH_J = false: the segment has no active infusion, the response J (and the 1/l_i it needs) is left out.
+template <bool ABS, bool WITH_J = true>
 __device__ __forceinline__ bool three_direct(double k10, double k12, double k13, double k21, double k31, double ka,
                                              double dt, ThreeProp& p, double& ea, double (&g)[3]) {
   double l[3];
@@ -459,25 +522,42 @@ __device__ __forceinline__ bool three_direct(double k10, double k12, double k13,
     p.j[k] = 0.0;
     g[k] = 0.0;
   }
+#ifdef PMX_THREE_ROLLED
+  double r0 = l[0], r1 = l[1], r2 = l[2];
+#pragma unroll 1
+  for (int i = 0; i < 3; ++i) {
+    const double li = r0, lo1 = r1, lo2 = r2;
+    r0 = lo1;
+    r1 = lo2;
+    r2 = li;
+#else
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const double li = l[i];
     const double lo1 = l[(i + 1) % 3], lo2 = l[(i + 2) % 3];
+#endif
     // the three reciprocals of this eigenvalue - 1/d_i, 1/l_i and (ABS) 1/(ka - l_i) - from ONE Newton reciprocal of
     // their product (a third of this loop's instructions were reciprocals)
     const double di = (lo1 - li) * (lo2 - li);
-    double inv, il, ia = 0.0;
-    if constexpr (ABS) {
+    double inv, il = 0.0, ia = 0.0;
+    if constexpr (ABS && WITH_J) {
       const double kl = ka - li;
       const double dl = di * li;
       const double r = pmx_rcp(dl * kl);
       inv = r * (li * kl);
       il = r * (di * kl);
       ia = r * dl;
-    } else {
+    } else if constexpr (ABS) {
+      const double kl = ka - li;
+      const double r = pmx_rcp(di * kl);
+      inv = r * kl;
+      ia = r * di;
+    } else if constexpr (WITH_J) {
       const double r = pmx_rcp(di * li);
       inv = r * li;
       il = r * di;
+    } else {
+      inv = pmx_rcp(di);
     }
     const double u = k21 - li, v = k31 - li, w = K - li;
     const double ui = u * inv, vi = v * inv;
@@ -492,10 +572,12 @@ __device__ __forceinline__ bool three_direct(double k10, double k12, double k13,
     p.m[6] = fma(c6, e, p.m[6]);
     p.m[7] = fma(k2113 * inv, e, p.m[7]);
     p.m[8] = fma(fma(w, u, -k1221) * inv, e, p.m[8]);
-    const double o = (1.0 - e) * il;
-    p.j[0] = fma(c0, o, p.j[0]);
-    p.j[1] = fma(c3, o, p.j[1]);
-    p.j[2] = fma(c6, o, p.j[2]);
+    if constexpr (WITH_J) {
+      const double o = (1.0 - e) * il;
+      p.j[0] = fma(c0, o, p.j[0]);
+      p.j[1] = fma(c3, o, p.j[1]);
+      p.j[2] = fma(c6, o, p.j[2]);
+    }
     if constexpr (ABS) {
       const double q = (e - ea) * ia;
       g[0] = fma(c0, q, g[0]);
@@ -527,16 +609,28 @@ struct Structure<S_THREE> {
 #pragma unroll
     for (int i = 0; i < 3; ++i) e[i] = pmx_exp(-(c.t.l[i] * dt));
   }
+  __device__ __forceinline__ static void from_exps_f(const Coef& c, const double (&e)[NE], Prop& p) { p.p.make_f(c.t, e); }
+  __device__ __forceinline__ static void from_exps_j(const Coef& c, const double (&e)[NE], Prop& p) { p.p.make_j(c.t, e); }
   __device__ __forceinline__ static void from_exps(const Coef& c, const double (&e)[NE], Prop& p) { p.p.make(c.t, e); }
+  template <bool WITH_J = true>
   __device__ __forceinline__ static bool make_prop_dyn(const double* kp, double dt, Prop& p) {
     double ea_unused, g_unused[3];
-    return three_direct<false>(kp[0], kp[1], kp[2], kp[3], kp[4], 0.0, dt, p.p, ea_unused, g_unused);
+    return three_direct<false, WITH_J>(kp[0], kp[1], kp[2], kp[3], kp[4], 0.0, dt, p.p, ea_unused, g_unused);
   }
   __device__ __forceinline__ static void apply(const Prop& q, double (&x)[NS], double r) {
     const ThreeProp& p = q.p;
     const double y0 = p.m[0] * x[0] + p.m[1] * x[1] + p.m[2] * x[2] + p.j[0] * r;
     const double y1 = p.m[3] * x[0] + p.m[4] * x[1] + p.m[5] * x[2] + p.j[1] * r;
     const double y2 = p.m[6] * x[0] + p.m[7] * x[1] + p.m[8] * x[2] + p.j[2] * r;
+    x[0] = y0;
+    x[1] = y1;
+    x[2] = y2;
+  }
+  __device__ __forceinline__ static void apply0(const Prop& q, double (&x)[NS]) {
+    const ThreeProp& p = q.p;
+    const double y0 = p.m[0] * x[0] + p.m[1] * x[1] + p.m[2] * x[2];
+    const double y1 = p.m[3] * x[0] + p.m[4] * x[1] + p.m[5] * x[2];
+    const double y2 = p.m[6] * x[0] + p.m[7] * x[1] + p.m[8] * x[2];
     x[0] = y0;
     x[1] = y1;
     x[2] = y2;
@@ -573,16 +667,25 @@ struct Structure<S_THREE_ABS> {
     for (int i = 0; i < 3; ++i) e4[i] = pmx_exp(-(c.t.l[i] * dt));
     e4[3] = pmx_exp(-c.ka * dt);
   }
-  __device__ __forceinline__ static void from_exps(const Coef& c, const double (&e4)[NE], Prop& p) {
+  __device__ __forceinline__ static void from_exps_f(const Coef& c, const double (&e4)[NE], Prop& p) {
     const double e[3] = {e4[0], e4[1], e4[2]};
     p.ea = e4[3];
-    p.p.make(c.t, e);
+    p.p.make_f(c.t, e);
     const double d0 = e[0] - p.ea, d1 = e[1] - p.ea, d2 = e[2] - p.ea;
 #pragma unroll
     for (int k = 0; k < 3; ++k) p.g[k] = (d0 * c.f[3 * k] + d1 * c.f[3 * k + 1] + d2 * c.f[3 * k + 2]) * c.ka;  // (:230)
   }
+  __device__ __forceinline__ static void from_exps_j(const Coef& c, const double (&e4)[NE], Prop& p) {
+    const double e[3] = {e4[0], e4[1], e4[2]};
+    p.p.make_j(c.t, e);
+  }
+  __device__ __forceinline__ static void from_exps(const Coef& c, const double (&e4)[NE], Prop& p) {
+    from_exps_f(c, e4, p);
+    from_exps_j(c, e4, p);
+  }
+  template <bool WITH_J = true>
   __device__ __forceinline__ static bool make_prop_dyn(const double* kp, double dt, Prop& p) {
-    return three_direct<true>(kp[1], kp[2], kp[3], kp[4], kp[5], kp[0], dt, p.p, p.ea, p.g);
+    return three_direct<true, WITH_J>(kp[1], kp[2], kp[3], kp[4], kp[5], kp[0], dt, p.p, p.ea, p.g);
   }
   __device__ __forceinline__ static void apply(const Prop& q, double (&x)[NS], double r) {
     const ThreeProp& p = q.p;
@@ -590,6 +693,17 @@ struct Structure<S_THREE_ABS> {
     const double y0 = p.m[0] * x[1] + p.m[1] * x[2] + p.m[2] * x[3] + p.j[0] * r + q.g[0] * g;
     const double y1 = p.m[3] * x[1] + p.m[4] * x[2] + p.m[5] * x[3] + p.j[1] * r + q.g[1] * g;
     const double y2 = p.m[6] * x[1] + p.m[7] * x[2] + p.m[8] * x[3] + p.j[2] * r + q.g[2] * g;
+    x[0] = g * q.ea;
+    x[1] = y0;
+    x[2] = y1;
+    x[3] = y2;
+  }
+  __device__ __forceinline__ static void apply0(const Prop& q, double (&x)[NS]) {
+    const ThreeProp& p = q.p;
+    const double g = x[0];
+    const double y0 = p.m[0] * x[1] + p.m[1] * x[2] + p.m[2] * x[3] + q.g[0] * g;
+    const double y1 = p.m[3] * x[1] + p.m[4] * x[2] + p.m[5] * x[3] + q.g[1] * g;
+    const double y2 = p.m[6] * x[1] + p.m[7] * x[2] + p.m[8] * x[3] + q.g[2] * g;
     x[0] = g * q.ea;
     x[1] = y0;
     x[2] = y1;
@@ -621,15 +735,32 @@ __device__ __forceinline__ void ladder_pow(double (&e)[NE], uint32_t n) {
 
 // covariate-derived rate constants: prepare + make for ONE segment.  Structures with a fused form provide
 // make_prop_dyn; the others go through their Coef.
-template <int ST>
+template <int ST, bool WITH_J = true>
 __device__ __forceinline__ bool make_prop_dyn(const double* kp, double dt, typename Structure<ST>::Prop& p) {
   if constexpr (ST == S_THREE || ST == S_THREE_ABS) {
-    return Structure<ST>::make_prop_dyn(kp, dt, p);
+    return Structure<ST>::template make_prop_dyn<WITH_J>(kp, dt, p);
   } else {
     typename Structure<ST>::Coef c;
     const bool ok = Structure<ST>::template prepare<true>(kp, c);
-    make_prop<ST>(c, dt, p);
+    double e[Structure<ST>::NE];
+    Structure<ST>::exps(c, dt, e);
+    Structure<ST>::from_exps_f(c, e, p);
+    if constexpr (WITH_J) Structure<ST>::from_exps_j(c, e, p);
     return ok;
+  }
+}
+
+// x' = F x + J r from the segment's exponentials, for a WAVE-UNIFORM rate r: a segment without an active infusion skips J
+template <int ST>
+__device__ __forceinline__ void step_from_exps(const typename Structure<ST>::Coef& c, const double (&e)[Structure<ST>::NE],
+                                               double (&x)[Structure<ST>::NS], double r) {
+  typename Structure<ST>::Prop p;
+  Structure<ST>::from_exps_f(c, e, p);
+  if (r != 0.0) {
+    Structure<ST>::from_exps_j(c, e, p);
+    Structure<ST>::apply(p, x, r);
+  } else {
+    Structure<ST>::apply0(p, x);
   }
 }
 

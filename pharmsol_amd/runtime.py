@@ -373,7 +373,8 @@ def compile_ops(model, flat: FlatPopulation) -> dict:
         out = dict(
             n_ops=n, n_subjects=S, n_cov=int(v.n_cov), n_rate=int(v.n_rate), max_input_used=int(v.max_input_used),
             max_outeq=int(v.max_outeq), subj_op_off=arr(v.subj_op_off, S + 1, np.int64), kind=(meta & 0xFF).astype(np.int32),
-            io=((meta >> 8) & 0xFFFF).astype(np.int32), a=arr(v.op_a, n, np.float64), b=arr(v.op_b, n, np.float64),
+            io=((meta >> 8) & 0xFFFF).astype(np.int32), flags=(meta >> 24).astype(np.int32),
+            a=arr(v.op_a, n, np.float64), b=arr(v.op_b, n, np.float64),
             n=arr(v.op_n, n, np.int32), rate=arr(v.op_rate, n * int(v.n_rate), np.float64).reshape(-1, max(int(v.n_rate), 1)),
             cov=arr(v.op_cov, n * int(v.n_cov), np.float64).reshape(-1, max(int(v.n_cov), 1)),
             subj_order=arr(v.subj_order, S, np.int32))
