@@ -654,10 +654,18 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
         } else if constexpr (PERDT) {
           // loose chunk: every member has its own step length, hence its own propagator; the members still share
           // the walk through the program (one scalar decode per step instead of G) and the paired stores
+          // the step's 2 G scalars (lengths, rates) come in up front with two wide scalar loads: fetched member by member
+          // each of the G blocks below began by waiting for its own s_load
+          double m_dt[G], m_r[G];
 #pragma unroll
           for (int j = 0; j < G; ++j) {
-            LM::S::exps(coef, dtv[voff + j], ex);
-            step_from_exps<LM::ST>(coef, ex, x[j], val[voff + j]);  // (the member's rate is a scalar: no infusion, no J)
+            m_dt[j] = dtv[voff + j];
+            m_r[j] = val[voff + j];
+          }
+#pragma unroll
+          for (int j = 0; j < G; ++j) {
+            LM::S::exps(coef, m_dt[j], ex);
+            step_from_exps<LM::ST>(coef, ex, x[j], m_r[j]);  // (the member's rate is a scalar: no infusion, no J)
             if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
           }
         } else {

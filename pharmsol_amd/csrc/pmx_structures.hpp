@@ -39,7 +39,7 @@ namespace pmx {
 // propagates.  ~19 VALU instructions instead of ~30, results within 1-2 ulp of the library's.  (Keeping the 16
 // constants resident in VGPRs instead of literals was tried for the generic kernel: one wave of occupancy less,
 // 6 % slower.)
-__device__ __forceinline__ double pmx_exp(double x) {
+__device__ __forceinline__ double pmx_exp_poly(double x) {
   const double n = __builtin_rint(x * 1.4426950408889634074);
   double r = fma(n, -6.93147180369123816490e-01, x);  // ln2 high part: 21 trailing zero bits, n * hi is exact
   r = fma(n, -1.90821492927058770002e-10, r);
@@ -59,6 +59,35 @@ __device__ __forceinline__ double pmx_exp(double x) {
   p = fma(p, r, 1.0);
   return ldexp(p, static_cast<int>(n));
 }
+
+// 2^t for the propagators: every exponential there is exp(-lambda dt), and lambda can carry the factor -log2(e) from the
+// once-per-lane (or once-per-rebuild) set-up, so the argument arrives in base 2: n = rint(t), r = t - n EXACTLY (no
+// two-piece ln2 reduction), degree-13 polynomial in r with coefficients ln2^k / k! (|r| <= 1/2: truncation 4e-18), scale
+// by 2^n.  17 FP64-rate instructions; the rounding of t = lambda' dt is the same one ulp the product -lambda dt had.
+__device__ __forceinline__ double pmx_exp2(double t) {
+  const double n = __builtin_rint(t);
+  const double r = t - n;
+  double p = 1.3691488853904128881e-12;
+  p = fma(p, r, 2.5678435993488205142e-11);
+  p = fma(p, r, 4.4455382718708114976e-10);
+  p = fma(p, r, 7.0549116208011233299e-09);
+  p = fma(p, r, 1.0178086009239699727e-07);
+  p = fma(p, r, 1.3215486790144309488e-06);
+  p = fma(p, r, 1.525273380405984028e-05);
+  p = fma(p, r, 1.5403530393381609954e-04);
+  p = fma(p, r, 1.3333558146428443423e-03);
+  p = fma(p, r, 9.618129107628477162e-03);
+  p = fma(p, r, 5.5504108664821579953e-02);
+  p = fma(p, r, 2.4022650695910071233e-01);
+  p = fma(p, r, 6.9314718055994530942e-01);
+  p = fma(p, r, 1.0);
+  return ldexp(p, static_cast<int>(n));
+}
+constexpr double kNegLog2e = -1.4426950408889634074;  // lambda' = -lambda log2(e):  exp(-lambda dt) = 2^(lambda' dt)
+
+// (Tried: a 64-entry table of 2^(j/64) + a degree-5 polynomial, 11 FP64-rate instructions instead of 19.  The per-lane
+// table fetch cost more than the eight FMAs it replaced: jittered C3 1.99 -> 2.43 ms, C5 and the generic walker unchanged.)
+__device__ __forceinline__ double pmx_exp(double x) { return pmx_exp_poly(x); }
 
 // 1/x to within an ulp or two: the hardware estimate polished by two Newton steps (what the IEEE division expands to,
 // minus its scaling and fix-up instructions: ~8 issue slots instead of ~15).  For the per-segment coefficient rebuild
@@ -140,19 +169,19 @@ template <>
 struct Structure<S_ONE> {
   static constexpr int NS = 1;
   struct Coef {
-    double ke, inv_ke;
+    double ke2, inv_ke;  // ke2 = -ke log2(e)
   };
   struct Prop {
     double e, j;
   };
   template <bool FAST = false>
   __device__ __forceinline__ static bool prepare(const double* kp, Coef& c) {
-    c.ke = kp[0];
+    c.ke2 = kp[0] * kNegLog2e;
     c.inv_ke = rcp_of<FAST>(kp[0]);
     return true;
   }
   static constexpr int NE = 1;
-  __device__ __forceinline__ static void exps(const Coef& c, double dt, double (&e)[NE]) { e[0] = pmx_exp(-c.ke * dt); }
+  __device__ __forceinline__ static void exps(const Coef& c, double dt, double (&e)[NE]) { e[0] = pmx_exp2(c.ke2 * dt); }
   // from_exps = from_exps_f (the transition part F) + from_exps_j (the response J to a unit infusion rate); a segment
   // without an active infusion (rate 0: wave-uniform in the GRID kernels) needs F only and advances with apply0
   __device__ __forceinline__ static void from_exps_f(const Coef&, const double (&e)[NE], Prop& p) { p.e = e[0]; }
@@ -171,23 +200,23 @@ template <>
 struct Structure<S_ONE_ABS> {
   static constexpr int NS = 2;
   struct Coef {
-    double ka, ke, inv_ke, ka_over;  // ka_over = ka / (ka - ke)
+    double ka2, ke2, inv_ke, ka_over;  // ka_over = ka / (ka - ke); ka2, ke2 = -k log2(e)
   };
   struct Prop {
     double ea, ee, j, g;
   };
   template <bool FAST = false>
   __device__ __forceinline__ static bool prepare(const double* kp, Coef& c) {
-    c.ka = kp[0];
-    c.ke = kp[1];
+    c.ka2 = kp[0] * kNegLog2e;
+    c.ke2 = kp[1] * kNegLog2e;
     c.inv_ke = rcp_of<FAST>(kp[1]);
     c.ka_over = FAST ? kp[0] * pmx_rcp(kp[0] - kp[1]) : kp[0] / (kp[0] - kp[1]);
     return true;
   }
   static constexpr int NE = 2;
   __device__ __forceinline__ static void exps(const Coef& c, double dt, double (&e)[NE]) {
-    e[0] = pmx_exp(-c.ka * dt);
-    e[1] = pmx_exp(-c.ke * dt);
+    e[0] = pmx_exp2(c.ka2 * dt);
+    e[1] = pmx_exp2(c.ke2 * dt);
   }
   __device__ __forceinline__ static void from_exps_f(const Coef& c, const double (&e)[NE], Prop& p) {
     p.ea = e[0];
@@ -214,6 +243,7 @@ struct Structure<S_ONE_ABS> {
 // ---------------------------------------------------------------- two compartments
 struct TwoCore {
   double l1, l2, inv_d;       // inv_d = 1/(l1-l2)
+  double l1s, l2s;            // -l log2(e): the exponents of make()'s 2^(ls dt)
   // every coefficient below already carries the 1/(l1-l2) of the reference's final division (two_compartment_models.rs:35-44)
   double a11, b11, kpc, kcp;  // M11 = a11 E1 + b11 E2 ; M12 = kpc (E2-E1) ; M21 = kcp (E2-E1)
   double a22, b22;            // M22 = a22 E1 + b22 E2
@@ -227,6 +257,8 @@ struct TwoCore {
     disc = sqrt(disc);
     l1 = (s + disc) / 2.0;
     l2 = (s - disc) / 2.0;
+    l1s = l1 * kNegLog2e;
+    l2s = l2 * kNegLog2e;
     inv_d = rcp_of<FAST>(l1 - l2);
     const double ua11 = l1 - kpc_, ub11 = kpc_ - l2;
     un[0] = ua11;
@@ -289,8 +321,8 @@ struct Structure<S_TWO> {
   }
   static constexpr int NE = 2;
   __device__ __forceinline__ static void exps(const Coef& c, double dt, double (&e)[NE]) {
-    e[0] = pmx_exp(-c.t.l1 * dt);
-    e[1] = pmx_exp(-c.t.l2 * dt);
+    e[0] = pmx_exp2(c.t.l1s * dt);
+    e[1] = pmx_exp2(c.t.l2s * dt);
   }
   __device__ __forceinline__ static void from_exps_f(const Coef& c, const double (&e)[NE], Prop& p) { p.p.make_f(c.t, e[0], e[1]); }
   __device__ __forceinline__ static void from_exps_j(const Coef& c, const double (&e)[NE], Prop& p) { p.p.make_j(c.t, e[0], e[1]); }
@@ -318,7 +350,7 @@ struct Structure<S_TWO_ABS> {
   static constexpr int NS = 3;
   struct Coef {
     TwoCore t;
-    double ka, a0a, a0b, a1a, a1b;  // absorption vector quotients (l1-kpc)/(ka-l1) ... times ka/(l1-l2)  (:97-103)
+    double ka2, a0a, a0b, a1a, a1b;  // ka2 = -ka log2(e); absorption vector quotients (l1-kpc)/(ka-l1) ... times ka/(l1-l2)  (:97-103)
   };
   struct Prop {
     TwoProp p;
@@ -329,9 +361,10 @@ struct Structure<S_TWO_ABS> {
     // native order [ke, ka, kcp, kpc] (two_compartment_models.rs:62-65)
     double un[3];
     const bool ok = c.t.template prepare<FAST>(kp[0], kp[2], kp[3], un);
-    c.ka = kp[1];
-    const double h = c.ka * c.t.inv_d;  // ka * x[0] / (l1 - l2)  (:103)
-    const double r1 = rcp_of<FAST>(c.ka - c.t.l1) * h, r2 = rcp_of<FAST>(c.ka - c.t.l2) * h;
+    const double ka = kp[1];
+    c.ka2 = ka * kNegLog2e;
+    const double h = ka * c.t.inv_d;  // ka * x[0] / (l1 - l2)  (:103)
+    const double r1 = rcp_of<FAST>(ka - c.t.l1) * h, r2 = rcp_of<FAST>(ka - c.t.l2) * h;
     c.a0a = un[0] * r1;
     c.a0b = un[1] * r2;
     c.a1a = -(un[2] * r1);
@@ -340,9 +373,9 @@ struct Structure<S_TWO_ABS> {
   }
   static constexpr int NE = 3;
   __device__ __forceinline__ static void exps(const Coef& c, double dt, double (&e)[NE]) {
-    e[0] = pmx_exp(-c.t.l1 * dt);
-    e[1] = pmx_exp(-c.t.l2 * dt);
-    e[2] = pmx_exp(-c.ka * dt);
+    e[0] = pmx_exp2(c.t.l1s * dt);
+    e[1] = pmx_exp2(c.t.l2s * dt);
+    e[2] = pmx_exp2(c.ka2 * dt);
   }
   __device__ __forceinline__ static void from_exps_f(const Coef& c, const double (&e)[NE], Prop& p) {
     const double e1 = e[0];
@@ -514,7 +547,8 @@ __device__ __forceinline__ bool three_direct(double k10, double k12, double k13,
   const bool ok = ThreeCore::eigen(k10, k12, k13, k21, k31, l);
   const double K = k10 + k12 + k13;
   const double k1331 = k13 * k31, k1221 = k12 * k21, k1231 = k12 * k31, k2113 = k21 * k13;
-  if constexpr (ABS) ea = pmx_exp(-ka * dt);
+  const double dts = dt * kNegLog2e;  // exp(-l dt) = 2^(l dts)
+  if constexpr (ABS) ea = pmx_exp2(ka * dts);
 #pragma unroll
   for (int k = 0; k < 9; ++k) p.m[k] = 0.0;
 #pragma unroll
@@ -561,7 +595,7 @@ __device__ __forceinline__ bool three_direct(double k10, double k12, double k13,
     }
     const double u = k21 - li, v = k31 - li, w = K - li;
     const double ui = u * inv, vi = v * inv;
-    const double e = pmx_exp(-(li * dt));
+    const double e = pmx_exp2(li * dts);
     const double c0 = u * vi, c3 = k12 * vi, c6 = k13 * ui;
     p.m[0] = fma(c0, e, p.m[0]);
     p.m[1] = fma(k21 * vi, e, p.m[1]);
@@ -606,8 +640,9 @@ struct Structure<S_THREE> {
   }
   static constexpr int NE = 3;
   __device__ __forceinline__ static void exps(const Coef& c, double dt, double (&e)[NE]) {
+    const double dts = dt * kNegLog2e;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) e[i] = pmx_exp(-(c.t.l[i] * dt));
+    for (int i = 0; i < 3; ++i) e[i] = pmx_exp2(c.t.l[i] * dts);
   }
   __device__ __forceinline__ static void from_exps_f(const Coef& c, const double (&e)[NE], Prop& p) { p.p.make_f(c.t, e); }
   __device__ __forceinline__ static void from_exps_j(const Coef& c, const double (&e)[NE], Prop& p) { p.p.make_j(c.t, e); }
@@ -663,9 +698,10 @@ struct Structure<S_THREE_ABS> {
   }
   static constexpr int NE = 4;
   __device__ __forceinline__ static void exps(const Coef& c, double dt, double (&e4)[NE]) {
+    const double dts = dt * kNegLog2e;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) e4[i] = pmx_exp(-(c.t.l[i] * dt));
-    e4[3] = pmx_exp(-c.ka * dt);
+    for (int i = 0; i < 3; ++i) e4[i] = pmx_exp2(c.t.l[i] * dts);
+    e4[3] = pmx_exp2(c.ka * dts);
   }
   __device__ __forceinline__ static void from_exps_f(const Coef& c, const double (&e4)[NE], Prop& p) {
     const double e[3] = {e4[0], e4[1], e4[2]};
