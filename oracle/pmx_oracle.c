@@ -717,6 +717,11 @@ static int ode_nstates(int model) {
   return (model >= 0 && model < PMX_ODE_MODEL_COUNT) ? n[model] : -1;
 }
 
+static int ode_nparams_of(int model) {
+  static const int n[PMX_ODE_MODEL_COUNT] = {1, 2, 3, 4, 5, 6, 3};
+  return (model >= 0 && model < PMX_ODE_MODEL_COUNT) ? n[model] : 0;
+}
+
 /* The user `diffeq` bodies (device functor registry mirrored here). */
 static void ode_rhs(int model, const double* x, const double* p, double* dx) {
   switch (model) {
@@ -765,7 +770,18 @@ static void ode_f(const ctx_t* c, double t, const double* x, const double* p, co
     g_custom_dynamics(t, x, p, m->n_covariates ? cv : 0, rate, 0, dx);
     return;
   }
-  ode_rhs(m->kernel, x, p, dx);
+  if (m->n_derived > 0 || m->n_bind > 0) { /* derive-style lines inside the body, covariates bound at t (expand/ode.rs:126-185) */
+    double derived[PMX_MAX_USER_DERIVED], kp[PMX_MAX_KPARAMS];
+    int np = ode_nparams_of(m->kernel);
+    if (eval_derived(c, p, t, derived)) {
+      for (int i = 0; i < m->nstates; i++) dx[i] = NAN;
+      return;
+    }
+    for (int j = 0; j < np; j++)
+      kp[j] = m->n_bind > 0 ? ((m->bind[j].src == PMX_SRC_DERIVED) ? derived[m->bind[j].index] : p[m->bind[j].index]) : p[j];
+    ode_rhs(m->kernel, x, kp, dx);
+  } else
+    ode_rhs(m->kernel, x, p, dx);
   for (int i = 0; i < m->ndrugs; i++) {
     if (rate[i] != 0.0) {
       int dest = m->infusion_dest[i] >= 0 ? m->infusion_dest[i] : ode_central_state(m->kernel);

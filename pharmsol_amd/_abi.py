@@ -260,3 +260,8 @@ def user_functions_of(source: str) -> int:
         if re.search(r"PMX_DEVICE\s+void\s+" + name + r"\s*\(", source):
             mask |= bit
     return mask
+
+# parameter names of the built-in diffeq bodies, in the order the bodies read them (include/pmx.h PMX_ODE_*)
+ODE_PARAMETER_NAMES = {"one_cmt_iv": ["ke"], "one_cmt_oral": ["ka", "ke"], "two_cmt_iv": ["ke", "kcp", "kpc"],
+                       "two_cmt_oral": ["ke", "ka", "kcp", "kpc"], "three_cmt_iv": ["k10", "k12", "k13", "k21", "k31"],
+                       "three_cmt_oral": ["ka", "k10", "k12", "k13", "k21", "k31"], "one_cmt_mm": ["vmax", "km", "v"]}

@@ -383,8 +383,15 @@ int32_t pmx_model_create(const pmx_model_desc* d, pmx_model** out) {
       return fail(PMX_ERR_INVALID_ARGUMENT, "unknown ode_solver");
     if (d->ode_solver == PMX_SOLVER_DOPRI5 && !(d->ode_rtol > 0.0 && d->ode_atol > 0.0))
       return fail(PMX_ERR_INVALID_ARGUMENT, "the adaptive solver needs ode_rtol > 0 and ode_atol > 0");
-    if (d->n_derived > 0 || d->n_bind > 0 || pm)
-      return fail(PMX_ERR_UNSUPPORTED, "derived parameters / pm indexing are not supported for ODE models yet");
+    if (pm) return fail(PMX_ERR_UNSUPPORTED, "pm indexing is not supported for ODE models");
+    if (d->n_bind != 0 && d->n_bind != ode_nparams(d->kernel))
+      return fail(PMX_ERR_INVALID_ARGUMENT, "n_bind must equal the diffeq's parameter count");
+    for (int j = 0; j < d->n_bind; ++j) {
+      const pmx_bind& b = d->bind[j];
+      if (b.src == PMX_SRC_PRIMARY ? (b.index < 0 || b.index >= d->nparams)
+                                   : (b.src != PMX_SRC_DERIVED || b.index < 0 || b.index >= d->n_derived))
+        return fail(PMX_ERR_INVALID_ARGUMENT, "bind entry out of range");
+    }
     {
       int n_lag = 0;
       for (int i = 0; i < PMX_MAX_INPUTS; ++i) n_lag += d->lag_param[i] >= 0;
@@ -409,6 +416,27 @@ int32_t pmx_model_create(const pmx_model_desc* d, pmx_model** out) {
   for (int i = 0; i < PMX_MAX_STATES; ++i) {
     if (d->init_param[i] >= d->nparams) return fail(PMX_ERR_INVALID_ARGUMENT, "init_param out of range");
     if (d->init_param[i] >= 0 && i < d->nstates) m->has_init = true;
+  }
+  if (d->eq_kind == PMX_EQ_ODE && (d->n_derived > 0 || d->n_bind > 0)) {
+    // covariate-derived parameters of a built-in diffeq body (expand/ode.rs:126-185): the body is written out as source
+    // and takes the run-time-compiled path, where covariates are looked up on the device at every stage time
+    pmx_model_desc dd = *d;
+    dd.kernel = PMX_ODE_CUSTOM;
+    dd.n_derived = 0;
+    dd.n_bind = 0;
+    pmx::JitSpec sp;
+    sp.nstates = d->nstates;
+    sp.nparams = d->nparams;
+    sp.nout = d->nout;
+    sp.ninputs = d->ndrugs > 0 ? d->ndrugs : 1;
+    sp.has_init = m->has_init;
+    sp.ncov = d->n_covariates;
+    sp.source = pmx::ode_descriptor_source(*d);
+    std::string log;
+    if (!pmx::jit_compile(sp, &m->jit_code, &log))
+      return fail(PMX_ERR_HIP, "hiprtc could not compile the generated diffeq body:\n" + log);
+    m->d = dd;
+    m->custom = true;
   }
   *out = m.release();
   return PMX_OK;

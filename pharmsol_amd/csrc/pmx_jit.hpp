@@ -26,6 +26,10 @@ struct JitSpec {
 // lag x log-likelihood x solver -, 4 for an analytical one - GRID/PAIR x log-likelihood).
 std::string jit_translation_unit(const JitSpec& spec);
 
+// Source text (pmx_dynamics / pmx_outputs / pmx_init) of a BUILT-IN diffeq body whose parameters / volumes are derived
+// from covariates through the descriptor (desc.derived[], desc.bind[]): the covariates are bound at the stage time.
+std::string ode_descriptor_source(const pmx_model_desc& d);
+
 // Compile for gfx950 (needs no device).  Returns true and fills *code (an AMDGPU code object); on failure *log has
 // the compiler's diagnostics.
 bool jit_compile(const JitSpec& spec, std::vector<char>* code, std::string* log);

@@ -526,6 +526,9 @@ class ODE(Equation):
         return _abi.PMX_ODE_CUSTOM if self.source is not None else _abi.ODE_MODELS[self.kernel_name]
 
     def _required_names(self) -> List[str]:
+        # a declared ode(...) with derived values binds the body's parameters by name, like the analytical structures
+        if self.has_metadata and self.source is None and self.derived:
+            return _abi.ODE_PARAMETER_NAMES[self.kernel_name]
         return []
 
 

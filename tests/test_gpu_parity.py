@@ -524,6 +524,62 @@ def test_c3_full_size_properties():
     assert rel_err(got, want).max() <= TOL_ANALYTICAL
 
 
+def test_c5_full_size_properties():
+    """BASELINE configs[4] whole: 200k subjects x 512 support points, three compartments + absorption, time-varying wt
+    (8.2 GB of predictions - too big for the oracle).  (1) a random sample of subjects against the oracle; (2) linearity in
+    the dose: a second pass with every amount doubled gives exactly twice the predictions of the sample (the system is
+    linear and the doubling is exact in binary); (3) every pair finite and OK; (4) the propagator kept across equal
+    segments of a subject (pmx_compile.cpp prop cache codes) against a pass that rebuilds every one: same numbers."""
+    import torch
+
+    from pharmsol_amd import _ffi
+    from pharmsol_amd.flatten import FlatPopulation
+
+    m, flat, theta = synth.config_c5(200_000, 512)
+    pop = runtime.DevicePopulation(flat, 0)
+    pred, status = runtime.predict(m, pop, theta)
+    torch.cuda.synchronize()
+    assert runtime.last_kernel_name() == "pmx_analytical_grid<dyn>"
+    assert int(status.max().item()) == 0 and bool(torch.isfinite(pred).all().item())
+    pr = pred.view(200_000, 10, 512)
+    idx = np.sort(np.random.default_rng(1).choice(200_000, size=48, replace=False))
+
+    def subset(fl):
+        ev = np.concatenate([np.arange(s * 13, s * 13 + 13) for s in idx])
+        k0, k1 = fl.cov_knot_off[idx], fl.cov_knot_off[idx + 1]
+        kn = np.concatenate([np.arange(a, b) for a, b in zip(k0, k1)])
+        return FlatPopulation(subj_occ_off=np.arange(49), occ_ev_off=np.arange(49) * 13, occ_index=np.zeros(48, np.int32),
+                              ev_time=fl.ev_time[ev], ev_value=fl.ev_value[ev], ev_duration=fl.ev_duration[ev], ev_kind=fl.ev_kind[ev],
+                              ev_io=fl.ev_io[ev], n_covariates=1, cov_knot_off=np.concatenate([[0], np.cumsum(k1 - k0)]),
+                              cov_knot_time=fl.cov_knot_time[kn], cov_knot_value=fl.cov_knot_value[kn])
+
+    want, _ = oracle.predict(m, subset(flat), theta)
+    got = pr[torch.as_tensor(idx, device="cuda")].reshape(480, 512).cpu().numpy()
+    assert rel_err(got, want).max() <= TOL_ANALYTICAL
+    # (4) no propagator reuse: rebuild on every segment
+    import os
+
+    os.environ["PMX_TUNE_PROP_SLOTS"] = "0"
+    _ffi.lib().pmx_debug_reload_env()
+    try:
+        pop0 = runtime.DevicePopulation(flat, 0)
+        pred0, _ = runtime.predict(m, pop0, theta)
+        torch.cuda.synchronize()
+        dev = float(((pred0 - pred).abs() / pred.abs().clamp_min(1e-12)).max().item())
+        assert dev < 1e-12, dev
+        del pred0, pop0
+    finally:
+        del os.environ["PMX_TUNE_PROP_SLOTS"]
+        _ffi.lib().pmx_debug_reload_env()
+    # (2) doubled doses
+    flat2 = synth.population_c5(200_000)
+    flat2.ev_value = np.where(flat2.ev_kind == _abi.PMX_EV_BOLUS, 2.0 * flat2.ev_value, flat2.ev_value)
+    pred2, _ = runtime.predict(m, runtime.DevicePopulation(flat2, 0), theta, pred=pred)
+    torch.cuda.synchronize()
+    got2 = pred2.view(200_000, 10, 512)[torch.as_tensor(idx, device="cuda")].reshape(480, 512).cpu().numpy()
+    np.testing.assert_array_equal(got2, 2.0 * got)
+
+
 def test_c4_full_size_against_closed_form():
     m, flat, theta = synth.config_c4(50_000)
     got, st = gpu_predict(m, flat, theta, batch=True)
