@@ -169,6 +169,9 @@ def main():
         if args.ragged:
             bound = "fp64_valu"
             label += " (jittered sampling times)"
+        if args.no_class or args.loglik:  # the generic walker / the fused fold are instruction-bound, not write-bound
+            bound = "fp64_valu"
+            counters_key += "_generic" if args.no_class else "_loglik"
         dtype_tol = 1e-6
     elif args.workload == "c4":
         S_arg = 50_000 if args.subjects == 100_000 else args.subjects
@@ -416,7 +419,7 @@ def main():
         # tools/kernel_counters.py): per-launch HBM traffic and vector wave-instructions of the dominant kernel
         counters, counters_src = {}, None
         cpath = os.path.join(ROOT, "profiles", "kernel_counters.json")
-        full_size = (world == 1 or not strong) and not args.loglik and not args.no_class and \
+        full_size = (world == 1 or not strong) and \
             S_arg == {"c3": 100_000, "c2": 10_000, "c4": 50_000, "c5": 200_000}[args.workload] and \
             P == {"c3": 1000, "c2": 1, "c4": 1, "c5": 512}[args.workload]
         if full_size and os.path.exists(cpath):

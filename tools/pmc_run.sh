@@ -5,7 +5,7 @@ set -u
 export TMPDIR=/tmp
 OUT=$1; shift
 mkdir -p "$OUT"
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline $*"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --place-gib 0 $*"
 i=0
 for set in \
   "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \

@@ -1,15 +1,32 @@
 #!/bin/bash
-# Round profile: rocprofv3 kernel-trace stats of the default bench command + PMC traffic passes.
+# Round profile (run on the GPU box): the default bench line; rocprofv3 kernel traces of the placed and the
+# first-allocation run with the timed passes isolated (last K dispatches); PMC passes (separate runs, counters only) for
+# the headline and the compute-bound workloads -> profiles/kernel_counters.json.
 # usage: tools/profile_round.sh <tag>      (outputs under gpurun_out/prof_<tag>/)
 set -u
 export TMPDIR=/tmp
 TAG=$1
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
+K=20
 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o kt -- python3 bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.err; echo "trace rc=$?"
-tools/pmc_run.sh $OUT/pmc > $OUT/pmc.log 2>&1; echo "pmc rc=$?"
+for mode in placed first; do
+  extra=""; [ $mode = first ] && extra="--place-gib 0"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$mode -o kt -- python3 bench.py --no-cpu-baseline --steps $K $extra > $OUT/bench_under_rocprof_$mode.json 2> $OUT/trace_$mode.err; echo "trace $mode rc=$?"
+  kt=$(find $OUT/trace_$mode -name "*kernel_trace.csv" | head -1)
+  python3 tools/trace_last_k.py "$kt" $K $OUT/bench_under_rocprof_$mode.json > $OUT/trace_${mode}_last_k.json; cat $OUT/trace_${mode}_last_k.json
+  st=$(find $OUT/trace_$mode -name "*kernel_stats.csv" | head -1); cp "$st" $OUT/kernel_stats_$mode.csv
+done
+for w in "c3:" "c5:--workload c5" "c3_ragged:--ragged" "c4:--workload c4"; do
+  key=${w%%:*}; args=${w#*:}
+  tools/pmc_run.sh $OUT/pmc_$key $args > $OUT/pmc_$key.log 2>&1; echo "pmc $key rc=$?"
+  python3 tools/pmc_summary.py $OUT/pmc_$key $OUT/pmc_$key.json > $OUT/pmc_$key.txt
+  python3 tools/kernel_counters.py $key $OUT/pmc_$key.json "round $TAG build: rocprofv3 --pmc, separate passes (tools/pmc_run.sh $args), mean per dispatch" > /dev/null
+done
+cp profiles/kernel_counters.json $OUT/kernel_counters.json
 for w in c2 c4 c5; do python bench.py --workload $w --no-cpu-baseline --steps 10 > $OUT/bench_$w.json 2>> $OUT/bench.err; done
+python bench.py --ragged --no-cpu-baseline --steps 10 > $OUT/bench_c3_ragged.json 2>> $OUT/bench.err
+python bench.py --loglik --no-cpu-baseline --steps 10 > $OUT/bench_c3_loglik.json 2>> $OUT/bench.err
 python bench.py --no-class --no-cpu-baseline --steps 10 > $OUT/bench_c3_generic.json 2>> $OUT/bench.err
-PMX_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 5 --warmup 2 --subjects 20000 > $OUT/bench_2rank_gloo_rehearsal.json 2> $OUT/rehearsal.err; echo "rehearsal rc=$?"
+PMX_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 5 --warmup 2 --subjects 50000 --scaling strong --no-cpu-baseline > $OUT/bench_2rank_gloo_rehearsal.json 2> $OUT/rehearsal.err; echo "rehearsal rc=$?"
 cat $OUT/bench.json
