@@ -974,6 +974,12 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
   std::memcpy(a.m.out, d.out, sizeof(d.out));
   if (state_override >= 0)  // Prediction::state: every output equation reads the raw amount of one state
     for (int o = 0; o < PMX_MAX_OUT; ++o) a.m.out[o] = pmx_out{state_override, PMX_SRC_NONE, 0};
+  for (int o = 0; o < PMX_MAX_OUT; ++o) {
+    a.m.out_vol_theta[o] = -1;
+    if (a.m.out[o].vol_src == PMX_SRC_PRIMARY) a.m.out_vol_theta[o] = a.m.out[o].vol_index;
+    if (a.m.out[o].vol_src == PMX_SRC_DERIVED && a.m.out[o].vol_index >= 0 && a.m.out[o].vol_index < PMX_MAX_DERIVED)
+      a.m.out_vol_theta[o] = d.derived[a.m.out[o].vol_index].src_param;
+  }
   std::memcpy(a.m.init_param, d.init_param, sizeof(d.init_param));
   std::memcpy(a.m.bolus_dest, d.bolus_dest, sizeof(d.bolus_dest));
   std::memcpy(a.m.infusion_dest, d.infusion_dest, sizeof(d.infusion_dest));

@@ -32,6 +32,8 @@ struct DevModel {
   int32_t lag_input[4];               // slot -> input
   int32_t lag_param[4];               // slot -> theta index of the lag time
   int32_t lag_dest[4];                // slot -> state that receives the bolus
+  int32_t out_vol_theta[PMX_MAX_OUT]; // theta index behind each output's volume when it is lane-constant (a primary
+                                      // parameter, or a derived value without covariate factors: its base parameter); -1 = none
   double rk4_h_max;                   // ODE + lag: pieces split on the device recompute n = ceil(dt / h_max)
   double ode_rtol, ode_atol;          // adaptive solver (PMX_SOLVER_DOPRI5)
 };

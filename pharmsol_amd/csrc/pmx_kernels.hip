@@ -736,17 +736,22 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
         int out_state = m.out[0].state - m.pm;
         double inv_vol = inv_vol0;
         if (oq != 0) {  // outputs beyond the first: rare, re-derive the volume instead of keeping 4 live
+          // ONE descriptor fetch each for state and volume (the host resolved "theta index behind the volume", derived
+          // values without covariate factors included: DevModel::out_vol_theta).  The compiler hoists these scalar
+          // fetches in front of the branch, into every observation step of the single-output case: with the six
+          // fetches + select chain of a device-side resolution C3 went from 0.83 to 0.97 ms.
+          //
+          // The volume's load must be CONSUMED inside this block on every path: when the division sat behind an
+          // exec-masked skip (lanes with complex roots), the load was still pending at the join and the waitcnt pass
+          // put `s_waitcnt vmcnt(0)` into the common emit path - every observation step then waited for all earlier
+          // prediction stores (C3 0.83 -> 0.98 ms).  Hence: divide unconditionally, pin the quotient, select after.
           out_state = m.out[oq].state - m.pm;
-          // (the volume may be a derived value WITHOUT covariate factors, which is still classed: its base parameter)
-          int vp = -1;
-          if (m.out[oq].vol_src == PMX_SRC_PRIMARY) vp = m.out[oq].vol_index;
-          if (m.out[oq].vol_src == PMX_SRC_DERIVED) {
-#pragma unroll
-            for (int dd = 0; dd < PMX_MAX_DERIVED; ++dd)
-              if (dd == m.out[oq].vol_index) vp = m.derived[dd].src_param;
-          }
-          const double v = (vp >= 0) ? th[vp] : 1.0;
-          inv_vol = (lane_good && !lane_badlag) ? 1.0 / v : __longlong_as_double(0x7ff8000000000000LL);
+          const int vp = m.out_vol_theta[oq];
+          double v = 1.0;
+          if (vp >= 0) v = th[vp];  // (scalar condition)
+          double iv = 1.0 / v;
+          asm volatile("" : "+v"(iv));
+          inv_vol = (lane_good && !lane_badlag) ? iv : __longlong_as_double(0x7ff8000000000000LL);
         }
         if constexpr (LL) {
           // fold the G predictions into the members' sums instead of storing them (ll_accumulate, per member;

@@ -287,3 +287,20 @@ def test_class_planner_exact_loose_and_generic_subjects():
     plan = runtime.class_plan(model, model.flatten(Data(subs)))
     # 20 exact -> 3 chunks of 8; 13 loose -> 2 chunks; 3 + the empty subject stay generic
     assert plan == dict(chunks_exact=3, chunks_loose=2, classed_subjects=33, generic_subjects=4, members_per_chunk=8)
+
+
+def test_prediction_stores_of_the_write_bound_kernels_stay_fire_and_forget():
+    """tools/isa_guard.py: on gfx950 loads and stores share one in-order counter, so a `s_waitcnt vmcnt(..)` that lands in
+    the emit path (a rarely taken branch leaving a vector load pending at a join did it once: C3 0.83 -> 0.98 ms) makes
+    every observation step wait for all earlier prediction stores.  The compiled assembly of every exact / loose prediction
+    instantiation of the classed kernel must have no vmcnt wait in a block that holds a 16-byte prediction store.
+    (Compiles pmx_kernels.hip to assembly once - about 90 s - and reuses it while the sources do not change.)"""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("isa_guard", os.path.join(root, "tools", "isa_guard.py"))
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    n, bad = g.check(g.assembly())
+    assert n == 24 and not bad, bad
