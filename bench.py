@@ -71,7 +71,7 @@ def parse_args(argv=None):
                     help="time the fused log-likelihood entry (pmx_loglik_device) instead of predictions: output S x P")
     ap.add_argument("--spin-up-ms", type=float, default=80.0,
                     help="untimed back-to-back passes before the warm-up, to bring the device clocks up after set-up")
-    ap.add_argument("--place-gib", type=float, default=24.0,
+    ap.add_argument("--place-gib", type=float, default=64.0,
                     help="size of the arena searched for the fastest window for the prediction matrix "
                          "(runtime.place_predictions; capped at 40 %% of the free device memory); 0 = plain first allocation")
     ap.add_argument("--alloc-tries", type=int, default=8,

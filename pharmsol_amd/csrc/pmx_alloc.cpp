@@ -114,6 +114,10 @@ int32_t pmx_prediction_buffer_create(const pmx_model* model, const pmx_populatio
       best = i;
     }
   }
+  if (const char* e = std::getenv("PMX_TUNE_PLACE_WINDOW")) {  // experiments: take this window whatever it measured
+    const long w = std::atol(e);
+    if (w >= 0 && static_cast<size_t>(w) < t.size()) best = static_cast<size_t>(w);
+  }
   if (!t.empty()) best_ms = t[best];
   if (rc != PMX_OK) {
     release(a);
