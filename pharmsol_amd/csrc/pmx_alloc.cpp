@@ -92,32 +92,43 @@ int32_t pmx_prediction_buffer_create(const pmx_model* model, const pmx_populatio
   std::vector<double> t;
   // a pass that moves less than ~1.5 TB/s of predictions is not write-bound: where the matrix sits is moot, take window 0
   const bool write_bound = rc == PMX_OK && ms > 0.0 && static_cast<double>(need) / (ms * 1.0e-3) > 1.5e12;
-  if (!write_bound && rc == PMX_OK) t.push_back(ms);
-  for (size_t i = 0; write_bound && rc == PMX_OK && i + win_chunks <= a.handles.size(); ++i) {
-    double* w = reinterpret_cast<double*>(static_cast<char*>(a.va) + i * chunk);
-    rc = pmx_time_predict_device(model, pop, d_theta, n_support, w, n_support, 4, stream, &ms);
-    if (std::getenv("PMX_DEBUG_PLACEMENT")) std::fprintf(stderr, "[pmx] window at chunk %zu (%.2f GiB): %.4f ms\n", i, i * chunk / 1073741824.0, ms);
-    t.push_back(ms);
-  }
-  // fast memory comes in plateaus several windows wide: take the window whose worse neighbour is best, i.e. one from
-  // the inside of a plateau rather than its edge
+  const bool debug = std::getenv("PMX_DEBUG_PLACEMENT") != nullptr;
+  // PMX_TUNE_PLACE_WINDOW=i: take window i without searching (profiling runs: the landscape of an arena repeats from
+  // process to process on one box, so a traced run can sit where an untraced one found the best window and the trace
+  // holds no search dispatches)
+  long forced = -1;
+  if (const char* e = std::getenv("PMX_TUNE_PLACE_WINDOW")) forced = std::atol(e);
+  if (forced >= 0 && static_cast<size_t>(forced) + win_chunks > a.handles.size()) forced = -1;
   size_t best = 0;
   double best_ms = 1e300;
-  for (size_t i = 0; i < t.size(); ++i) {
-    double score = t[i];
-    if (t.size() >= 3) {
-      if (i > 0) score = score > t[i - 1] ? score : t[i - 1];
-      if (i + 1 < t.size()) score = score > t[i + 1] ? score : t[i + 1];
+  if (forced >= 0 && rc == PMX_OK) {
+    best = static_cast<size_t>(forced);
+    double* w = reinterpret_cast<double*>(static_cast<char*>(a.va) + best * chunk);
+    rc = pmx_time_predict_device(model, pop, d_theta, n_support, w, n_support, 4, stream, &ms);
+    t.assign(best + 1, ms);
+  } else {
+    if (!write_bound && rc == PMX_OK) t.push_back(ms);
+    for (size_t i = 0; write_bound && rc == PMX_OK && i + win_chunks <= a.handles.size(); ++i) {
+      double* w = reinterpret_cast<double*>(static_cast<char*>(a.va) + i * chunk);
+      rc = pmx_time_predict_device(model, pop, d_theta, n_support, w, n_support, 4, stream, &ms);
+      if (debug) std::fprintf(stderr, "[pmx] window at chunk %zu (%.2f GiB): %.4f ms\n", i, i * chunk / 1073741824.0, ms);
+      t.push_back(ms);
     }
-    if (score < best_ms) {
-      best_ms = score;
-      best = i;
+    // fast memory comes in plateaus several windows wide: take the window whose worse neighbour is best, i.e. one from
+    // the inside of a plateau rather than its edge
+    for (size_t i = 0; i < t.size(); ++i) {
+      double score = t[i];
+      if (t.size() >= 3) {
+        if (i > 0) score = score > t[i - 1] ? score : t[i - 1];
+        if (i + 1 < t.size()) score = score > t[i + 1] ? score : t[i + 1];
+      }
+      if (score < best_ms) {
+        best_ms = score;
+        best = i;
+      }
     }
   }
-  if (const char* e = std::getenv("PMX_TUNE_PLACE_WINDOW")) {  // experiments: take this window whatever it measured
-    const long w = std::atol(e);
-    if (w >= 0 && static_cast<size_t>(w) < t.size()) best = static_cast<size_t>(w);
-  }
+  if (debug) std::fprintf(stderr, "[pmx] chosen window %zu\n", best);
   if (!t.empty()) best_ms = t[best];
   if (rc != PMX_OK) {
     release(a);

@@ -1068,17 +1068,19 @@ hipError_t launch_analytical(const LaunchArgs& a, const char** name) {
         // (the log-likelihood variant writes almost nothing: it prefers fewer, longer blocks that amortise the lane setup)
         const bool ll = a.ops.ll_obs != nullptr;
         const int64_t n_exact = a.cls.n_chunks_exact, n_loose = a.cls.n_chunks - a.cls.n_chunks_exact;
-        auto blocks_for = [&](int64_t n, int64_t* cpb_out) {
-          int64_t cpb = (n * a.n_ptiles) / (ll ? 8192 : 32768);
+        // (the loose launch is FP64-bound too and behaves the same: 4 chunks per block 1.83 ms, one 1.88 ms, eight 1.84 ms
+        // on jittered C3, profiles/r02_loose_chunks_per_block.txt)
+        auto blocks_for = [&](int64_t n, bool loose, int64_t* cpb_out) {
+          int64_t cpb = (n * a.n_ptiles) / ((ll || loose) ? 8192 : 32768);
           if (cpb < 1) cpb = 1;
-          if (cpb > 8) cpb = 8;
+          if (cpb > (loose && !ll ? 4 : 8)) cpb = loose && !ll ? 4 : 8;
           if (a.tune_cpb > 0) cpb = a.tune_cpb;  // tuning experiments (PMX_TUNE_CPB, read once by pmx_api.cpp)
           *cpb_out = cpb;
           return ((n + cpb - 1) / cpb + 7) / 8 * 8;  // whole XCD groups
         };
         auto launch_cls = [&](auto ll_c, auto perdt_c, auto cens_c, int64_t n) {
           int64_t cpb = 1;
-          const int64_t cblocks = blocks_for(n, &cpb);
+          const int64_t cblocks = blocks_for(n, decltype(perdt_c)::value, &cpb);
           hipLaunchKernelGGL((pmx_analytical_classed<KID, decltype(ll_c)::value, decltype(perdt_c)::value, LAG, decltype(cens_c)::value,
                                                      (DYN && decltype(perdt_c)::value)>),
                              dim3(static_cast<uint32_t>(cblocks * a.n_ptiles)), dim3(grid_threads(a.P)), 0, st, a.m, a.ops, a.cls,

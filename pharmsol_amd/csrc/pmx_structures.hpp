@@ -35,26 +35,25 @@ namespace pmx {
 
 // exp() for the propagators' arguments (-lambda dt: finite, almost always <= 0).  Same scheme as the library's
 // (n = rint(x log2 e), r = x - n ln2 in two pieces, polynomial, scale by 2^n) without its special-case selects:
-// degree-13 Taylor on |r| <= ln2/2 (truncation 4e-18), Horner in FMAs; v_ldexp saturates to 0 / inf by itself and NaN
-// propagates.  ~19 VALU instructions instead of ~30, results within 1-2 ulp of the library's.  (Keeping the 16
-// constants resident in VGPRs instead of literals was tried for the generic kernel: one wave of occupancy less,
-// 6 % slower.)
+// a degree-11 near-minimax polynomial on |r| <= ln2/2 (Chebyshev fit of e^r in 60-digit arithmetic, tools/exp_poly_fit.py:
+// approximation error 3.2e-18, i.e. the result is as good as the Horner evaluation in FMAs, within 1-2 ulp of the
+// library's; the degree-13 Taylor series this replaced was no more accurate and two FMAs longer); v_ldexp saturates to
+// 0 / inf by itself and NaN propagates.  ~17 VALU instructions instead of ~30.  (Keeping the constants resident in VGPRs
+// instead of literals was tried for the generic kernel: one wave of occupancy less, 6 % slower.)
 __device__ __forceinline__ double pmx_exp_poly(double x) {
   const double n = __builtin_rint(x * 1.4426950408889634074);
   double r = fma(n, -6.93147180369123816490e-01, x);  // ln2 high part: 21 trailing zero bits, n * hi is exact
   r = fma(n, -1.90821492927058770002e-10, r);
-  double p = 1.6059043836821614599e-10;  // 1/13!
-  p = fma(p, r, 2.0876756987868098979e-09);
-  p = fma(p, r, 2.5052108385441718775e-08);
-  p = fma(p, r, 2.7557319223985890653e-07);
-  p = fma(p, r, 2.7557319223985892511e-06);
-  p = fma(p, r, 2.4801587301587301566e-05);
-  p = fma(p, r, 1.9841269841269841253e-04);
-  p = fma(p, r, 1.3888888888888889419e-03);
-  p = fma(p, r, 8.3333333333333332177e-03);
-  p = fma(p, r, 4.1666666666666664354e-02);
-  p = fma(p, r, 1.6666666666666665741e-01);
-  p = fma(p, r, 0.5);
+  double p = 2.5110180394444085e-08;
+  p = fma(p, r, 2.763282532538488e-07);
+  p = fma(p, r, 2.7557240532217283e-06);
+  p = fma(p, r, 2.480148497989361e-05);
+  p = fma(p, r, 0.00019841269890408497);
+  p = fma(p, r, 0.0013888888952784725);
+  p = fma(p, r, 0.008333333333319464);
+  p = fma(p, r, 0.04166666666648633);
+  p = fma(p, r, 0.1666666666666668);
+  p = fma(p, r, 0.5000000000000019);
   p = fma(p, r, 1.0);
   p = fma(p, r, 1.0);
   return ldexp(p, static_cast<int>(n));
@@ -62,26 +61,46 @@ __device__ __forceinline__ double pmx_exp_poly(double x) {
 
 // 2^t for the propagators: every exponential there is exp(-lambda dt), and lambda can carry the factor -log2(e) from the
 // once-per-lane (or once-per-rebuild) set-up, so the argument arrives in base 2: n = rint(t), r = t - n EXACTLY (no
-// two-piece ln2 reduction), degree-13 polynomial in r with coefficients ln2^k / k! (|r| <= 1/2: truncation 4e-18), scale
-// by 2^n.  17 FP64-rate instructions; the rounding of t = lambda' dt is the same one ulp the product -lambda dt had.
+// two-piece ln2 reduction), degree-11 near-minimax polynomial of 2^r on |r| <= 1/2 (same fit: approximation error 3.2e-18,
+// 1.7e-16 worst relative error with the double coefficients), scale by 2^n.  15 FP64-rate instructions; the rounding of
+// t = lambda' dt is the same one ulp the product -lambda dt had.
 __device__ __forceinline__ double pmx_exp2(double t) {
   const double n = __builtin_rint(t);
   const double r = t - n;
-  double p = 1.3691488853904128881e-12;
-  p = fma(p, r, 2.5678435993488205142e-11);
-  p = fma(p, r, 4.4455382718708114976e-10);
-  p = fma(p, r, 7.0549116208011233299e-09);
-  p = fma(p, r, 1.0178086009239699727e-07);
-  p = fma(p, r, 1.3215486790144309488e-06);
-  p = fma(p, r, 1.525273380405984028e-05);
-  p = fma(p, r, 1.5403530393381609954e-04);
-  p = fma(p, r, 1.3333558146428443423e-03);
-  p = fma(p, r, 9.618129107628477162e-03);
-  p = fma(p, r, 5.5504108664821579953e-02);
-  p = fma(p, r, 2.4022650695910071233e-01);
-  p = fma(p, r, 6.9314718055994530942e-01);
+  double p = 4.4558179083360645e-10;
+  p = fma(p, r, 7.074194297288521e-09);
+  p = fma(p, r, 1.0178057087733941e-07);
+  p = fma(p, r, 1.3215432535912375e-06);
+  p = fma(p, r, 1.5252733841556773e-05);
+  p = fma(p, r, 0.00015403530463724353);
+  p = fma(p, r, 0.001333355814640647);
+  p = fma(p, r, 0.009618129107587256);
+  p = fma(p, r, 0.055504108664821625);
+  p = fma(p, r, 0.24022650695910158);
+  p = fma(p, r, 0.6931471805599453);
   p = fma(p, r, 1.0);
   return ldexp(p, static_cast<int>(n));
+}
+// N of them at once, the Horner chains interleaved coefficient by coefficient: one chain alone is eleven FMAs that each
+// wait for the one before (the compiler emits N calls back to back as N such chains)
+template <int N>
+__device__ __forceinline__ void pmx_exp2_n(const double (&t)[N], double (&e)[N]) {
+  constexpr double kC[11] = {7.074194297288521e-09, 1.0178057087733941e-07, 1.3215432535912375e-06, 1.5252733841556773e-05,
+                             0.00015403530463724353, 0.001333355814640647,  0.009618129107587256,  0.055504108664821625,
+                             0.24022650695910158,    0.6931471805599453,    1.0};
+  double n[N], r[N], p[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    n[k] = __builtin_rint(t[k]);
+    r[k] = t[k] - n[k];
+    p[k] = 4.4558179083360645e-10;
+  }
+#pragma unroll
+  for (int i = 0; i < 11; ++i)
+#pragma unroll
+    for (int k = 0; k < N; ++k) p[k] = fma(p[k], r[k], kC[i]);
+#pragma unroll
+  for (int k = 0; k < N; ++k) e[k] = ldexp(p[k], static_cast<int>(n[k]));
 }
 constexpr double kNegLog2e = -1.4426950408889634074;  // lambda' = -lambda log2(e):  exp(-lambda dt) = 2^(lambda' dt)
 
@@ -215,8 +234,8 @@ struct Structure<S_ONE_ABS> {
   }
   static constexpr int NE = 2;
   __device__ __forceinline__ static void exps(const Coef& c, double dt, double (&e)[NE]) {
-    e[0] = pmx_exp2(c.ka2 * dt);
-    e[1] = pmx_exp2(c.ke2 * dt);
+    const double t[2] = {c.ka2 * dt, c.ke2 * dt};
+    pmx_exp2_n<2>(t, e);
   }
   __device__ __forceinline__ static void from_exps_f(const Coef& c, const double (&e)[NE], Prop& p) {
     p.ea = e[0];
@@ -321,8 +340,8 @@ struct Structure<S_TWO> {
   }
   static constexpr int NE = 2;
   __device__ __forceinline__ static void exps(const Coef& c, double dt, double (&e)[NE]) {
-    e[0] = pmx_exp2(c.t.l1s * dt);
-    e[1] = pmx_exp2(c.t.l2s * dt);
+    const double t[2] = {c.t.l1s * dt, c.t.l2s * dt};
+    pmx_exp2_n<2>(t, e);
   }
   __device__ __forceinline__ static void from_exps_f(const Coef& c, const double (&e)[NE], Prop& p) { p.p.make_f(c.t, e[0], e[1]); }
   __device__ __forceinline__ static void from_exps_j(const Coef& c, const double (&e)[NE], Prop& p) { p.p.make_j(c.t, e[0], e[1]); }
@@ -373,9 +392,8 @@ struct Structure<S_TWO_ABS> {
   }
   static constexpr int NE = 3;
   __device__ __forceinline__ static void exps(const Coef& c, double dt, double (&e)[NE]) {
-    e[0] = pmx_exp2(c.t.l1s * dt);
-    e[1] = pmx_exp2(c.t.l2s * dt);
-    e[2] = pmx_exp2(c.ka2 * dt);
+    const double t[3] = {c.t.l1s * dt, c.t.l2s * dt, c.ka2 * dt};
+    pmx_exp2_n<3>(t, e);
   }
   __device__ __forceinline__ static void from_exps_f(const Coef& c, const double (&e)[NE], Prop& p) {
     const double e1 = e[0];
@@ -548,7 +566,24 @@ __device__ __forceinline__ bool three_direct(double k10, double k12, double k13,
   const double K = k10 + k12 + k13;
   const double k1331 = k13 * k31, k1221 = k12 * k21, k1231 = k12 * k31, k2113 = k21 * k13;
   const double dts = dt * kNegLog2e;  // exp(-l dt) = 2^(l dts)
+#ifdef PMX_THREE_SEQ_EXP
   if constexpr (ABS) ea = pmx_exp2(ka * dts);
+#else
+  // the segment's exponentials as one interleaved batch (pmx_exp2_n), ahead of the coefficient loop
+  double ev[3];
+  if constexpr (ABS) {
+    const double t4[4] = {l[0] * dts, l[1] * dts, l[2] * dts, ka * dts};
+    double e4[4];
+    pmx_exp2_n<4>(t4, e4);
+    ev[0] = e4[0];
+    ev[1] = e4[1];
+    ev[2] = e4[2];
+    ea = e4[3];
+  } else {
+    const double t3[3] = {l[0] * dts, l[1] * dts, l[2] * dts};
+    pmx_exp2_n<3>(t3, ev);
+  }
+#endif
 #pragma unroll
   for (int k = 0; k < 9; ++k) p.m[k] = 0.0;
 #pragma unroll
@@ -595,7 +630,11 @@ __device__ __forceinline__ bool three_direct(double k10, double k12, double k13,
     }
     const double u = k21 - li, v = k31 - li, w = K - li;
     const double ui = u * inv, vi = v * inv;
+#ifdef PMX_THREE_SEQ_EXP
     const double e = pmx_exp2(li * dts);
+#else
+    const double e = ev[i];
+#endif
     const double c0 = u * vi, c3 = k12 * vi, c6 = k13 * ui;
     p.m[0] = fma(c0, e, p.m[0]);
     p.m[1] = fma(k21 * vi, e, p.m[1]);
@@ -641,8 +680,8 @@ struct Structure<S_THREE> {
   static constexpr int NE = 3;
   __device__ __forceinline__ static void exps(const Coef& c, double dt, double (&e)[NE]) {
     const double dts = dt * kNegLog2e;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) e[i] = pmx_exp2(c.t.l[i] * dts);
+    const double t[3] = {c.t.l[0] * dts, c.t.l[1] * dts, c.t.l[2] * dts};
+    pmx_exp2_n<3>(t, e);
   }
   __device__ __forceinline__ static void from_exps_f(const Coef& c, const double (&e)[NE], Prop& p) { p.p.make_f(c.t, e); }
   __device__ __forceinline__ static void from_exps_j(const Coef& c, const double (&e)[NE], Prop& p) { p.p.make_j(c.t, e); }
@@ -699,9 +738,8 @@ struct Structure<S_THREE_ABS> {
   static constexpr int NE = 4;
   __device__ __forceinline__ static void exps(const Coef& c, double dt, double (&e4)[NE]) {
     const double dts = dt * kNegLog2e;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) e4[i] = pmx_exp2(c.t.l[i] * dts);
-    e4[3] = pmx_exp2(c.ka * dts);
+    const double t[4] = {c.t.l[0] * dts, c.t.l[1] * dts, c.t.l[2] * dts, c.ka * dts};
+    pmx_exp2_n<4>(t, e4);
   }
   __device__ __forceinline__ static void from_exps_f(const Coef& c, const double (&e4)[NE], Prop& p) {
     const double e[3] = {e4[0], e4[1], e4[2]};

@@ -9,14 +9,19 @@ TAG=$1
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 K=20
-python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
+PMX_DEBUG_PLACEMENT=1 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
+# the traced "placed" run sits in the window the untraced run chose (an arena's landscape repeats from process to
+# process on one box) without searching, so the trace and its --stats average hold passes into that window only
+WIN=$(grep "chosen window" $OUT/bench.err | tail -1 | awk '{print $4}'); echo "window ${WIN:-none}"
 for mode in placed first; do
   extra=""; [ $mode = first ] && extra="--place-gib 0"
+  export -n PMX_TUNE_PLACE_WINDOW; [ $mode = placed ] && [ -n "${WIN:-}" ] && export PMX_TUNE_PLACE_WINDOW=$WIN
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$mode -o kt -- python3 bench.py --no-cpu-baseline --steps $K $extra > $OUT/bench_under_rocprof_$mode.json 2> $OUT/trace_$mode.err; echo "trace $mode rc=$?"
   kt=$(find $OUT/trace_$mode -name "*kernel_trace.csv" | head -1)
   python3 tools/trace_last_k.py "$kt" $K $OUT/bench_under_rocprof_$mode.json > $OUT/trace_${mode}_last_k.json; cat $OUT/trace_${mode}_last_k.json
   st=$(find $OUT/trace_$mode -name "*kernel_stats.csv" | head -1); cp "$st" $OUT/kernel_stats_$mode.csv
 done
+unset PMX_TUNE_PLACE_WINDOW
 for w in "c3:" "c5:--workload c5" "c3_ragged:--ragged" "c4:--workload c4"; do
   key=${w%%:*}; args=${w#*:}
   tools/pmc_run.sh $OUT/pmc_$key $args > $OUT/pmc_$key.log 2>&1; echo "pmc $key rc=$?"
