@@ -71,8 +71,8 @@ def parse_args(argv=None):
                     help="time the fused log-likelihood entry (pmx_loglik_device) instead of predictions: output S x P")
     ap.add_argument("--spin-up-ms", type=float, default=80.0,
                     help="untimed back-to-back passes before the warm-up, to bring the device clocks up after set-up")
-    ap.add_argument("--place-gib", type=float, default=64.0,
-                    help="size of the arena searched for the fastest window for the prediction matrix "
+    ap.add_argument("--place-gib", type=float, default=96.0,
+                    help="size limit of the arena searched for a fast window for the prediction matrix "
                          "(runtime.place_predictions; capped at 40 %% of the free device memory); 0 = plain first allocation")
     ap.add_argument("--alloc-tries", type=int, default=8,
                     help="fallback when the arena cannot be mapped: candidate allocations, the fastest is kept")
@@ -241,13 +241,14 @@ def main():
             pred = torch.empty((n_obs, ld), dtype=torch.float64, device=dev)[:, :P]
         elif want_placement:
             # where the matrix lands in HBM changes the write rate of the row-strided stream by up to 25 %: the library maps
-            # an arena, times the kernel into every window of it, keeps the best window and returns the rest (set-up,
-            # outside the timed region; the buffer is then reused by every pass)
+            # an arena window by window, times the kernel into each, stops inside the first fast plateau (or at the size
+            # limit), keeps that window and returns the rest (set-up, outside the timed region; the buffer is then reused
+            # by every pass)
             free_b, _tot = torch.cuda.mem_get_info(dev)
             gib = min(args.place_gib, 0.4 * free_b / (1 << 30))
             try:
                 pred = runtime.place_predictions(model, pop, d_theta, search_gib=gib)
-                placed = "best window of a %.0f GiB arena (%.3f ms during the search)" % (gib, pred._pmx_owner.ms_per_pass)
+                placed = "placed window, arena limit %.0f GiB (%.3f ms during the search)" % (gib, pred._pmx_owner.ms_per_pass)
             except Exception as e:  # no virtual-memory API / not enough memory: best of a few plain allocations
                 alloc_log = []
                 pred = runtime.alloc_predictions(model, pop, d_theta, tries=args.alloc_tries, log=alloc_log)

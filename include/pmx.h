@@ -294,9 +294,11 @@ int32_t pmx_time_predict_device(const pmx_model* model, const pmx_population* po
                                 double* ms_per_pass);
 
 /* A prediction matrix [n_observations x n_support] (ld = n_support) placed where the kernel writes it fastest: an
- * arena of `search_bytes` (at least the matrix; 0 = just the matrix) is mapped from separately allocated physical chunks,
- * the real kernel is timed into every window of it, the chunks under the best window are kept and all others are
- * returned to the device.  *ms_per_pass receives the pass time measured in the chosen window.  Current device =
+ * arena of up to `search_bytes` (at least the matrix; 0 = just the matrix) is mapped window by window from separately
+ * allocated physical chunks and the real kernel is timed into each; the search stops inside the first plateau of the
+ * fast kind (three neighbouring windows at >= 6.4 TB/s, or 15 % faster than the slowest seen) or at `search_bytes`; the
+ * chunks under the chosen window are kept and all others are returned to the device.  *ms_per_pass receives the pass
+ * time measured in the chosen window.  Current device =
  * the population's.  Free with pmx_prediction_buffer_destroy. */
 int32_t pmx_prediction_buffer_create(const pmx_model* model, const pmx_population* pop, const double* d_theta,
                                      int64_t n_support, int64_t search_bytes, void* stream, double** d_pred,

@@ -3,8 +3,9 @@
 // On MI355X the rate of the prediction stream depends on WHERE in device memory the matrix sits (the same kernel:
 // 0.81-0.90 ms in some 5.6 GB windows, 1.04-1.12 ms in most; linear fills do not care; tools/store_pattern_probe.hip
 // `arena`).  Nothing in the HIP API says which memory is the fast kind, so this helper measures: it maps
-// an arena out of separately allocated physical chunks (HIP virtual-memory API), times the real kernel into windows
-// of the arena, keeps the chunks under the best window and gives every other chunk back.
+// an arena out of separately allocated physical chunks (HIP virtual-memory API) window by window, times the real kernel
+// into each, stops inside the first plateau of the fast kind (or at the arena's size limit, with the best window seen),
+// keeps the chunks under the chosen window and gives every other chunk back.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -64,28 +65,41 @@ int32_t pmx_prediction_buffer_create(const pmx_model* model, const pmx_populatio
   a.chunk = chunk;
   a.total = n_chunks * chunk;
   if (hipMemAddressReserve(&a.va, a.total, 0, nullptr, 0) != hipSuccess) return PMX_ERR_OUT_OF_MEMORY;
-  for (size_t i = 0; i < n_chunks; ++i) {
-    hipMemGenericAllocationHandle_t h;
-    if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) break;  // as much as the device gives
-    if (hipMemMap(static_cast<char*>(a.va) + i * chunk, chunk, 0, h, 0) != hipSuccess) {
-      (void)hipMemRelease(h);
-      break;
-    }
-    a.handles.push_back(h);
-    a.mapped.push_back(1);
-  }
-  if (a.handles.size() < win_chunks) {
-    release(a);
-    return PMX_ERR_OUT_OF_MEMORY;
-  }
   hipMemAccessDesc acc{};
   acc.location = prop.location;
   acc.flags = hipMemAccessFlagsProtReadWrite;
-  if (hipMemSetAccess(a.va, a.handles.size() * chunk, &acc, 1) != hipSuccess) {
+  // chunks are created and mapped as the search reaches them: a search that finds a fast plateau early never touches
+  // the rest of the arena
+  bool exhausted = false;
+  auto map_up_to = [&](size_t want) {  // chunks [0, want) mapped; false when the device gave out first
+    while (!exhausted && a.handles.size() < want && a.handles.size() < n_chunks) {
+      hipMemGenericAllocationHandle_t h;
+      char* at = static_cast<char*>(a.va) + a.handles.size() * chunk;
+      if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) {
+        exhausted = true;
+        break;
+      }
+      if (hipMemMap(at, chunk, 0, h, 0) != hipSuccess) {
+        (void)hipMemRelease(h);
+        exhausted = true;
+        break;
+      }
+      if (hipMemSetAccess(at, chunk, &acc, 1) != hipSuccess) {
+        (void)hipMemUnmap(at, chunk);
+        (void)hipMemRelease(h);
+        exhausted = true;
+        break;
+      }
+      a.handles.push_back(h);
+      a.mapped.push_back(1);
+    }
+    return a.handles.size() >= want;
+  };
+  if (!map_up_to(win_chunks)) {
     release(a);
-    return PMX_ERR_HIP;
+    return PMX_ERR_OUT_OF_MEMORY;
   }
-  // clocks up, then time the kernel into every window
+  // clocks up, then time the kernel into window after window
   double ms = 0.0;
   double* w0 = static_cast<double*>(a.va);
   int32_t rc = pmx_time_predict_device(model, pop, d_theta, n_support, w0, n_support, 30, stream, &ms);
@@ -95,35 +109,55 @@ int32_t pmx_prediction_buffer_create(const pmx_model* model, const pmx_populatio
   const bool debug = std::getenv("PMX_DEBUG_PLACEMENT") != nullptr;
   // PMX_TUNE_PLACE_WINDOW=i: take window i without searching (profiling runs: the landscape of an arena repeats from
   // process to process on one box, so a traced run can sit where an untraced one found the best window and the trace
-  // holds no search dispatches)
+  // holds no search dispatches).  PMX_TUNE_PLACE_FULL=1: time every window of the arena (landscape studies).
   long forced = -1;
   if (const char* e = std::getenv("PMX_TUNE_PLACE_WINDOW")) forced = std::atol(e);
-  if (forced >= 0 && static_cast<size_t>(forced) + win_chunks > a.handles.size()) forced = -1;
+  if (forced >= 0 && !map_up_to(static_cast<size_t>(forced) + win_chunks)) forced = -1;
+  const bool full = std::getenv("PMX_TUNE_PLACE_FULL") != nullptr;
   size_t best = 0;
   double best_ms = 1e300;
+  // fast memory comes in plateaus several windows wide: a window is scored by the worst of itself and its two
+  // neighbours, i.e. windows inside a plateau win over windows on its edge
+  auto score_of = [&](size_t i) {
+    double sc = t[i];
+    if (i > 0 && t[i - 1] > sc) sc = t[i - 1];
+    if (i + 1 < t.size() && t[i + 1] > sc) sc = t[i + 1];
+    return sc;
+  };
   if (forced >= 0 && rc == PMX_OK) {
     best = static_cast<size_t>(forced);
     double* w = reinterpret_cast<double*>(static_cast<char*>(a.va) + best * chunk);
     rc = pmx_time_predict_device(model, pop, d_theta, n_support, w, n_support, 4, stream, &ms);
     t.assign(best + 1, ms);
+  } else if (!write_bound) {
+    if (rc == PMX_OK) t.push_back(ms);
   } else {
-    if (!write_bound && rc == PMX_OK) t.push_back(ms);
-    for (size_t i = 0; write_bound && rc == PMX_OK && i + win_chunks <= a.handles.size(); ++i) {
+    double slowest = 0.0;
+    long stopped_at = -1;
+    for (size_t i = 0; rc == PMX_OK && map_up_to(i + win_chunks); ++i) {
       double* w = reinterpret_cast<double*>(static_cast<char*>(a.va) + i * chunk);
       rc = pmx_time_predict_device(model, pop, d_theta, n_support, w, n_support, 4, stream, &ms);
       if (debug) std::fprintf(stderr, "[pmx] window at chunk %zu (%.2f GiB): %.4f ms\n", i, i * chunk / 1073741824.0, ms);
       t.push_back(ms);
-    }
-    // fast memory comes in plateaus several windows wide: take the window whose worse neighbour is best, i.e. one from
-    // the inside of a plateau rather than its edge
-    for (size_t i = 0; i < t.size(); ++i) {
-      double score = t[i];
-      if (t.size() >= 3) {
-        if (i > 0) score = score > t[i - 1] ? score : t[i - 1];
-        if (i + 1 < t.size()) score = score > t[i + 1] ? score : t[i + 1];
+      if (ms > slowest) slowest = ms;
+      // stop inside the first plateau that is clearly the fast kind: its middle window and both neighbours write at
+      // >= 6.4 TB/s, or 15 % faster than the slowest window met so far (the two kinds differ by 20-25 %)
+      if (!full && i >= 2) {
+        const double sc = score_of(i - 1);
+        if (static_cast<double>(need) / (sc * 1.0e-3) >= 6.4e12 || sc < 0.85 * slowest) {
+          stopped_at = static_cast<long>(i) - 1;  // the plateau's middle window, not its last-timed edge
+          break;
+        }
       }
-      if (score < best_ms) {
-        best_ms = score;
+    }
+    if (stopped_at >= 0) {
+      best = static_cast<size_t>(stopped_at);
+      best_ms = t[best];
+    }
+    for (size_t i = 0; stopped_at < 0 && i < t.size(); ++i) {
+      const double sc = t.size() >= 3 ? score_of(i) : t[i];
+      if (sc < best_ms) {
+        best_ms = sc;
         best = i;
       }
     }

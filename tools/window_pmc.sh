@@ -6,7 +6,7 @@ set -u
 export TMPDIR=/tmp
 OUT=$1; GIB=$2
 mkdir -p $OUT
-PMX_DEBUG_PLACEMENT=1 python3 bench.py --place-gib $GIB --no-cpu-baseline --steps 5 2> $OUT/landscape.txt > /dev/null
+PMX_TUNE_PLACE_FULL=1 PMX_DEBUG_PLACEMENT=1 python3 bench.py --place-gib $GIB --no-cpu-baseline --steps 5 2> $OUT/landscape.txt > /dev/null
 grep "window at" $OUT/landscape.txt | awk '{print NR-1, $8}' > $OUT/windows.txt
 FAST=$(sort -k2 -n $OUT/windows.txt | head -1 | cut -d" " -f1)
 SLOW=$(sort -k2 -n $OUT/windows.txt | tail -1 | cut -d" " -f1)
