@@ -241,14 +241,14 @@ def main():
             pred = torch.empty((n_obs, ld), dtype=torch.float64, device=dev)[:, :P]
         elif want_placement:
             # where the matrix lands in HBM changes the write rate of the row-strided stream by up to 25 %: the library maps
-            # an arena window by window, times the kernel into each, stops inside the first fast plateau (or at the size
-            # limit), keeps that window and returns the rest (set-up, outside the timed region; the buffer is then reused
-            # by every pass)
+            # an arena window by window, times the kernel into each (here: every window; the helper's default stops inside
+            # the first fast plateau), keeps the best window and returns the rest (set-up, outside the timed region; the
+            # buffer is then reused by every pass)
             free_b, _tot = torch.cuda.mem_get_info(dev)
             gib = min(args.place_gib, 0.4 * free_b / (1 << 30))
             try:
-                pred = runtime.place_predictions(model, pop, d_theta, search_gib=gib)
-                placed = "placed window, arena limit %.0f GiB (%.3f ms during the search)" % (gib, pred._pmx_owner.ms_per_pass)
+                pred = runtime.place_predictions(model, pop, d_theta, search_gib=gib, exhaustive=True)
+                placed = "best window of a %.0f GiB arena (%.3f ms during the search)" % (gib, pred._pmx_owner.ms_per_pass)
             except Exception as e:  # no virtual-memory API / not enough memory: best of a few plain allocations
                 alloc_log = []
                 pred = runtime.alloc_predictions(model, pop, d_theta, tries=args.alloc_tries, log=alloc_log)

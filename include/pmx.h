@@ -297,7 +297,9 @@ int32_t pmx_time_predict_device(const pmx_model* model, const pmx_population* po
  * arena of up to `search_bytes` (at least the matrix; 0 = just the matrix) is mapped window by window from separately
  * allocated physical chunks and the real kernel is timed into each; the search stops inside the first plateau of the
  * fast kind (three neighbouring windows at >= 6.4 TB/s, or 15 % faster than the slowest seen) or at `search_bytes`; the
- * chunks under the chosen window are kept and all others are returned to the device.  *ms_per_pass receives the pass
+ * chunks under the chosen window are kept and all others are returned to the device.  A NEGATIVE `search_bytes` asks
+ * for the exhaustive form: every window of an arena of |search_bytes| is timed and the best one kept (about 1 s for
+ * 96 GiB; typically 3-4 % faster than the first plateau).  *ms_per_pass receives the pass
  * time measured in the chosen window.  Current device =
  * the population's.  Free with pmx_prediction_buffer_destroy. */
 int32_t pmx_prediction_buffer_create(const pmx_model* model, const pmx_population* pop, const double* d_theta,

@@ -59,6 +59,8 @@ int32_t pmx_prediction_buffer_create(const pmx_model* model, const pmx_populatio
   size_t chunk = ((need / 8 + (2u << 20) - 1) / (2u << 20)) * (2u << 20);
   if (chunk < (2u << 20)) chunk = 2u << 20;
   const size_t win_chunks = (need + chunk - 1) / chunk;
+  const bool exhaustive = search_bytes < 0;  // -bytes: time every window of the arena, keep the best
+  if (exhaustive) search_bytes = -search_bytes;
   size_t n_chunks = search_bytes > 0 ? static_cast<size_t>(search_bytes) / chunk : 0;
   if (n_chunks < win_chunks) n_chunks = win_chunks;
   Arena a;
@@ -113,7 +115,7 @@ int32_t pmx_prediction_buffer_create(const pmx_model* model, const pmx_populatio
   long forced = -1;
   if (const char* e = std::getenv("PMX_TUNE_PLACE_WINDOW")) forced = std::atol(e);
   if (forced >= 0 && !map_up_to(static_cast<size_t>(forced) + win_chunks)) forced = -1;
-  const bool full = std::getenv("PMX_TUNE_PLACE_FULL") != nullptr;
+  const bool full = exhaustive || std::getenv("PMX_TUNE_PLACE_FULL") != nullptr;
   size_t best = 0;
   double best_ms = 1e300;
   // fast memory comes in plateaus several windows wide: a window is scored by the worst of itself and its two

@@ -129,10 +129,11 @@ class _PlacedBuffer:
             self.ptr = 0
 
 
-def place_predictions(model, pop: DevicePopulation, theta, search_gib: float = 48.0):
-    """A prediction matrix ``[n_observations, n_support]`` in the fastest window of a ``search_gib`` arena
-    (``pmx_prediction_buffer_create``: physical chunks mapped through the HIP virtual-memory API, the real kernel timed
-    into every window, everything outside the best window returned to the device).  Returns a CUDA tensor; the
+def place_predictions(model, pop: DevicePopulation, theta, search_gib: float = 48.0, exhaustive: bool = False):
+    """A prediction matrix ``[n_observations, n_support]`` in a fast window of an arena of up to ``search_gib``
+    (``pmx_prediction_buffer_create``: physical chunks mapped through the HIP virtual-memory API window by window, the
+    real kernel timed into each; the search stops inside the first fast plateau, or - ``exhaustive`` - times every window
+    and keeps the best; everything outside the chosen window is returned to the device).  Returns a CUDA tensor; the
     memory lives as long as the tensor (``tensor._pmx_owner``)."""
     import torch
 
@@ -144,7 +145,7 @@ def place_predictions(model, pop: DevicePopulation, theta, search_gib: float = 4
     out, ms = C.c_void_p(), C.c_double()
     with torch.cuda.device(dev):
         _ffi.check(_ffi.lib().pmx_prediction_buffer_create(_as_model(model).handle, pop.handle, theta.data_ptr(), P,
-                                                           int(search_gib * (1 << 30)),
+                                                           int(search_gib * (1 << 30)) * (-1 if exhaustive else 1),
                                                            torch.cuda.current_stream(dev).cuda_stream, C.byref(out),
                                                            C.byref(ms)))
     owner = _PlacedBuffer(out.value, (pop.n_observations, P), ms.value)

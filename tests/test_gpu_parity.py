@@ -746,9 +746,11 @@ def test_status_bytes_cleared_by_the_kernel_itself():
     assert (st2.cpu().numpy() == 0).all()
 
 
-def test_placed_prediction_buffer():
-    """pmx_prediction_buffer_create: an arena mapped through the HIP virtual-memory API, the kernel timed into every
-    window, the best window kept and everything else returned.  The buffer behaves like any other device buffer."""
+@pytest.mark.parametrize("exhaustive", [False, True])
+def test_placed_prediction_buffer(exhaustive):
+    """pmx_prediction_buffer_create: an arena mapped through the HIP virtual-memory API window by window, the kernel timed
+    into each (every window when exhaustive), one window kept and everything else returned.  The buffer behaves like any
+    other device buffer."""
     import gc
 
     import torch
@@ -756,7 +758,8 @@ def test_placed_prediction_buffer():
     m, flat, theta = synth.config_c3(300, 64)
     pop = runtime.DevicePopulation(flat, 0)
     free0 = torch.cuda.mem_get_info()[0]
-    pred = runtime.place_predictions(m, pop, theta, search_gib=0.25)  # the matrix is ~1 MB: chunks of 2 MiB, 128 windows
+    # the matrix is ~1 MB: chunks of 2 MiB, 128 windows
+    pred = runtime.place_predictions(m, pop, theta, search_gib=0.25, exhaustive=exhaustive)
     assert pred.shape == (flat.n_observations, 64) and pred.is_cuda and pred._pmx_owner.ms_per_pass > 0
     assert free0 - torch.cuda.mem_get_info()[0] < (64 << 20)  # only the window's chunks stayed allocated
     out, st = runtime.predict(m, pop, theta, pred=pred)
