@@ -237,27 +237,10 @@ def main():
         out_shape = (n_obs,) if batch else ((pop.n_subjects, P) if args.loglik else (n_obs, P))
         ld = max(args.ld, P) if (args.ld and not batch and not args.loglik) else None
         want_placement = not batch and not args.loglik and args.place_gib > 0 and ld is None and n_obs * P * 8 > (1 << 28)
-        if ld is not None:  # rows padded to a leading dimension (ld_pred of pmx_predict_device); same bytes written
-            pred = torch.empty((n_obs, ld), dtype=torch.float64, device=dev)[:, :P]
-        elif want_placement:
-            # where the matrix lands in HBM changes the write rate of the row-strided stream by up to 25 %: the library maps
-            # an arena window by window, times the kernel into each (here: every window; the helper's default stops inside
-            # the first fast plateau), keeps the best window and returns the rest (set-up, outside the timed region; the
-            # buffer is then reused by every pass)
-            free_b, _tot = torch.cuda.mem_get_info(dev)
-            gib = min(args.place_gib, 0.4 * free_b / (1 << 30))
-            try:
-                pred = runtime.place_predictions(model, pop, d_theta, search_gib=gib, exhaustive=True)
-                placed = "best window of a %.0f GiB arena (%.3f ms during the search)" % (gib, pred._pmx_owner.ms_per_pass)
-            except Exception as e:  # no virtual-memory API / not enough memory: best of a few plain allocations
-                alloc_log = []
-                pred = runtime.alloc_predictions(model, pop, d_theta, tries=args.alloc_tries, log=alloc_log)
-                placed = "best of %d candidate allocations (%s)" % (len(alloc_log), type(e).__name__)
-        else:
-            pred = torch.empty(out_shape, dtype=torch.float64, device=dev)
         em_c = em.to_c(model) if em is not None else None
         status = None if args.no_status else torch.zeros((pop.n_subjects,) if batch else (pop.n_subjects, P),
                                                          dtype=torch.uint8, device=dev)
+        pred = None
 
         def one_pass(out=None):
             if args.loglik:
@@ -266,31 +249,61 @@ def main():
                 runtime.predict(model, pop, d_theta, pred=pred if out is None else out, status=status, batch=batch,
                                 want_status=not args.no_status)
 
-        # Spin-up (untimed, before the W warm-up passes): after the set-up phase (allocations, frees, host work) the device
-        # sits idle for a while and comes back with reduced clocks (profiles/r01_dispatch_ramp.txt).
-        t_spin = time.perf_counter()
-        while time.perf_counter() - t_spin < args.spin_up_ms * 1e-3:
-            for _ in range(8):
-                one_pass()
-            torch.cuda.synchronize()
-        if want_placement and placed != "first allocation":
-            # the same kernel into a PLAIN first allocation, for the record (`frac_first_allocation`): what a caller who
-            # hands pmx_predict_device his own buffer gets
-            try:
-                plain = torch.empty(out_shape, dtype=torch.float64, device=dev)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                for _ in range(3):
-                    one_pass(plain)
-                e0.record()
-                for _ in range(10):
-                    one_pass(plain)
-                e1.record()
+        def spin_up(out=None):
+            # untimed back-to-back passes: after the set-up phase (allocations, frees, host work) the device sits idle for
+            # a while and comes back with reduced clocks (profiles/r01_dispatch_ramp.txt)
+            t_spin = time.perf_counter()
+            while time.perf_counter() - t_spin < args.spin_up_ms * 1e-3:
+                for _ in range(8):
+                    one_pass(out)
                 torch.cuda.synchronize()
-                first_alloc_ms = e0.elapsed_time(e1) / 10
-                del plain
-                torch.cuda.empty_cache()
-            except RuntimeError:
-                first_alloc_ms = None
+
+        def ms_into(out, reps=10):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(3):
+                one_pass(out)
+            e0.record()
+            for _ in range(reps):
+                one_pass(out)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+
+        if ld is not None:  # rows padded to a leading dimension (ld_pred of pmx_predict_device); same bytes written
+            pred = torch.empty((n_obs, ld), dtype=torch.float64, device=dev)[:, :P]
+        elif want_placement:
+            # Where the matrix lands in HBM changes the write rate of the row-strided stream by up to 25 %, and which memory
+            # is the fast kind differs from box to box.  Candidates, all timed with the real kernel
+            # during set-up (outside the timed region; the chosen buffer is then reused by every pass):
+            #   1. the plain first allocation of the process (what a caller who hands pmx_predict_device his own buffer
+            #      gets: `frac_first_allocation`);
+            #   2. the best window of an arena the library maps chunk by chunk and times window by window
+            #      (pmx_prediction_buffer_create, exhaustive form).
+            # (PMX_TUNE_PLACE_WINDOW = a traced re-run into the window an earlier run chose: no other candidate, so that
+            # the trace holds passes into that window only; tools/profile_round.sh)
+            forced = os.environ.get("PMX_TUNE_PLACE_WINDOW") is not None
+            plain = None
+            if not forced:
+                plain = torch.empty(out_shape, dtype=torch.float64, device=dev)
+                spin_up(plain)
+                first_alloc_ms = ms_into(plain)
+            free_b, _tot = torch.cuda.mem_get_info(dev)
+            gib = min(args.place_gib, 0.75 * free_b / (1 << 30))
+            try:
+                pred = runtime.place_predictions(model, pop, d_theta, search_gib=gib, exhaustive=True)
+                placed = "best window of a %.0f GiB arena (%.3f ms during the search)" % (gib, pred._pmx_owner.ms_per_pass)
+                if plain is not None and ms_into(pred) > first_alloc_ms:  # (boxes exist whose arenas hold no fast window at all)
+                    pred = plain
+                    placed = "first allocation (no window of a %.0f GiB arena was faster)" % gib
+            except Exception as e:  # no virtual-memory API / not enough memory: best of a few plain allocations
+                alloc_log = []
+                pred = runtime.alloc_predictions(model, pop, d_theta, tries=args.alloc_tries, log=alloc_log)
+                placed = "best of %d candidate allocations (%s)" % (len(alloc_log), type(e).__name__)
+            del plain
+            torch.cuda.empty_cache()
+        else:
+            pred = torch.empty(out_shape, dtype=torch.float64, device=dev)
+        spin_up()
         for _ in range(args.warmup):
             one_pass()
         torch.cuda.synchronize()
