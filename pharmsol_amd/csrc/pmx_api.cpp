@@ -802,13 +802,14 @@ int32_t get_stream(pmx_population* pop, const pmx::CompileKey& key, DeviceStream
         for (int64_t o = cp.cls_prog_off[cl]; o < cp.cls_prog_off[cl + 1]; ++o) nobs += (cp.prog_meta[static_cast<size_t>(o)] >> 24) & 1u;
         ds->h_chunk_nobs[static_cast<size_t>(c)] = nobs;
       }
-      {  // where each chunk's [observation][value|const|weight][G] block starts in a slot's cobs
-        std::vector<int64_t> off(static_cast<size_t>(cp.n_chunks));
+      {  // where each chunk's block {[G] constant sums, [G] flags, [observation][value|weight][G]} starts in a slot's cobs
+        std::vector<int64_t> off(static_cast<size_t>(cp.n_chunks) + 1);
         int64_t at = 0;
         for (int64_t c = 0; c < cp.n_chunks; ++c) {
           off[static_cast<size_t>(c)] = at;
-          at += static_cast<int64_t>(ds->h_chunk_nobs[static_cast<size_t>(c)]) * 3 * cp.G;
+          at += (static_cast<int64_t>(ds->h_chunk_nobs[static_cast<size_t>(c)]) * 2 + 2) * cp.G;
         }
+        off[static_cast<size_t>(cp.n_chunks)] = at;  // sentinel
         ds->cobs_size = at;
         if ((rc = upload(ds->h_chunk_nobs, &ds->d_chunk_nobs, &ds->allocs)) != PMX_OK) return rc;
         if ((rc = upload(off, &ds->d_chunk_obs_off, &ds->allocs)) != PMX_OK) return rc;
@@ -874,7 +875,8 @@ int32_t acquire_ll_slot(const pmx_model* model, pmx_population* pop, DeviceStrea
       ds->allocs.push_back(p);
       slot->d_obs = static_cast<double*>(p);
       if (ds->cobs_size > 0) {
-        PMX_HIP(hipMalloc(&p, static_cast<size_t>(ds->cobs_size) * sizeof(double)));
+        // (+ 2 G doubles of slack: the kernel requests a step's observation block before it knows the step has one)
+        PMX_HIP(hipMalloc(&p, static_cast<size_t>(ds->cobs_size + 2 * ds->cls.G) * sizeof(double)));
         ds->allocs.push_back(p);
         slot->d_cobs = static_cast<double*>(p);
       }

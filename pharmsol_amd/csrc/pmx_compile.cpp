@@ -812,6 +812,7 @@ void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, i
     cp->generic_subjects.insert(cp->generic_subjects.end(), leftover.begin(), leftover.end());
   }
   cp->n_chunks = static_cast<int64_t>(cp->chunk_cls.size());
+  cp->chunk_val_off.push_back(static_cast<int64_t>(cp->val.size()));  // sentinel: chunk c's block is [off[c], off[c+1])
   std::sort(cp->generic_subjects.begin(), cp->generic_subjects.end());
 }
 

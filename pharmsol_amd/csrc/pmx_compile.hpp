@@ -144,7 +144,7 @@ struct ClassPlan {
   std::vector<int64_t> cls_prog_off;   // [n_classes+1]
   std::vector<int32_t> chunk_cls;      // [n_chunks]
   std::vector<int32_t> chunk_n;        // [n_chunks] live members (<= G)
-  std::vector<int64_t> chunk_val_off;  // [n_chunks] offset of the chunk's value block in `val`
+  std::vector<int64_t> chunk_val_off;  // [n_chunks + 1] offset of the chunk's value block in `val` (+ the total)
   std::vector<int32_t> chunk_subj;     // [n_chunks*G] subject ids, -1 = padding
   std::vector<int64_t> chunk_row;      // [n_chunks*G] first prediction row of each member
   std::vector<double> val;             // per chunk: [program length][G]  BOLUS amount / PROP rate

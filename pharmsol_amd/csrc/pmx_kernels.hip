@@ -566,13 +566,16 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
       const int64_t zp = static_cast<int64_t>(ptile) * kBlock + (threadIdx.x & ~63u) + 8 * (lane & 7u);
       if (zsid >= 0 && zp < P) *reinterpret_cast<uint64_t*>(status + zsid * P + zp) = 0ull;
     }
+    uint64_t plain_obs = 0;  // log-likelihood mode: bit k = observation k is a plain row for every live member
+    (void)plain_obs;
     double* slot[G / 2];  // this lane's 16-byte slot in the first prediction row of each member pair
     double ll_acc[G];     // log-likelihood mode: running sum of each member
     int64_t cobs_off = 0;  // log-likelihood mode: the chunk's {value, const, weight} block, advanced per observation
     int64_t kobs = 0;      // ... and how many observations of the program have been folded
     (void)kobs;
     if constexpr (LL) {
-      cobs_off = as_const(cp.chunk_obs_off)[c];
+      cobs_off = as_const(cp.chunk_obs_off)[c] + 2 * G;  // (behind the chunk's [G] constant sums and [G] flags)
+      plain_obs = static_cast<uint64_t>(__double_as_longlong(as_const(cp.cobs)[cobs_off - G]));
 #pragma unroll
       for (int j = 0; j < G; ++j) ll_acc[j] = 0.0;
     } else {
@@ -627,6 +630,47 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
     (void)lag_tau;
     for (int64_t o = pb; o < pe; ++o, voff += G) {
       const uint32_t meta = prog_meta[o];
+      // Log-likelihood mode stores nothing inside this loop; what it waits for is scalar fetches, and fetched where they
+      // are used a step has four of them one behind the other (meta -> lengths / rates -> descriptor -> observed values
+      // and weights; SQ_WAIT_ANY: ~2000 cycles per wave-step).  So every scalar of the step is requested here, in one go,
+      // whether or not the step turns out to need it (a step without an observation reads the next one's values; the
+      // chunk's block is followed by the next chunk's, the array by 2 G doubles of slack), and pinned, so that the
+      // compiler neither sinks the fetches back to their uses nor splits the wait.
+#ifdef PMX_EXP_NO_UPFRONT
+      constexpr bool kUpfront = false;
+#else
+      constexpr bool kUpfront = LL && !LAGC && !DYNC;
+#endif
+      double up_dt = 0.0, up_v[G], up_l[G], up_y[G], up_w[G];
+      (void)up_dt;
+      (void)up_v;
+      (void)up_l;
+      (void)up_y;
+      (void)up_w;
+      if constexpr (kUpfront) {
+        const auto ov = as_const(cp.cobs) + cobs_off;
+        if constexpr (!PERDT) up_dt = prog_dt[o];
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+          up_v[j] = val[voff + j];
+          if constexpr (PERDT) up_l[j] = dtv[voff + j];
+          up_y[j] = ov[j];
+          up_w[j] = ov[G + j];
+        }
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+          int64_t bv = __double_as_longlong(up_v[j]), by = __double_as_longlong(up_y[j]), bw = __double_as_longlong(up_w[j]);
+          asm volatile("" : "+s"(bv), "+s"(by), "+s"(bw));
+          up_v[j] = __longlong_as_double(bv);
+          up_y[j] = __longlong_as_double(by);
+          up_w[j] = __longlong_as_double(bw);
+          if constexpr (PERDT) {
+            int64_t bl = __double_as_longlong(up_l[j]);
+            asm volatile("" : "+s"(bl));
+            up_l[j] = __longlong_as_double(bl);
+          }
+        }
+      }
       const uint32_t kind = meta & 0xffu;
       const int io = static_cast<int>((meta >> 8) & 0xffffu);
       if (kind == OP_PROP) {
@@ -659,8 +703,8 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
           double m_dt[G], m_r[G];
 #pragma unroll
           for (int j = 0; j < G; ++j) {
-            m_dt[j] = dtv[voff + j];
-            m_r[j] = val[voff + j];
+            m_dt[j] = kUpfront ? up_l[j] : dtv[voff + j];
+            m_r[j] = kUpfront ? up_v[j] : val[voff + j];
           }
 #pragma unroll
           for (int j = 0; j < G; ++j) {
@@ -671,7 +715,7 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
         } else {
           const uint32_t rung = (meta >> 27) & 7u;
           if (rung == 0u) {
-            LM::S::exps(coef, prog_dt[o], ex);
+            LM::S::exps(coef, kUpfront ? up_dt : prog_dt[o], ex);
           } else if (rung != 1u) {
             ladder_pow<LM::S::NE>(ex, rung);
           }
@@ -679,7 +723,7 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
           LM::S::from_exps(coef, ex, pr);  // (one propagator per step for G members: splitting off J does not pay here)
 #pragma unroll
           for (int j = 0; j < G; ++j) {
-            LM::S::apply(pr, x[j], val[voff + j]);
+            LM::S::apply(pr, x[j], kUpfront ? up_v[j] : val[voff + j]);
             // keep the scheduler from interleaving all G updates (it would hold old and new state of
             // every member at once: +2*NS*G registers, one wave per SIMD less)
             if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
@@ -689,7 +733,7 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
         const double f = fa_of(m, th, io);  // the lane's bioavailability of this input (1.0 when the model has none)
 #pragma unroll
         for (int j = 0; j < G; ++j) {
-          const double a = val[voff + j] * f;
+          const double a = (kUpfront ? up_v[j] : val[voff + j]) * f;
 #pragma unroll
           for (int i = 0; i < NS; ++i) x[j][i] += (i == io - m.pm) ? a : 0.0;  // (pm_: model input 1 = kernel state 0)
         }
@@ -759,30 +803,69 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
           // the step's 3 x G scalars are fetched unconditionally and up front (a few wide s_loads instead of 3 G
           // dependent ones behind the weight test: the kernel was scalar-fetch-latency bound)
           const auto ov = as_const(cp.cobs) + cobs_off;
-          double ov_y[G], ov_c[G], ov_w[G];
+          double ov_y[G], ov_w[G];
 #pragma unroll
           for (int j = 0; j < G; ++j) {
-            ov_y[j] = ov[j];
-            ov_c[j] = ov[G + j];
-            ov_w[j] = ov[2 * G + j];
+            ov_y[j] = kUpfront ? up_y[j] : ov[j];
+            ov_w[j] = kUpfront ? up_w[j] : ov[G + j];
           }
+          // one member-observation: d = y_obs - pred ; sum -= w d^2   (the constants come in at the end: csum).  The
+          // weight tests are on the BITS (scalar integer compares; a floating-point compare of two SGPR values is a
+          // vector instruction); the output's state is picked by a scalar branch around the whole member loop
+          auto fold = [&](auto st_c) {
+            constexpr int ST = decltype(st_c)::value;
+            if constexpr (!DYNC) {
+              // the common step: a plain row for every live member - no tests (a scalar branch per member costs more
+              // than the three instructions it guards); padding members carry weight 0 and finite states: they add -0
+              if (kobs < 63 && ((plain_obs >> kobs) & 1ull)) {
 #pragma unroll
-          for (int j = 0; j < G; ++j) {
-            if (ov_w[j] != 0.0) {  // wave-uniform; weight 0 = missing observation (or chunk padding)
-              double y = select_state<NS>(x[j], out_state) * inv_vol;
-              if constexpr (DYNC) {
-                y = ((cplx >> j) & 1u) ? __longlong_as_double(0x7ff8000000000000LL)
-                                       : lane_out<KID>(m, Ld, x[j], 0.0, oq, cp.faco + (voff + j) * cp.n_fac);
-              }
-              if (CENS && ov_w[j] < 0.0) {  // censored row (marker from pmx_ll_prepare_chunks): the generic fold on its full record
-                ll_accumulate(as_const(ops.ll_obs) + (chunk_row[c * G + j] + kobs) * 4, y, ll_acc[j]);
-              } else {
-                const double d = ov_y[j] - y;
-                ll_acc[j] += ov_c[j] - (d * d) * ov_w[j];
+                for (int j = 0; j < G; ++j) {
+                  const double d = fma(-inv_vol, x[j][ST], ov_y[j]);
+                  ll_acc[j] = fma(-(d * ov_w[j]), d, ll_acc[j]);
+                }
+                return;
               }
             }
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+              const int64_t wb = __double_as_longlong(ov_w[j]);
+              if (wb != 0) {  // wave-uniform; weight 0 = missing observation (or chunk padding)
+                if (CENS && wb < 0) {  // censored row (marker from pmx_ll_prepare_chunks): the generic fold on its full record
+                  double y = x[j][ST] * inv_vol;
+                  if constexpr (DYNC) {
+                    y = ((cplx >> j) & 1u) ? __longlong_as_double(0x7ff8000000000000LL)
+                                           : lane_out<KID>(m, Ld, x[j], 0.0, oq, cp.faco + (voff + j) * cp.n_fac);
+                  }
+                  ll_accumulate(as_const(ops.ll_obs) + (chunk_row[c * G + j] + kobs) * 4, y, ll_acc[j]);
+                } else {
+                  double d;
+                  if constexpr (DYNC) {
+                    const double y = ((cplx >> j) & 1u) ? __longlong_as_double(0x7ff8000000000000LL)
+                                                        : lane_out<KID>(m, Ld, x[j], 0.0, oq, cp.faco + (voff + j) * cp.n_fac);
+                    d = ov_y[j] - y;
+                  } else {
+                    d = fma(-inv_vol, x[j][ST], ov_y[j]);
+                  }
+                  ll_acc[j] = fma(-(d * ov_w[j]), d, ll_acc[j]);
+                }
+              }
+            }
+          };
+          if constexpr (DYNC) {
+            fold(std::integral_constant<int, 0>{});  // (lane_out picks the state itself)
+          } else {
+            if (out_state == 0) fold(std::integral_constant<int, 0>{});
+            if constexpr (NS > 1) {
+              if (out_state == 1) fold(std::integral_constant<int, 1>{});
+            }
+            if constexpr (NS > 2) {
+              if (out_state == 2) fold(std::integral_constant<int, 2>{});
+            }
+            if constexpr (NS > 3) {
+              if (out_state == 3) fold(std::integral_constant<int, 3>{});
+            }
           }
-          cobs_off += 3 * G;
+          cobs_off += 2 * G;
           ++kobs;
         } else {
           if constexpr (DYNC) {
@@ -810,8 +893,9 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
       for (int j = 0; j < G; ++j) {
         if (j < n_live) {
           const int64_t sid = chunk_subj[c * G + j];
-          if (!isfinite(ll_acc[j])) bad |= (1u << j);  // NonFiniteLikelihood (prediction.rs:119-124)
-          if (lane_ok) ops.ll_out[sid * ops.ll_ld + p] = ll_acc[j];  // (NaN already for a lane with complex roots)
+          const double llj = ll_acc[j] + as_const(cp.cobs)[as_const(cp.chunk_obs_off)[c] + j];  // + the member's constants
+          if (!isfinite(llj)) bad |= (1u << j);  // NonFiniteLikelihood (prediction.rs:119-124)
+          if (lane_ok) ops.ll_out[sid * ops.ll_ld + p] = llj;  // (NaN already for a lane with complex roots)
         }
       }
     }
@@ -1238,24 +1322,53 @@ __global__ __launch_bounds__(256) void pmx_ll_prepare_obs(LLPrepareArgs a) {
   a.obs4[r * 4 + 3] = q3;
 }
 
-// cobs[chunk][k][f][j] = obs4[chunk_row[chunk][j] + k][f] for live members, 0 for padding
+// A chunk's block of cobs: [G] csum, [G] flags, then [k][2][G] = {observed value, weight} of observation k of member j (0 for padding
+// members and missing observations).  A plain row's term is  c - w (y - pred)^2 ; the constants c depend on nothing the
+// kernel computes, so they are summed here, once per (error model, population), and the kernel adds csum[j] at the end.
+// A censored row (BLOQ / ALOQ) or a residual-model row carries weight -1 as a marker: the kernel takes the row's full
+// record {value, const, weight, censor scale} from obs4 (rare, out of the main path; its constant is not in csum).
 __global__ __launch_bounds__(256) void pmx_ll_prepare_chunks(LLPrepareArgs a) {
   const int64_t ch = blockIdx.x;
   if (ch >= a.n_chunks) return;
   const int32_t nobs = a.chunk_nobs[ch], n_live = a.chunk_n[ch];
   const int64_t base = a.chunk_obs_off[ch];
-  const int32_t total = nobs * 3 * a.G;
+  const int32_t total = nobs * 2 * a.G;
   for (int32_t i = threadIdx.x; i < total; i += 256) {
-    const int32_t j = i % a.G, f = (i / a.G) % 3, k = i / (3 * a.G);
+    const int32_t j = i % a.G, f = (i / a.G) % 2, k = i / (2 * a.G);
     double v = 0.0;
     if (j < n_live) {
       const double* rec = a.obs4 + (a.chunk_row[ch * a.G + j] + k) * 4;
-      v = rec[f];
-      // a censored row (BLOQ / ALOQ): its weight slot carries -1 as a marker, the kernel then takes the row's full
-      // record {value, const, weight, censor scale} from obs4 (rare, out of the main path)
-      if (f == 2 && (rec[3] != 0.0 || rec[2] < 0.0) && v == v) v = -1.0;  // (or a residual-model row: same detour)
+      v = f == 0 ? rec[0] : rec[2];
+      if (f == 1 && (rec[3] != 0.0 || rec[2] < 0.0) && v == v) v = -1.0;
     }
-    a.cobs[base + i] = v;
+    a.cobs[base + 2 * a.G + i] = v;
+  }
+  if (threadIdx.x == 0) {
+    // bit k: every live member's row of observation k is a plain one (weight neither 0 = missing nor the detour marker):
+    // the kernel then folds the G members without a test per member
+    uint64_t plain = 0;
+    for (int32_t k = 0; k < nobs && k < 63; ++k) {
+      bool all = true;
+      for (int32_t j = 0; j < n_live; ++j) {
+        const double* rec = a.obs4 + (a.chunk_row[ch * a.G + j] + k) * 4;
+        const bool detour = (rec[3] != 0.0 || rec[2] < 0.0) && rec[2] == rec[2];
+        all = all && !detour && __double_as_longlong(rec[2]) != 0;
+      }
+      if (all) plain |= (1ull << k);
+    }
+    a.cobs[base + a.G] = __longlong_as_double(static_cast<int64_t>(plain));
+    for (int32_t j = 1; j < a.G; ++j) a.cobs[base + a.G + j] = 0.0;
+  }
+  for (int32_t j = threadIdx.x; j < a.G; j += 256) {
+    double csum = 0.0;
+    if (j < n_live) {
+      for (int32_t k = 0; k < nobs; ++k) {
+        const double* rec = a.obs4 + (a.chunk_row[ch * a.G + j] + k) * 4;
+        const bool detour = (rec[3] != 0.0 || rec[2] < 0.0) && rec[2] == rec[2];
+        if (rec[2] != 0.0 && !detour) csum += rec[1];
+      }
+    }
+    a.cobs[base + j] = csum;
   }
 }
 }  // namespace

@@ -28,7 +28,9 @@ struct DevClassPlan {
   const double* faco;               // ... and of the observation fused into the step
   int32_t n_fac;
   int32_t pad_;
-  const double* cobs;               // log-likelihood mode: per chunk [observation k][3][G] = value, const term, weight
+  const double* cobs;               // log-likelihood mode: per chunk {[G] sum of the members' constant terms, [G] flags
+                                    //   (slot 0: bit k = observation k is plain for every live member),
+                                    //   [observation k][2][G] = observed value, weight} (pmx_ll_prepare_chunks)
   const int64_t* chunk_obs_off;     // [n_chunks] offset of the chunk's block in cobs
   const int32_t* generic_subjects;  // subjects the generic GRID kernel still has to walk
   int64_t n_chunks;

@@ -61,6 +61,26 @@ def test_c3_shared_design_classed_kernel(em):
     assert_ll_parity(m, flat, em, theta, expect_kernel="pmx_analytical_classed<ll>")
 
 
+@pytest.mark.parametrize("missing_frac", [0.0, 0.02])
+def test_classed_fold_without_per_member_tests(missing_frac):
+    """A step whose rows are plain for every live member is folded without a test per member (pmx_ll_prepare_chunks'
+    flag word, one bit per observation, 63 bits): no missing values -> every step takes that path; 2 % missing -> steps
+    of both kinds in one chunk; 70 observations per subject -> observations 63.. take the tested path again."""
+    rng = np.random.default_rng(11)
+    times = np.sort(rng.uniform(0.1, 48.0, 70))
+    subs = []
+    for i in range(61):  # 61: a partial last chunk
+        b = Subject.builder(f"s{i}").infusion(0.0, 300.0 + 7.0 * i, 0, 0.5)
+        for t in times:
+            b = b.missing_observation(float(t), 0)
+        subs.append(b.build())
+    m = models.handwritten_analytical("two_compartments", 0, 4).with_ndrugs(1)
+    flat = m.flatten(Data(subs))
+    theta = synth.theta_c3(130)
+    flat = with_observed_values(m, flat, theta[:1], rng, missing_frac=missing_frac)
+    assert_ll_parity(m, flat, EM_PROP, theta, expect_kernel="pmx_analytical_classed<ll>")
+
+
 def test_ragged_population_generic_and_pair_kernels():
     rng = np.random.default_rng(2)
     subs = [models.random_subject(rng, multi_occasion=True) for _ in range(150)]
