@@ -14,7 +14,7 @@ PMX_DEBUG_PLACEMENT=1 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo 
 # process on one box) without searching, so the trace and its --stats average hold passes into that window only
 WIN=$(grep "chosen window" $OUT/bench.err | tail -1 | awk '{print $4}'); echo "window ${WIN:-none}"
 # (a box whose arena held no window faster than the plain first allocation: the bench kept that one, so does the trace)
-PLAIN=0; grep -q '"prediction_buffer": "first allocation' $OUT/bench.json && PLAIN=1 && WIN="" && echo "bench kept the first allocation"
+PLAIN=0; grep -q '"prediction_buffer": "best of [0-9]* plain' $OUT/bench.json && PLAIN=1 && WIN="" && echo "bench kept the first allocation"
 for mode in placed first; do
   extra=""; [ $mode = first ] && extra="--place-gib 0"; [ $mode = placed ] && [ $PLAIN = 1 ] && extra="--place-gib 0"
   export -n PMX_TUNE_PLACE_WINDOW; [ $mode = placed ] && [ -n "${WIN:-}" ] && export PMX_TUNE_PLACE_WINDOW=$WIN
