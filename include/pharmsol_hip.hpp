@@ -171,6 +171,54 @@ class SubjectPredictions {
   }
 };
 
+// ---------------------------------------------------------------- error models (error_model.rs:1045-1080)
+/// AssayErrorModel::additive(ErrorPoly::new(c0..c3), lambda) / ::proportional(.., gamma): sigma from the OBSERVATION,
+/// alpha = c0 + c1 y + c2 y^2 + c3 y^3; additive sqrt(alpha^2 + lambda^2), proportional gamma * alpha.
+struct AssayErrorModel {
+  static pmx_error_model additive(double c0, double c1, double c2, double c3, double lambda) {
+    return pmx_error_model{PMX_EM_ADDITIVE, 0, {c0, c1, c2, c3}, lambda};
+  }
+  static pmx_error_model proportional(double c0, double c1, double c2, double c3, double gamma) {
+    return pmx_error_model{PMX_EM_PROPORTIONAL, 0, {c0, c1, c2, c3}, gamma};
+  }
+  static pmx_error_model none() { return pmx_error_model{PMX_EM_NONE, 0, {0, 0, 0, 0}, 0}; }
+};
+
+/// ParameterOrder (src/parameter_order.rs:12-16; parameters.rs:125-145): the permutation between a caller's parameter
+/// columns (e.g. the order of an NPAG support-point table) and the model's declaration order.
+class ParameterOrder {
+ public:
+  /// `source` = the caller's column names, `model` = the model's parameter names; both must hold the same set.
+  ParameterOrder(const std::vector<std::string>& source, const std::vector<std::string>& model) {
+    if (source.size() != model.size()) throw Error(PMX_ERR_INVALID_ARGUMENT, "parameter count differs from the model's");
+    perm_.resize(model.size());
+    for (size_t i = 0; i < model.size(); ++i) {
+      auto it = std::find(source.begin(), source.end(), model[i]);
+      if (it == source.end()) throw Error(PMX_ERR_INVALID_ARGUMENT, "missing parameter '" + model[i] + "'");
+      if (std::count(source.begin(), source.end(), model[i]) != 1)
+        throw Error(PMX_ERR_INVALID_ARGUMENT, "parameter '" + model[i] + "' given twice");
+      perm_[i] = static_cast<size_t>(it - source.begin());
+    }
+  }
+  bool is_identity() const {
+    for (size_t i = 0; i < perm_.size(); ++i)
+      if (perm_[i] != i) return false;
+    return true;
+  }
+  /// rows of `n` source-order values -> model order, row by row
+  std::vector<double> reorder(const std::vector<double>& theta_source) const {
+    const size_t k = perm_.size();
+    if (k == 0 || theta_source.size() % k) throw Error(PMX_ERR_INVALID_ARGUMENT, "theta is not a whole number of rows");
+    std::vector<double> out(theta_source.size());
+    for (size_t r = 0; r < theta_source.size() / k; ++r)
+      for (size_t i = 0; i < k; ++i) out[r * k + i] = theta_source[r * k + perm_[i]];
+    return out;
+  }
+
+ private:
+  std::vector<size_t> perm_;
+};
+
 namespace equation {
 
 struct Route {
@@ -187,7 +235,7 @@ class Equation {
   ~Equation() {
     if (handle_) pmx_model_destroy(handle_);
   }
-  Equation(const Equation& o) : desc_(o.desc_), source_(o.source_), has_init_(o.has_init_), params_(o.params_),
+  Equation(const Equation& o) : desc_(o.desc_), source_(o.source_), has_init_(o.has_init_), user_functions_(o.user_functions_), params_(o.params_),
                                 outputs_(o.outputs_), routes_(o.routes_), covariates_(o.covariates_),
                                 has_metadata_(o.has_metadata_) {}
   Equation& operator=(const Equation&) = delete;
@@ -313,6 +361,89 @@ class Equation {
           !throw_on_pair_failure);
   }
 
+  /// Equation::estimate_log_likelihood (equation/mod.rs:468-477): one subject, one support point.
+  double estimate_log_likelihood(const Subject& subject, const std::vector<double>& parameters,
+                                 const std::vector<pmx_error_model>& error_models, int device = 0) {
+    std::vector<double> ll;
+    std::vector<uint8_t> status;
+    log_likelihood_matrix({subject}, parameters, 1, error_models, device, &ll, &status, /*throw_on_pair_failure=*/true);
+    return ll[0];
+  }
+
+  /// log_likelihood_batch(&eq, &data, &parameters, &error_models) (likelihood/mod.rs:119-177): subject s under ITS OWN
+  /// row of `theta` ([n_subjects x nparams]); a subject whose simulation or likelihood fails gets -inf
+  /// (likelihood/mod.rs:137-140) and a status byte saying why - the call itself succeeds.
+  std::vector<double> log_likelihood_batch(const Data& data, const std::vector<double>& theta,
+                                           const std::vector<pmx_error_model>& error_models, int device = 0,
+                                           std::vector<uint8_t>* status = nullptr) {
+    if (theta.size() != data.size() * static_cast<size_t>(desc_.nparams))
+      throw Error(PMX_ERR_INVALID_ARGUMENT, "theta must hold one row of nparams values per subject");
+    if (static_cast<int>(error_models.size()) != desc_.nout)
+      throw Error(PMX_ERR_INVALID_ARGUMENT, "one error model per output equation");
+    Flat flat = flatten(data);
+    pmx_population* pop = nullptr;
+    pmx_population_desc d = flat.desc();
+    check(pmx_population_create(&d, device, &pop));
+    struct Guard { pmx_population* p; ~Guard() { pmx_population_destroy(p); } } guard{pop};
+    std::vector<double> ll(data.size(), std::numeric_limits<double>::quiet_NaN());
+    std::vector<uint8_t> st(data.size(), 0);
+    check(pmx_loglik_batch(handle(), pop, error_models.data(), theta.data(), ll.data(), st.data()), true);
+    if (status) *status = std::move(st);
+    return ll;
+  }
+
+  /// One theta row per subject, predictions only (the batch twin of predict_matrix; pmx_predict_batch).
+  std::vector<double> predict_batch(const Data& data, const std::vector<double>& theta, int device = 0,
+                                    std::vector<uint8_t>* status = nullptr) {
+    if (theta.size() != data.size() * static_cast<size_t>(desc_.nparams))
+      throw Error(PMX_ERR_INVALID_ARGUMENT, "theta must hold one row of nparams values per subject");
+    Flat flat = flatten(data);
+    pmx_population* pop = nullptr;
+    pmx_population_desc d = flat.desc();
+    check(pmx_population_create(&d, device, &pop));
+    struct Guard { pmx_population* p; ~Guard() { pmx_population_destroy(p); } } guard{pop};
+    std::vector<double> pred(static_cast<size_t>(pmx_population_n_observations(pop)), std::numeric_limits<double>::quiet_NaN());
+    std::vector<uint8_t> st(data.size(), 0);
+    check(pmx_predict_batch(handle(), pop, theta.data(), pred.data(), st.data()), true);
+    if (status) *status = std::move(st);
+    return pred;
+  }
+
+  /// A population kept on the device across calls - what an NPAG loop holds: flattened, label-resolved and compiled
+  /// once; every cycle calls log_likelihood_matrix with a new support-point table.  (`Data` in the reference is borrowed
+  /// by every `log_likelihood_matrix` call; here the borrow is the handle.)
+  class Resident {
+   public:
+    Resident(Equation& eq, const Data& data, int device = 0) : eq_(eq), n_subjects_(static_cast<int64_t>(data.size())) {
+      Flat flat = eq.flatten(data);
+      pmx_population_desc d = flat.desc();
+      check(pmx_population_create(&d, device, &pop_));
+    }
+    ~Resident() {
+      if (pop_) pmx_population_destroy(pop_);
+    }
+    Resident(const Resident&) = delete;
+    Resident& operator=(const Resident&) = delete;
+    int64_t n_subjects() const { return n_subjects_; }
+    int64_t n_observations() const { return pmx_population_n_observations(pop_); }
+    int64_t n_events() const { return pmx_population_n_events(pop_); }
+    /// ll [n_subjects x n_support] row-major (pass a pmx_host_alloc'ed buffer for a copy at link rate)
+    void log_likelihood_matrix(const double* theta, int64_t n_support, const std::vector<pmx_error_model>& error_models,
+                               double* ll, uint8_t* status, bool throw_on_pair_failure = false) {
+      check(pmx_loglik(eq_.handle(), pop_, error_models.data(), theta, n_support, ll, n_support, status), !throw_on_pair_failure);
+    }
+    /// pred [n_observations x n_support] row-major
+    void predict_matrix(const double* theta, int64_t n_support, double* pred, uint8_t* status, bool throw_on_pair_failure = false) {
+      check(pmx_predict(eq_.handle(), pop_, theta, n_support, pred, n_support, status), !throw_on_pair_failure);
+    }
+    const pmx_population* handle() const { return pop_; }
+
+   private:
+    Equation& eq_;
+    pmx_population* pop_ = nullptr;
+    int64_t n_subjects_;
+  };
+
   // Flattened population (the pmx_population_desc arrays), exposed for tests.
   struct Flat {
     std::vector<int64_t> subj_occ_off{0}, occ_ev_off{0}, cov_knot_off{0};
@@ -391,8 +522,9 @@ class Equation {
       desc_.lag_param[i] = desc_.fa_param[i] = desc_.bolus_dest[i] = desc_.infusion_dest[i] = -1;
   }
   pmx_model_desc desc_;
-  std::string source_;  // user ODE bodies (ODE::custom)
+  std::string source_;  // user closures as source text (ODE::custom, Analytical::with_closures)
   bool has_init_ = false;
+  uint32_t user_functions_ = 0;  // PMX_FN_* bits of the closures `source_` defines (pmx_model_create_user)
   Equation& invalidate() {
     if (handle_) pmx_model_destroy(handle_);
     handle_ = nullptr;
@@ -405,7 +537,9 @@ class Equation {
   }
   pmx_model* handle() {
     if (!handle_) {
-      if (!source_.empty())
+      if (!source_.empty() && user_functions_ != 0)
+        check(pmx_model_create_user(&desc_, source_.c_str(), user_functions_, &handle_));
+      else if (!source_.empty())
         check(pmx_model_create_custom(&desc_, source_.c_str(), has_init_ ? 1 : 0, &handle_));
       else
         check(pmx_model_create(&desc_, &handle_));
@@ -424,6 +558,19 @@ class Equation {
 class Analytical : public Equation {
  public:
   Analytical(int32_t kernel, int32_t nparams) : Equation(PMX_EQ_ANALYTICAL, kernel, nparams) {}
+  /// Analytical::new(eq, seq_eq, lag, fa, init, out) with the closures given as source text (pmx.h, "user closures"):
+  /// `functions` = PMX_FN_* bits of the roles `source` defines (pmx_derive / pmx_route_lag / pmx_route_bioavailability /
+  /// pmx_init / pmx_outputs / pmx_seq_eq / pmx_eq), all taking (t, x, p, cov, rateiv, derived, out) like the reference's
+  /// compiled kernels (src/dsl/native.rs:45-53); compiled for gfx950 with hiprtc on first use.  `kernel` stays the
+  /// built-in structure the closures wrap, or PMX_K_CUSTOM with PMX_FN_EQ.  `cov[c]` follows the covariate order of
+  /// with_metadata(.., covariates).
+  Analytical& with_closures(const std::string& source, uint32_t functions, int n_derived = 0) {
+    source_ = source;
+    user_functions_ = functions;
+    desc_.n_derived = n_derived;
+    invalidate();
+    return *this;
+  }
 };
 /// ODE::new(diffeq, ..) with a built-in diffeq body (ode/mod.rs:115; PMX_ODE_*), integrated with fixed-step RK4.
 class ODE : public Equation {

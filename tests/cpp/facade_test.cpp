@@ -214,6 +214,139 @@ static void test_gpu_custom_ode_dopri5_and_loglik() {
   }
 }
 
+// ---- round 2: user closures, ParameterOrder, per-subject / batch likelihoods, the resident population
+// The covariate model of the reference's own parity test (tests/analytical_macro_lowering.rs:225-260): lag, fa, init and
+// the output volume are functions of (theta, t, covariates); same bodies as tests/test_user_analytical.py.
+#define PMX_SIG "double t, const double* x, const double* p, const double* cov, const double* rateiv, const double* derived, double* "
+static const char* kCovariateSrc =
+    "enum { P_ka, P_ke0, P_v, P_tlag, P_f_oral, P_base_gut, P_base_central };\n"
+    "enum { D_ke, D_adjusted_v };  enum { COV_wt, COV_renal };  enum { X_gut, X_central };\n"
+    "PMX_DEVICE void pmx_derive(" PMX_SIG "d) {\n"
+    "  const double wt = cov[COV_wt], renal = cov[COV_renal];\n"
+    "  d[D_ke] = p[P_ke0] * pow(wt / 70.0, 0.75) * pow(renal / 90.0, 0.25);\n"
+    "  d[D_adjusted_v] = p[P_v] * (wt / 70.0) * (1.0 + 0.001 * (renal - 90.0));\n"
+    "}\n"
+    "PMX_DEVICE void pmx_route_lag(" PMX_SIG "lag) {\n"
+    "  lag[0] = p[P_tlag] * sqrt(cov[COV_wt] / 70.0) * pow(90.0 / cov[COV_renal], 0.1);\n"
+    "}\n"
+    "PMX_DEVICE void pmx_route_bioavailability(" PMX_SIG "fa) {\n"
+    "  fa[0] = fmin(fmax(p[P_f_oral] * pow(cov[COV_renal] / 90.0, 0.1), 0.0), 1.0);\n"
+    "}\n"
+    "PMX_DEVICE void pmx_init(" PMX_SIG "xi) {\n"
+    "  xi[X_gut] = p[P_base_gut] + 0.03 * cov[COV_wt];\n"
+    "  xi[X_central] = p[P_base_central] + 0.08 * cov[COV_renal];\n"
+    "}\n"
+    "PMX_DEVICE void pmx_outputs(" PMX_SIG "y) { y[0] = x[X_central] / derived[D_adjusted_v]; }\n";
+static const uint32_t kCovariateFns =
+    PMX_FN_DERIVE | PMX_FN_ROUTE_LAG | PMX_FN_ROUTE_BIOAVAILABILITY | PMX_FN_INIT | PMX_FN_OUTPUTS;
+
+static Analytical covariate_model() {
+  Analytical m(PMX_K_ONE_COMPARTMENT_WITH_ABSORPTION, 7);
+  m.with_nstates(2).with_ndrugs(1).with_nout(1);
+  m.with_bind({{PMX_SRC_PRIMARY, 0}, {PMX_SRC_DERIVED, 0}});  // structure order [ka, ke] <- theta ka, derived ke
+  m.with_metadata({"ka", "ke0", "v", "tlag", "f_oral", "base_gut", "base_central"}, {"cp"},
+                  {Route::bolus("oral", 0), Route::infusion("iv", 1)}, {"wt", "renal"});
+  m.with_closures(kCovariateSrc, kCovariateFns, /*n_derived=*/2);
+  return m;
+}
+static Subject covariate_subject() {  // tests/analytical_macro_lowering.rs:35-51
+  auto b = Subject::builder("analytical-macro-covariates").bolus(1.0, 100.0, "oral").infusion(6.0, 140.0, "iv", 2.0);
+  for (double t : {0.25, 0.75, 1.5, 3.0, 6.5, 7.0, 8.0}) b.missing_observation(t, "cp");
+  b.covariate("wt", 0.0, 68.0).covariate("wt", 8.0, 74.0).covariate("renal", 0.0, 95.0).covariate("renal", 8.0, 72.0);
+  return b.build();
+}
+
+static void test_parameter_order_and_error_model_helpers() {
+  ParameterOrder ord({"v", "ke", "ka"}, {"ka", "ke", "v"});
+  CHECK(!ord.is_identity());
+  auto r = ord.reorder({194.0, 0.08, 1.2, 200.0, 0.09, 1.3});
+  CHECK(r.size() == 6 && r[0] == 1.2 && r[1] == 0.08 && r[2] == 194.0 && r[3] == 1.3 && r[5] == 200.0);
+  CHECK(ParameterOrder({"a", "b"}, {"a", "b"}).is_identity());
+  bool threw = false;
+  try { ParameterOrder({"a", "c"}, {"a", "b"}); } catch (const Error&) { threw = true; }
+  CHECK(threw);
+  threw = false;
+  try { ParameterOrder({"a", "a"}, {"a", "b"}); } catch (const Error&) { threw = true; }
+  CHECK(threw);
+  const pmx_error_model em = AssayErrorModel::proportional(0.02, 0.15, 0.001, 0.0, 1.3);
+  CHECK(em.kind == PMX_EM_PROPORTIONAL && em.c[1] == 0.15 && em.scalar == 1.3);
+  CHECK(AssayErrorModel::additive(0.1, 0.1, 0, 0, 0.2).kind == PMX_EM_ADDITIVE && AssayErrorModel::none().kind == PMX_EM_NONE);
+}
+
+static void test_user_closures_compile_without_gpu() {
+  Analytical m = covariate_model();
+  pmx_model* h = nullptr;
+  CHECK(pmx_model_create_user(&m.desc(), kCovariateSrc, kCovariateFns, &h) == PMX_OK);
+  if (h) pmx_model_destroy(h);
+  // a closure the source does not define is a link-time hole, reported with the compiler's text
+  h = nullptr;
+  CHECK(pmx_model_create_user(&m.desc(), kCovariateSrc, kCovariateFns | PMX_FN_SEQ_EQ, &h) == PMX_ERR_INVALID_ARGUMENT);
+  CHECK(std::string(pmx_last_error()).find("pmx_seq_eq") != std::string::npos);
+}
+
+static void test_gpu_reference_covariate_fixture() {
+  // expected: the fixture marched in plain Python from the reference's rules
+  // (tests/test_user_analytical.py independent_fixture_predictions, support point :470-483)
+  const double want[7] = {0.6899882426482612, 0.6952166346374732, 0.6754383593029405, 2.2271922879272488,
+                          2.6237756574341624, 3.4411825895032986, 4.868892669547507};
+  Analytical m = covariate_model();
+  const auto theta = Parameters::with_model(m, {{"ka", 1.0}, {"ke0", 0.16}, {"v", 32.0}, {"tlag", 0.5}, {"f_oral", 0.8},
+                                                {"base_gut", 3.0}, {"base_central", 14.0}});
+  auto got = m.estimate_predictions(covariate_subject(), theta).flat_predictions();
+  CHECK(got.size() == 7);
+  for (size_t i = 0; i < got.size() && i < 7; ++i) CHECK_CLOSE(got[i], want[i], 1e-9);
+}
+
+static void test_gpu_batch_and_resident_likelihoods() {
+  Analytical m(PMX_K_TWO_COMPARTMENTS, 4);
+  m.with_nstates(2).with_ndrugs(1).with_nout(1).with_output(0, 0, 3);
+  m.with_metadata({"ke", "kcp", "kpc", "v"}, {"cp"}, {Route::infusion("iv", 0)});
+  Data data;
+  for (int s = 0; s < 12; ++s) {
+    auto b = Subject::builder(std::to_string(s)).infusion(0.0, 500.0 + 10.0 * s, "iv", 0.5);
+    for (double t : {0.5, 1.0, 2.0, 4.0, 8.0}) b.observation(t, 8.0 / (1.0 + t) + 0.1 * s, "cp");
+    data.push_back(b.build());
+  }
+  const std::vector<pmx_error_model> em = {AssayErrorModel::additive(0.05, 0.1, 0.0, 0.0, 0.1)};
+  const int P = 3;
+  const std::vector<double> theta = {0.10, 0.30, 0.20, 50.0, 0.20, 0.10, 0.15, 40.0, 0.05, 0.20, 0.10, 60.0};
+  std::vector<double> ll;
+  std::vector<uint8_t> st;
+  m.log_likelihood_matrix(data, theta, P, em, 0, &ll, &st);
+  // per-subject entry == estimate_log_likelihood
+  const double one = m.estimate_log_likelihood(data[4], {0.20, 0.10, 0.15, 40.0}, em);
+  CHECK_CLOSE(one, ll[4 * P + 1], 1e-12);
+  // the resident population gives the same table, call after call
+  equation::Equation::Resident pop(m, data);
+  CHECK(pop.n_subjects() == 12 && pop.n_observations() == 60 && pop.n_events() == 72);
+  std::vector<double> ll2(ll.size());
+  std::vector<uint8_t> st2(st.size());
+  for (int rep = 0; rep < 2; ++rep) {
+    pop.log_likelihood_matrix(theta.data(), P, em, ll2.data(), st2.data());
+    for (size_t i = 0; i < ll.size(); ++i) CHECK(ll2[i] == ll[i]);
+  }
+  // batch: subject s under its own row; the diagonal of a (subject x row) table; a failing row -> -inf, not an error
+  std::vector<double> tb;
+  for (int s = 0; s < 12; ++s)
+    for (int k = 0; k < 4; ++k) tb.push_back(theta[static_cast<size_t>((s % P) * 4 + k)]);
+  tb[7 * 4 + 0] = 1.0;   // subject 7: ke = 1, kcp = -0.5, kpc = 1 -> complex eigenvalues (two_compartment_models.rs:20-22)
+  tb[7 * 4 + 1] = -0.5;
+  tb[7 * 4 + 2] = 1.0;
+  std::vector<uint8_t> stb;
+  const auto llb = m.log_likelihood_batch(data, tb, em, 0, &stb);
+  CHECK(llb.size() == 12 && stb.size() == 12);
+  for (int s = 0; s < 12; ++s) {
+    if (s == 7) {
+      CHECK(std::isinf(llb[7]) && llb[7] < 0 && stb[7] == PMX_PAIR_COMPLEX_ROOTS);
+    } else {
+      CHECK_CLOSE(llb[static_cast<size_t>(s)], ll[static_cast<size_t>(s * P + s % P)], 1e-12);
+      CHECK(stb[static_cast<size_t>(s)] == PMX_PAIR_OK);
+    }
+  }
+  const auto pb = m.predict_batch(data, tb, 0);
+  CHECK(pb.size() == 60 && std::isnan(pb[7 * 5]) && std::isfinite(pb[0]));
+}
+
 int main(int argc, char** argv) {
   const std::string mode = argc > 1 ? argv[1] : "cpu";
   try {
@@ -221,7 +354,11 @@ int main(int argc, char** argv) {
     test_labels_and_parameters();
     test_compile_without_gpu();
     test_custom_source_compiles_without_gpu();
+    test_parameter_order_and_error_model_helpers();
+    test_user_closures_compile_without_gpu();
     if (mode == "gpu") {
+      test_gpu_reference_covariate_fixture();
+      test_gpu_batch_and_resident_likelihoods();
       test_gpu_readme();
       test_gpu_two_compartment_matrix_vs_oracle();
       test_gpu_ode_dose_conservation();
