@@ -261,6 +261,7 @@ void pmx_population_destroy(pmx_population* pop);
 int64_t pmx_population_n_subjects(const pmx_population* pop);
 int64_t pmx_population_n_observations(const pmx_population* pop); /* rows of pred */
 int64_t pmx_population_n_events(const pmx_population* pop);       /* subject-event-steps per support point */
+int32_t pmx_population_device(const pmx_population* pop);         /* the device ordinal it was created on (-1: NULL) */
 /* obs_off[n_subjects+1]: first prediction row of each subject. */
 int32_t pmx_population_observation_offsets(const pmx_population* pop, int64_t* obs_off);
 /* Per prediction row: time / outeq / subject of the observation, in prediction
@@ -300,8 +301,8 @@ int32_t pmx_time_predict_device(const pmx_model* model, const pmx_population* po
  * chunks under the chosen window are kept and all others are returned to the device.  A NEGATIVE `search_bytes` asks
  * for the exhaustive form: every window of an arena of |search_bytes| is timed and the best one kept (about 1 s for
  * 96 GiB; typically 3-4 % faster than the first plateau).  *ms_per_pass receives the pass
- * time measured in the chosen window.  Current device =
- * the population's.  Free with pmx_prediction_buffer_destroy. */
+ * time measured in the chosen window.  The arena is allocated on the population's device (the caller's current device
+ * is restored on return).  Free with pmx_prediction_buffer_destroy. */
 int32_t pmx_prediction_buffer_create(const pmx_model* model, const pmx_population* pop, const double* d_theta,
                                      int64_t n_support, int64_t search_bytes, void* stream, double** d_pred,
                                      double* ms_per_pass);

@@ -29,6 +29,7 @@ SYMBOLS = [
     ("pmx_population_n_subjects", C.c_int64, [C.c_void_p]),
     ("pmx_population_n_observations", C.c_int64, [C.c_void_p]),
     ("pmx_population_n_events", C.c_int64, [C.c_void_p]),
+    ("pmx_population_device", C.c_int32, [C.c_void_p]),
     ("pmx_population_observation_offsets", C.c_int32, [C.c_void_p, C.c_void_p]),
     ("pmx_population_observation_info", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("pmx_model_create", C.c_int32, [_MD, C.POINTER(C.c_void_p)]),

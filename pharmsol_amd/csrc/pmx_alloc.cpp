@@ -49,8 +49,14 @@ int32_t pmx_prediction_buffer_create(const pmx_model* model, const pmx_populatio
   *d_pred = nullptr;
   const size_t need = static_cast<size_t>(pmx_population_n_observations(pop)) * static_cast<size_t>(n_support) * sizeof(double);
   if (need == 0) return PMX_ERR_INVALID_ARGUMENT;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return PMX_ERR_NO_DEVICE;
+  // the arena lives on the population's device, whatever the calling thread's current device is (restored on return)
+  const int dev = pmx_population_device(pop);
+  int prev = 0;
+  if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(dev) != hipSuccess) return PMX_ERR_NO_DEVICE;
+  struct Restore {
+    int d;
+    ~Restore() { (void)hipSetDevice(d); }
+  } restore{prev};
   hipMemAllocationProp prop{};
   prop.type = hipMemAllocationTypePinned;
   prop.location.type = hipMemLocationTypeDevice;

@@ -304,6 +304,7 @@ void pmx_population_destroy(pmx_population* pop) {
 int64_t pmx_population_n_subjects(const pmx_population* pop) { return pop ? pop->hp.n_subjects : -1; }
 int64_t pmx_population_n_observations(const pmx_population* pop) { return pop ? pop->hp.n_obs : -1; }
 int64_t pmx_population_n_events(const pmx_population* pop) { return pop ? pop->hp.n_events : -1; }
+int32_t pmx_population_device(const pmx_population* pop) { return pop ? pop->device : -1; }
 
 int32_t pmx_population_observation_offsets(const pmx_population* pop, int64_t* obs_off) {
   if (!pop || !obs_off) return fail(PMX_ERR_INVALID_ARGUMENT, "null argument");
