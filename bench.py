@@ -60,7 +60,9 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--subjects", type=int, default=100_000, help="subjects per GPU (weak) / in total (strong); C3: 100000")
     ap.add_argument("--support", type=int, default=1000, help="support points (C3: 1000)")
-    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c4", "c5"])
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c4", "c5", "user"],
+                    help="c2..c5: BASELINE.json's configs; user: the reference's covariate parity model "
+                         "(tests/analytical_macro_lowering.rs:225-260, closures compiled at run time), 50k subjects x 256")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N>1: weak = --subjects per GPU; strong = one population of --subjects split N ways (BASELINE configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -182,6 +184,16 @@ def main():
         bound, counters_key = "fp64_valu", "c4"
         label = "C4: ode one_cmt_iv RK4 h<=0.02, %s, irregular schedules, one theta per subject (ODE parity is against the RK4 oracle and closed forms: the reference's diffsol BDF is unpinnable here)"
         dtype_tol = 1e-4
+    elif args.workload == "user":
+        S_arg = 50_000 if args.subjects == 100_000 else args.subjects
+        S_global = S_arg if strong else S_arg * world
+        P = 256 if args.support == 1000 else args.support
+        model = synth.model_user_covariates()
+        theta = synth.theta_user(P)
+        flat_global = synth.population_user(S_global)
+        bound, counters_key = "fp64_valu", "user"
+        label = f"user closures: one_compartment_with_absorption, lag / fa / init / volume as functions of (theta, t, wt, renal), %s x {P} support points"
+        dtype_tol = 1e-6
     else:
         S_arg = 200_000 if args.subjects == 100_000 else args.subjects
         S_global = S_arg if strong else S_arg * world
@@ -450,8 +462,8 @@ def main():
         counters, counters_src = {}, None
         cpath = os.path.join(ROOT, "profiles", "kernel_counters.json")
         full_size = (world == 1 or not strong) and \
-            S_arg == {"c3": 100_000, "c2": 10_000, "c4": 50_000, "c5": 200_000}[args.workload] and \
-            P == {"c3": 1000, "c2": 1, "c4": 1, "c5": 512}[args.workload]
+            S_arg == {"c3": 100_000, "c2": 10_000, "c4": 50_000, "c5": 200_000, "user": 50_000}[args.workload] and \
+            P == {"c3": 1000, "c2": 1, "c4": 1, "c5": 512, "user": 256}[args.workload]
         if full_size and os.path.exists(cpath):
             try:
                 counters = json.load(open(cpath)).get(counters_key, {})

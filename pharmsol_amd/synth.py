@@ -69,6 +69,82 @@ def model_three_cpt_abs_wt(cov_time: str = "segment_dt"):
                       routes=[bolus("oral", "gut")], out={"cp": Ratio("central", "v")}, cov_time=cov_time)
 
 
+_SIG = ("double t, const double* x, const double* p, const double* cov, const double* rateiv, "
+        "const double* derived, double* ")
+# the bodies of the derive / lag / fa / init / out blocks of the reference's covariate parity model
+# (tests/analytical_macro_lowering.rs:236-258), as closure source text (pmx.h "user closures")
+USER_COVARIATE_SRC = f"""
+PMX_DEVICE void pmx_derive({_SIG}d) {{
+  const double wt = cov[COV_wt], renal = cov[COV_renal];
+  const double wt_scale = pow(wt / 70.0, 0.75);
+  const double renal_scale = pow(renal / 90.0, 0.25);
+  d[D_ke] = p[P_ke0] * wt_scale * renal_scale;
+  d[D_adjusted_v] = p[P_v] * (wt / 70.0) * (1.0 + 0.001 * (renal - 90.0));
+}}
+PMX_DEVICE void pmx_route_lag({_SIG}lag) {{
+  const double lag_scale = sqrt(cov[COV_wt] / 70.0) * pow(90.0 / cov[COV_renal], 0.1);
+  lag[R_oral] = p[P_tlag] * lag_scale;
+}}
+PMX_DEVICE void pmx_route_bioavailability({_SIG}fa) {{
+  const double fa_scale = pow(cov[COV_renal] / 90.0, 0.1);
+  fa[R_oral] = fmin(fmax(p[P_f_oral] * fa_scale, 0.0), 1.0);
+}}
+PMX_DEVICE void pmx_init({_SIG}xi) {{
+  xi[X_gut] = p[P_base_gut] + 0.03 * cov[COV_wt];
+  xi[X_central] = p[P_base_central] + 0.08 * cov[COV_renal];
+}}
+PMX_DEVICE void pmx_outputs({_SIG}y) {{ y[Y_cp] = x[X_central] / derived[D_adjusted_v]; }}
+"""
+
+
+def model_user_covariates(cov_time: str = "segment_dt"):
+    """macro_covariate_analytical(), tests/analytical_macro_lowering.rs:225-260: lag, fa, init and the output volume are
+    functions of (theta, t, covariates) - user closures compiled for the device at run time."""
+    return analytical(name="one_cmt_abs_covariates",
+                      params=["ka", "ke0", "v", "tlag", "f_oral", "base_gut", "base_central"],
+                      derived=["ke", "adjusted_v"], covariates=["wt", "renal"], states=["gut", "central"], outputs=["cp"],
+                      routes=[bolus("oral", "gut"), infusion("iv", "central")],
+                      structure="one_compartment_with_absorption", source=USER_COVARIATE_SRC, cov_time=cov_time)
+
+
+def theta_user(n_support: int = 256) -> np.ndarray:
+    """log-uniform around the fixture's support point [1.0, 0.16, 32, 0.5, 0.8, 3, 14] (:470-483); ka > ke always."""
+    rng = SplitMix64(SEED ^ 0x05E7)
+    lo = np.array([0.8, 0.05, 20.0, 0.1, 0.5, 1.0, 5.0])
+    hi = np.array([2.5, 0.35, 60.0, 1.0, 1.2, 5.0, 20.0])
+    u = rng.uniform(7 * n_support).reshape(n_support, 7)
+    return np.exp(np.log(lo) + u * (np.log(hi) - np.log(lo)))
+
+
+def population_user(n_subjects: int) -> FlatPopulation:
+    """The fixture's subject (tests/analytical_macro_lowering.rs:35-51: oral bolus at 1 h, 2 h infusion from 6 h, seven
+    observations, wt and renal as two-knot lines) varied per subject: doses, recorded sampling times, covariate values."""
+    rng = SplitMix64(SEED ^ 0x0B5E)
+    S, E = n_subjects, 9
+    obs_t = np.array([0.25, 0.75, 1.5, 3.0, 6.5, 7.0, 8.0])
+    scale = 0.5 + rng.uniform(S)
+    t = np.tile(np.concatenate([[1.0, 6.0], obs_t]), S).reshape(S, E)
+    t[:, 2:] += 0.2 * (rng.uniform(S * 7).reshape(S, 7) - 0.5) * np.array([0.2, 0.2, 0.4, 1.0, 0.4, 0.4, 0.4])
+    kind = np.tile(np.array([_abi.PMX_EV_BOLUS, _abi.PMX_EV_INFUSION] + [_abi.PMX_EV_OBSERVATION] * 7, dtype=np.uint8), S)
+    v = np.full((S, E), np.nan)
+    v[:, 0] = 100.0 * scale
+    v[:, 1] = 140.0 * scale
+    dur = np.zeros((S, E))
+    dur[:, 1] = 2.0
+    # covariates per occasion in declaration order (wt, renal), two knots each at 0 and 8 h
+    kt = np.tile(np.array([0.0, 8.0, 0.0, 8.0]), S)
+    kv = np.empty((S, 4))
+    kv[:, 0] = 55.0 + 30.0 * rng.uniform(S)
+    kv[:, 1] = kv[:, 0] + 8.0 * (rng.uniform(S) - 0.3)
+    kv[:, 2] = 70.0 + 40.0 * rng.uniform(S)
+    kv[:, 3] = kv[:, 2] - 25.0 * rng.uniform(S)
+    return FlatPopulation(subj_occ_off=np.arange(S + 1), occ_ev_off=np.arange(S + 1) * E,
+                          occ_index=np.zeros(S, dtype=np.int32), ev_time=t.reshape(-1), ev_value=v.reshape(-1),
+                          ev_duration=dur.reshape(-1), ev_kind=kind, ev_io=np.zeros(S * E, dtype=np.uint16),
+                          n_covariates=2, cov_knot_off=np.arange(2 * S + 1) * 2, cov_knot_time=kt,
+                          cov_knot_value=kv.reshape(-1), presorted=False)
+
+
 # ---------------------------------------------------------------------------- populations
 _C23_OBS_T = np.array([0.5, 1.0, 2.0, 4.0, 8.0, 12.0, 24.0])
 

@@ -21,39 +21,13 @@ from pharmsol_amd import (Analytical, AssayErrorModel, AssayErrorModels, Data, E
 SIG = ("double t, const double* x, const double* p, const double* cov, const double* rateiv, "
        "const double* derived, double* ")
 
-# the bodies of the macro's derive / lag / fa / init / out blocks (tests/analytical_macro_lowering.rs:236-258)
-COVARIATE_SRC = f"""
-PMX_DEVICE void pmx_derive({SIG}d) {{
-  const double wt = cov[COV_wt], renal = cov[COV_renal];
-  const double wt_scale = pow(wt / 70.0, 0.75);
-  const double renal_scale = pow(renal / 90.0, 0.25);
-  d[D_ke] = p[P_ke0] * wt_scale * renal_scale;
-  d[D_adjusted_v] = p[P_v] * (wt / 70.0) * (1.0 + 0.001 * (renal - 90.0));
-}}
-PMX_DEVICE void pmx_route_lag({SIG}lag) {{
-  const double lag_scale = sqrt(cov[COV_wt] / 70.0) * pow(90.0 / cov[COV_renal], 0.1);
-  lag[R_oral] = p[P_tlag] * lag_scale;
-}}
-PMX_DEVICE void pmx_route_bioavailability({SIG}fa) {{
-  const double fa_scale = pow(cov[COV_renal] / 90.0, 0.1);
-  fa[R_oral] = fmin(fmax(p[P_f_oral] * fa_scale, 0.0), 1.0);
-}}
-PMX_DEVICE void pmx_init({SIG}xi) {{
-  xi[X_gut] = p[P_base_gut] + 0.03 * cov[COV_wt];
-  xi[X_central] = p[P_base_central] + 0.08 * cov[COV_renal];
-}}
-PMX_DEVICE void pmx_outputs({SIG}y) {{ y[Y_cp] = x[X_central] / derived[D_adjusted_v]; }}
-"""
+# the bodies of the macro's derive / lag / fa / init / out blocks (tests/analytical_macro_lowering.rs:236-258) live in
+# pharmsol_amd.synth (bench.py --workload user runs the same model at scale)
+from pharmsol_amd import synth  # noqa: E402
+
+COVARIATE_SRC = synth.USER_COVARIATE_SRC
 COVARIATE_THETA = [1.0, 0.16, 32.0, 0.5, 0.8, 3.0, 14.0]  # ka ke0 v tlag f_oral base_gut base_central (:470-483)
-
-
-def covariate_model(cov_time="segment_dt"):
-    """macro_covariate_analytical(), tests/analytical_macro_lowering.rs:225-260"""
-    return analytical(name="one_cmt_abs_covariates",
-                      params=["ka", "ke0", "v", "tlag", "f_oral", "base_gut", "base_central"],
-                      derived=["ke", "adjusted_v"], covariates=["wt", "renal"], states=["gut", "central"], outputs=["cp"],
-                      routes=[bolus("oral", "gut"), infusion("iv", "central")],
-                      structure="one_compartment_with_absorption", source=COVARIATE_SRC, cov_time=cov_time)
+covariate_model = synth.model_user_covariates
 
 
 def covariate_subject(i=0, scale=1.0):

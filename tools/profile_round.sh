@@ -24,14 +24,14 @@ for mode in placed first; do
   st=$(find $OUT/trace_$mode -name "*kernel_stats.csv" | head -1); cp "$st" $OUT/kernel_stats_$mode.csv
 done
 unset PMX_TUNE_PLACE_WINDOW
-for w in "c3:" "c5:--workload c5" "c3_ragged:--ragged" "c4:--workload c4"; do
+for w in "c3:" "c5:--workload c5" "c3_ragged:--ragged" "c4:--workload c4" "user:--workload user"; do
   key=${w%%:*}; args=${w#*:}
   tools/pmc_run.sh $OUT/pmc_$key $args > $OUT/pmc_$key.log 2>&1; echo "pmc $key rc=$?"
   python3 tools/pmc_summary.py $OUT/pmc_$key $OUT/pmc_$key.json > $OUT/pmc_$key.txt
   python3 tools/kernel_counters.py $key $OUT/pmc_$key.json "round $TAG build: rocprofv3 --pmc, separate passes (tools/pmc_run.sh $args), mean per dispatch" > /dev/null
 done
 cp profiles/kernel_counters.json $OUT/kernel_counters.json
-for w in c2 c4 c5; do python bench.py --workload $w --no-cpu-baseline --steps 10 > $OUT/bench_$w.json 2>> $OUT/bench.err; done
+for w in c2 c4 c5 user; do python bench.py --workload $w --no-cpu-baseline --steps 10 > $OUT/bench_$w.json 2>> $OUT/bench.err; done
 python bench.py --ragged --no-cpu-baseline --steps 10 > $OUT/bench_c3_ragged.json 2>> $OUT/bench.err
 python bench.py --loglik --no-cpu-baseline --steps 10 > $OUT/bench_c3_loglik.json 2>> $OUT/bench.err
 python bench.py --no-class --no-cpu-baseline --steps 10 > $OUT/bench_c3_generic.json 2>> $OUT/bench.err
