@@ -6,6 +6,9 @@
   * tests/test_solvers.rs:68-103           the same one-compartment model under every solver, |diff| < 0.01 (:81)
   * ode/mod.rs:1459-1538, 1541-1700        103 very short, very large infusions into a six-state non-linear model
                                            (hybrid phage): the run completes, plasma prediction finite and positive
+  * tests/support/bimodal_ke.rs:10-60,     the model every run-time back-end of the reference is checked on (JIT / AOT ==
+    tests/bimodal_ke_entrypoint_matrix.rs  reference predictions at 1e-10): here the hiprtc-compiled body against the
+                                           built-in one, the closed form and the oracle
 
 The reference compares diffsol solvers with each other; here the ODE side is the library's RK4 / Dormand-Prince twin and
 the analytical side its closed forms, so the reference's tolerances are kept AND the tighter ones this build promises
@@ -238,6 +241,39 @@ def test_oracle_many_short_infusions_complete():
             assert (np.abs(p[:, 0] - ref) / np.maximum(np.abs(ref), 1e-3 * np.abs(ref).max())).max() < 1e-3
 
 
+# ---- tests/support/bimodal_ke.rs: `dx(central) = -ke * central`, `out(cp) = central / v`, infusion(iv) -> central
+BIMODAL_SRC = f"""
+PMX_DEVICE void pmx_dynamics({SIG}dx) {{ dx[0] = -p[0] * x[0] + rateiv[0]; }}
+PMX_DEVICE void pmx_outputs({SIG}y) {{ y[0] = x[0] / p[1]; }}
+"""
+BIMODAL_T = [0.5, 1.0, 2.0, 3.0, 4.0, 6.0, 8.0]  # OBSERVATION_TIMES (:11)
+BIMODAL_THETA = [1.2, 50.0]                       # SUPPORT_POINT (:12)
+
+
+def _bimodal():
+    b = Subject.builder("bimodal_ke").infusion(0.0, 500.0, 0, 0.5)  # subject_for_indices (:50-56)
+    for t in BIMODAL_T:
+        b = b.missing_observation(t, 0)
+    ke, v = BIMODAL_THETA
+    cf = []
+    for t in BIMODAL_T:
+        te = min(t, 0.5)
+        cf.append((1000.0 / ke) * (1.0 - math.exp(-ke * te)) * math.exp(-ke * (t - te)) / v)
+    return b.build(), np.array(cf)
+
+
+def test_oracle_run_time_compiled_body_matches_the_built_in_one():
+    oracle.compile_custom(BIMODAL_SRC)
+    sub, cf = _bimodal()
+    th = np.array([BIMODAL_THETA])
+    jit = ODE.custom(BIMODAL_SRC, nstates=1, nparams=2, h_max=0.01)
+    builtin = ODE.new("one_cmt_iv", {0: Ratio(0, 1)}, nparams=2, h_max=0.01).with_nstates(1).with_ndrugs(1).with_nout(1)
+    a, _ = oracle.predict(jit, jit.flatten(sub), th)
+    b, _ = oracle.predict(builtin, builtin.flatten(sub), th)
+    assert (np.abs(a - b) / np.abs(b)).max() < 1e-10  # tests/bimodal_ke_entrypoint_matrix.rs: 1e-10
+    assert (np.abs(a[:, 0] - cf) / cf).max() < 1e-8
+
+
 # --------------------------------------------------------------------------- GPU half
 def _gpu(model, flat, theta):
     import torch
@@ -306,3 +342,20 @@ def test_gpu_many_short_infusions_complete():
     got2, st2 = _gpu(m2, m2.flatten(Data([sub] * 2)), np.array([[0.0]]))
     assert st2.max() == 0 and np.isfinite(got2).all()
     assert (np.abs(got2 - got) / np.maximum(np.abs(got), 1e-3 * np.abs(got).max())).max() < 1e-3
+
+
+@pytest.mark.gpu
+def test_gpu_run_time_compiled_body_matches_the_built_in_one():
+    oracle.compile_custom(BIMODAL_SRC)
+    sub, cf = _bimodal()
+    th = np.array([BIMODAL_THETA])
+    jit = ODE.custom(BIMODAL_SRC, nstates=1, nparams=2, h_max=0.01)
+    builtin = ODE.new("one_cmt_iv", {0: Ratio(0, 1)}, nparams=2, h_max=0.01).with_nstates(1).with_ndrugs(1).with_nout(1)
+    a, sa_ = _gpu(jit, jit.flatten(sub), th)
+    assert runtime.last_kernel_name().startswith("pmx_jit_ode_rk4")
+    b, sb_ = _gpu(builtin, builtin.flatten(sub), th)
+    assert sa_.max() == 0 and sb_.max() == 0
+    assert (np.abs(a - b) / np.abs(b)).max() < 1e-10
+    want, _ = oracle.predict(jit, jit.flatten(sub), th)
+    assert (np.abs(a - want) / np.abs(want)).max() < 1e-10
+    assert (np.abs(a[:, 0] - cf) / cf).max() < 1e-8
