@@ -598,6 +598,19 @@ def analytical(*, name: str, params: Sequence[str], structure: Optional[str], st
     if cov_time not in ("segment_dt", "segment_end_abs"):
         raise ValueError("cov_time must be 'segment_dt' or 'segment_end_abs'")
     m.cov_time = cov_time
+    # Like the reference, an analytical model puts a dose into x[input index] (`x.add_bolus(input, amount)`,
+    # equation/mod.rs:313-328; a route's `to_state` is descriptive metadata for this back-end,
+    # ode/mod.rs:1141 "input_policy_is_descriptive_only"; the analytical! macro lowers routes to metadata only,
+    # expand/analytical.rs:480-522) and an infusion's rate into rateiv[input index], which the structure adds to its
+    # central state.  Routes declared in another order than the structure's states would silently dose another state
+    # than their `to_state` says: say so.
+    for r, idx in m._route_inputs():
+        if r.kind == "bolus" and m.state_index(r.dest) != idx:
+            import warnings
+
+            warnings.warn(f"analytical model '{name}': bolus route '{r.name}' is input {idx}, so its doses go to state "
+                          f"{idx} ('{m.states[idx] if idx < len(m.states) else '?'}'), not to '{r.dest}' - declare the bolus "
+                          "routes in the order of the states they dose (the reference behaves the same way)", stacklevel=2)
     return m
 
 
