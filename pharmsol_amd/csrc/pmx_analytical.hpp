@@ -287,6 +287,16 @@ __device__ __forceinline__ void user_walk_subject(const DevOps& ops, const doubl
       }
       if (t1 > t) user_piece<M>(ops, occ, th, coef, s, t, t1, rate);
     } else if (kind == OP_OBS) {
+      if constexpr (M::HAS_LAG) {
+        // lagged boluses landing before this observation with no PROP step in between (events closer than the solve's
+        // 1e-12 dedup): taken first, without propagation.  (Behind a PROP step nothing is pending below its end.)
+#pragma unroll 1
+        for (;;) {
+          const double tau = user_lag_next(lagst);
+          if (!(tau < a)) break;
+          user_lag_apply<M>(ops, occ, th, s, lagst);
+        }
+      }
       UserCov<M> cov;
       UserDer<M> der;
       user_cov_der<M>(ops, occ, a, th, cov, der);

@@ -305,7 +305,14 @@ int32_t compile_ops(const HostPopulation& hp, const CompileKey& key, OpStream* o
           } else if (k == PMX_EV_INFUSION) {
             inf.push_back({hp.ev_time[e], hp.ev_value[e], hp.ev_dur[e], static_cast<int32_t>(hp.ev_io[e])});
           } else {
+            // Lag models: the lagged boluses are not in this list; the device merges them into the PROP steps at their
+            // landing times.  An observation that no PROP step precedes (events closer than the solve's 1e-12 dedup, or
+            // at the same instant) can still have a lagged bolus landing in front of it - a zero lag leaves the bolus
+            // where it was recorded, between two observations one ulp apart (found by the fuzz suite: seed 2235).  Bit 31
+            // tells the device to take the boluses landing before this observation's time first.
+            const bool flush = n_slots > 0 && !os->op_meta.empty() && (os->op_meta.back() & 0xffu) != OP_PROP;
             push(OP_OBS, hp.ev_io[e], hp.ev_time[e], 0.0, 0, nullptr, oc, hp.ev_time[e], true);
+            if (flush) os->op_meta.back() |= (1u << 31);
           }
           int64_t en = e + 1;  // next event that stays in the list
           if (n_slots > 0)
@@ -669,15 +676,17 @@ void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, i
       const uint32_t kind = os.op_meta[o] & 0xffu;
       const uint32_t io = (os.op_meta[o] >> 8) & 0xffffu;
       if (kind == OP_OBS) {
+        const uint32_t flush = os.op_meta[o] & (1u << 31);  // lag models: lagged boluses may land in front of it (see above)
         if (!step_meta.empty() && ((step_meta.back() >> 24) & 1u) == 0u) {
-          step_meta.back() |= (1u << 24) | ((io & 3u) << 25);
+          step_meta.back() |= (1u << 24) | ((io & 3u) << 25) | flush;
+          if (flush) step_t1.back() = os.op_a[o];  // (never a PROP step: its t1 slot is free) the observation's time
           obs_step_of_op[static_cast<size_t>(o - r0)] = static_cast<int32_t>(step_meta.size()) - 1;
         } else {
           obs_step_of_op[static_cast<size_t>(o - r0)] = static_cast<int32_t>(step_meta.size());
-          step_meta.push_back(make_meta(OP_OBS, 0) | (1u << 24) | ((io & 3u) << 25));
+          step_meta.push_back(make_meta(OP_OBS, 0) | (1u << 24) | ((io & 3u) << 25) | flush);
           step_dt.push_back(0.0);
           step_t0.push_back(0.0);
-          step_t1.push_back(0.0);
+          step_t1.push_back(flush ? os.op_a[o] : 0.0);
         }
       } else {
         step_meta.push_back(make_meta(kind, io));

@@ -123,6 +123,23 @@ __device__ __forceinline__ double lag_next(const DevModel& m, const DevOps& ops,
 
 template <int NS>
 __device__ __forceinline__ void lag_apply_bolus(const DevModel& m, const DevOps& ops, LagState& ls, int which,
+                                                const double* __restrict__ th, double (&x)[NS]);
+
+// An observation that no PROP step precedes (OBS op bit 31, pmx_compile.cpp): the lagged boluses landing before its
+// time are taken first, without propagation - the reference's solve does not advance over gaps below 1e-12 either.
+template <int NS>
+__device__ __forceinline__ void lag_flush_before(const DevModel& m, const DevOps& ops, LagState& ls, double t_obs,
+                                                 const double* __restrict__ th, double (&x)[NS]) {
+  for (;;) {
+    int which;
+    const double tau = lag_next(m, ops, ls, which);
+    if (!(tau < t_obs)) break;
+    lag_apply_bolus<NS>(m, ops, ls, which, th, x);
+  }
+}
+
+template <int NS>
+__device__ __forceinline__ void lag_apply_bolus(const DevModel& m, const DevOps& ops, LagState& ls, int which,
                                                 const double* __restrict__ th, double (&x)[NS]) {
   int32_t idx = 0;
   int input = 0, dest = 0;

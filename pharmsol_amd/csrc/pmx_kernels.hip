@@ -341,6 +341,9 @@ __global__ __launch_bounds__(kBlock, (!LAG && LaneModel<KID>::NS <= 2) ? 4 : ((!
         }
         xpad = 0.0;  // pm_* wrappers re-pad slot 0 with 0 after every kernel call (analytical/mod.rs:70-75)
       } else if (kind == OP_OBS) {
+        if constexpr (LAG) {  // no PROP step in front of this observation: lagged boluses may land before it (bit 31)
+          if (meta >> 31) lag_flush_before<NS>(m, ops, ls, a, th, x);
+        }
         double y = lane_out<KID>(m, L, x, xpad, io, cov);
         if (st == PMX_PAIR_COMPLEX_ROOTS || st == PMX_PAIR_BAD_LAG) y = nanv;
         if constexpr (LL) {
@@ -774,6 +777,14 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
         }
       }  // (kind == OP_OBS: a second observation at the same instant, no state change)
       if ((meta >> 24) & 1u) {  // the observation fused into this step (pmx_compile.cpp build_class_plan)
+        if constexpr (LAGC) {
+          // no PROP step in front of this observation (bit 31; its time sits in the step's t1 slot): the lagged boluses
+          // landing before it come first, without propagation (the members share the landing times)
+          if (meta >> 31) {
+            const double t_obs = as_const(cp.prog_t1)[o];
+            while (lag_tau() < t_obs) bolus_all();
+          }
+        }
         const int oq = static_cast<int>((meta >> 25) & 3u);
         // (pm_ models: the plan only holds subjects that never dose the pad slot and models that never read it, so
         // kernel state = model state - 1 is all the wrapper amounts to; pmx_compile.cpp build_class_plan)
@@ -992,6 +1003,9 @@ __global__ __launch_bounds__(kBlock) void pmx_analytical_pair(DevModel m, DevOps
         }
         xpad = 0.0;
       } else if (kind == OP_OBS) {
+        if constexpr (LAG) {  // (see the GRID kernel)
+          if (meta >> 31) lag_flush_before<NS>(m, ops, ls, a, th, x);
+        }
         double y = lane_out<KID>(m, L, x, xpad, io, cov);
         if (st == PMX_PAIR_COMPLEX_ROOTS || st == PMX_PAIR_BAD_LAG) y = nanv;
         if constexpr (LL) {

@@ -410,6 +410,39 @@ def test_negative_lag_shifts_the_bolus_earlier_like_the_reference(n_support):
     assert (np.delete(st, 7, axis=1) == 0).all() and np.isfinite(np.delete(got, 7, axis=1)).all()
 
 
+def test_lagged_bolus_landing_between_observations_an_ulp_apart():
+    """Analytical::solve drops sub-segments shorter than 1e-12 (analytical/mod.rs:327): between two observations one ulp
+    apart there is no propagation step at all.  A bolus recorded between them stays between them when its lag is zero
+    (structs.rs:629-634: no shift, no re-sort), and a lag can put one there from anywhere.  The device merges lagged
+    boluses into PROP steps; where none exists it has to take them at the observation (OBS op bit 31, pmx_compile.cpp).
+    Found by the fuzz suite (seed 2235).  GRID, PAIR, the lag classes and the user-closure walker."""
+    m = Analytical.new("two_compartments", {0: Ratio(0, 3)}, nparams=6, lag={0: 4}, fa={0: 5}).with_nstates(2).with_ndrugs(
+        1).with_nout(1)
+    t = 10.6
+    t_next = float(np.nextafter(t, 20.0))
+
+    def subject(i, amt):
+        return (Subject.builder(f"u{i}").missing_observation(10.3, 0).infusion(10.3, 286.0 + i, 0, 0.3).missing_observation(t, 0)
+                .bolus(t, amt, 0).missing_observation(t_next, 0).missing_observation(t_next, 0).missing_observation(14.3, 0)
+                .bolus(13.3, 50.0, 0).missing_observation(13.8, 0).missing_observation(float(np.nextafter(13.8, 20.0)), 0).build())
+
+    rng = np.random.default_rng(2235)
+    n = 48
+    th = np.concatenate([synth.theta_c3(n), np.zeros((n, 1)), rng.uniform(0.4, 1.0, (n, 1))], axis=1)
+    th[1::4, 4] = -0.0
+    th[2::4, 4] = 0.5    # the second bolus (13.3) lands exactly on the observation at 13.8: behind it, in front of 13.8 + ulp
+    th[3::4, 4] = 1.25
+    one = m.flatten(subject(0, 309.0))
+    got, want = assert_parity(m, one, th, TOL_ANALYTICAL, expect_kernel="pmx_analytical_grid<lag>")
+    zero = th[:, 4] == 0.0
+    assert (want[2, zero] > want[1, zero] + 1.0).all()   # zero lag: the observation an ulp later sees the bolus
+    half = th[:, 4] == 0.5
+    assert (want[5, half] > want[4, half] * 1.01).all()  # lag 0.5: 13.3 -> 13.8 exactly, seen an ulp later only
+    assert_parity(m, one, th[:6], TOL_ANALYTICAL, expect_kernel="pmx_analytical_pair<lag>")
+    shared = m.flatten(Data([subject(i, 300.0 + i) for i in range(19)]))
+    assert_parity(m, shared, th, TOL_ANALYTICAL, expect_kernel="pmx_analytical_classed<lag>")
+
+
 @pytest.mark.parametrize("structure,nparams,central", [("one_compartment", 2, 0), ("two_compartments", 4, 0),
                                                        ("two_compartments_with_absorption", 5, 1),
                                                        ("three_compartments", 6, 0)])
