@@ -332,7 +332,7 @@ def test_user_closures_equal_the_descriptor_kernels_on_an_expressible_model(n_su
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PMX_FUZZ_USER_LAG", "12"))))  # (more seeds: set the variable)
 def test_random_lag_closures_that_reorder_doses(seed):
     """Lag closures whose value changes from dose to dose (a covariate falling steeply) re-order the boluses of one
     input among themselves and against the fixed events; negative lags move doses before the occasion's first event;
