@@ -290,3 +290,91 @@ def test_random_covariate_model(seed):
         scale = np.maximum(np.abs(want[ok]), 1e-9 * np.abs(want[ok]).max() + 1e-300)
         err = (np.abs(got[ok] - want[ok]) / scale).max()
         assert err < 1e-6, (err, recipe, runtime.last_kernel_name())
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PMX_FUZZ_CLASSED", "60"))))
+def test_random_classed_design_with_outputs_and_likelihoods(seed):
+    """Populations that share a program SHAPE: one prototype schedule, every subject's times stretched by its own factor
+    (loose classes: step lengths per member) or not at all (exact classes), one or two outputs (a second state / another
+    volume), predictions and the fused log-likelihood with missing, censored and own-polynomial rows in any mix -
+    the classed kernel's per-step fold with and without tests (pmx_ll_prepare_chunks' flag word), its partial last chunk,
+    the secondary-output volume path."""
+    import torch
+
+    from tests.test_gpu_likelihood import _censor_some
+
+    rng = np.random.default_rng(31000 + seed)
+    name = list(STRUCTS)[int(rng.integers(0, len(STRUCTS)))]
+    ns, nk, central = STRUCTS[name]
+    nout = int(rng.integers(1, 3))
+    stretch = bool(rng.random() < 0.6)
+    multi = bool(rng.random() < 0.3)
+    n_sub = int(rng.integers(9, 60))
+    n = int(rng.choice([8, 40, 64, 70, 130]))
+    outs = {0: Ratio(central, nk)}
+    if nout == 2:
+        outs[1] = Ratio(int(rng.integers(0, ns)), nk + 1)
+    m = Analytical.new(name, outs, nparams=nk + 2).with_nstates(ns).with_ndrugs(1).with_nout(nout)
+    proto = models.random_subject(rng, multi_occasion=multi, ties=bool(rng.random() < 0.5))
+    subs = []
+    for i in range(n_sub):
+        f = float(rng.uniform(0.85, 1.2)) if stretch else 1.0
+        b = Subject.builder(f"s{i}")
+        for oi, occ in enumerate(proto.occasions):
+            if oi:
+                b = b.reset()
+            for ev in occ.events:
+                if hasattr(ev, "duration"):
+                    b = b.infusion(ev.time * f, ev.amount * (1 + 0.01 * i), 0, ev.duration * f)
+                elif hasattr(ev, "amount"):
+                    b = b.bolus(ev.time * f, ev.amount * (1 + 0.01 * i), 0)
+                else:
+                    b = b.missing_observation(ev.time * f, 0)
+        subs.append(b.build())
+    # (the output of each observation is part of the shape: drawn once per prototype position)
+    flat = m.flatten(Data(subs))
+    if nout == 2:
+        is_obs = flat.ev_kind == _abi.PMX_EV_OBSERVATION
+        per_subject = int(is_obs.sum()) // n_sub
+        pattern = rng.integers(0, 2, per_subject).astype(flat.ev_io.dtype)
+        io = flat.ev_io.copy()
+        io[is_obs] = np.tile(pattern, n_sub)
+        flat.ev_io = io
+    theta = np.concatenate([kernel_theta(name, n, rng), rng.uniform(10, 80, (n, 2))], axis=1)
+    recipe = dict(seed=seed, structure=name, nout=nout, stretch=stretch, multi=multi, subjects=n_sub, support=n)
+    pop = runtime.DevicePopulation(flat, 0)
+    pred, st = runtime.predict(m, pop, np.ascontiguousarray(theta))
+    torch.cuda.synchronize()
+    if n >= 40 and flat.n_events > 0:  # every subject shares the shape: one class, never the generic walker
+        assert runtime.last_kernel_name().startswith("pmx_analytical_classed"), (recipe, runtime.last_kernel_name())
+        assert ("loose" in runtime.last_kernel_name()) == (stretch and flat.n_events > n_sub), (recipe, runtime.last_kernel_name())
+    got, st = pred.cpu().numpy(), st.cpu().numpy()
+    want, wst = oracle.predict(m, flat, theta)
+    np.testing.assert_array_equal(st, wst, err_msg=str(recipe))
+    ok = np.isfinite(want)
+    np.testing.assert_array_equal(np.isfinite(got), ok, err_msg=str(recipe))
+    if ok.any():
+        scale = np.maximum(np.abs(want[ok]), 1e-9 * np.abs(want[ok]).max() + 1e-300)
+        assert (np.abs(got[ok] - want[ok]) / scale).max() < 1e-6, (recipe, runtime.last_kernel_name())
+    if not flat.n_observations:
+        return
+    vals = np.abs(np.where(np.isfinite(want[:, 0]), want[:, 0], 1.0)) * np.exp(rng.normal(0, 0.2, want.shape[0])) + 0.05
+    vals[rng.random(vals.shape) < float(rng.choice([0.0, 0.0, 0.05, 0.3]))] = np.nan
+    flat.ev_value = flat.ev_value.copy()
+    flat.ev_value[flat.ev_kind == _abi.PMX_EV_OBSERVATION] = vals
+    if rng.random() < 0.5:
+        flat = _censor_some(flat, rng, frac_bloq=float(rng.choice([0.0, 0.1])), frac_aloq=float(rng.choice([0.0, 0.1])),
+                            frac_poly=float(rng.choice([0.0, 0.2])))
+    em = AssayErrorModels.empty().add(0, AssayErrorModel.additive(ErrorPoly(0.05, 0.1, 0.0, 0.0), 0.1))
+    if nout == 2:
+        em = em.add(1, AssayErrorModel.proportional(ErrorPoly(0.02, 0.15, 0.001, 0.0), 1.3))
+    pop2 = runtime.DevicePopulation(flat, 0)
+    ll, lst = runtime.loglik(m, pop2, em, np.ascontiguousarray(theta))
+    torch.cuda.synchronize()
+    wll, wlst = oracle.loglik(m, flat, em, theta)
+    np.testing.assert_array_equal(lst.cpu().numpy(), wlst, err_msg=str(recipe))
+    okl = np.isfinite(wll)
+    gl = ll.cpu().numpy()
+    np.testing.assert_array_equal(np.isfinite(gl), okl, err_msg=str(recipe))
+    if okl.any():
+        assert (np.abs(gl[okl] - wll[okl]) / np.maximum(np.abs(wll[okl]), 1.0)).max() < 1e-6, (recipe, runtime.last_kernel_name())
