@@ -514,6 +514,35 @@ def test_host_pointer_form_matches_device_pointer_form():
     np.testing.assert_array_equal(sa, sb)
 
 
+def test_host_pointer_form_large_pitched_and_page_locked_outputs():
+    """pmx_predict / pmx_loglik with outputs larger than the 32 MB pinned bounce buffers (several pieces, the DMA of one
+    overlapping the host copy of the previous), rows padded to a leading dimension (pieces split at row ends), pageable
+    and page-locked (pmx_host_alloc: one DMA) destinations: all bit-identical to the device-pointer form."""
+    import ctypes as C
+
+    from pharmsol_amd import _ffi
+
+    L = _ffi.lib()
+    m, flat, theta = synth.config_c3(3000, 504)  # 21 000 rows x 504 x 8 B = 85 MB: three pieces
+    want, wst = gpu_predict(m, flat, theta)
+    pop = runtime.DevicePopulation(flat, 0)
+    dm = runtime._as_model(m)
+    n_obs, P = flat.n_observations, theta.shape[0]
+    th = np.ascontiguousarray(theta)
+    for ld in (P, P + 3):
+        out = np.full((n_obs, ld), -7.0)
+        st = np.zeros((flat.n_subjects, P), dtype=np.uint8)
+        _ffi.check(L.pmx_predict(dm.handle, pop.handle, th.ctypes.data, P, out.ctypes.data, ld, st.ctypes.data))
+        np.testing.assert_array_equal(out[:, :P], want)
+        np.testing.assert_array_equal(st, wst)
+        if ld > P:
+            assert (out[:, P:] == -7.0).all()  # the padding columns are the caller's
+    pinned = runtime.host_empty((n_obs, P))
+    _ffi.check(L.pmx_predict(dm.handle, pop.handle, th.ctypes.data, P, pinned.ctypes.data, P, None))
+    np.testing.assert_array_equal(pinned, want)
+    del pinned
+
+
 def test_results_are_deterministic_across_launches():
     m, flat, theta = synth.config_c3(200, 300)
     a, _ = gpu_predict(m, flat, theta)
