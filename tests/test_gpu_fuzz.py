@@ -378,3 +378,109 @@ def test_random_classed_design_with_outputs_and_likelihoods(seed):
     np.testing.assert_array_equal(np.isfinite(gl), okl, err_msg=str(recipe))
     if okl.any():
         assert (np.abs(gl[okl] - wll[okl]) / np.maximum(np.abs(wll[okl]), 1.0)).max() < 1e-6, (recipe, runtime.last_kernel_name())
+
+
+ODE_TWIN = {  # analytical structure -> (built-in diffeq, its states)
+    "one_compartment": ("one_cmt_iv", ["central"]), "one_compartment_with_absorption": ("one_cmt_oral", ["gut", "central"]),
+    "two_compartments": ("two_cmt_iv", ["central", "periph"]),
+    "two_compartments_with_absorption": ("two_cmt_oral", ["gut", "central", "periph"]),
+    "three_compartments": ("three_cmt_iv", ["central", "periph1", "periph2"]),
+}
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PMX_FUZZ_COVARIATE_CLASSED", "12"))))
+def test_random_covariate_model_on_a_shared_shape_and_its_ode_twin(seed):
+    """Covariate-derived rate constants / volumes on populations that share a program shape (classed<dyn> for the one- and
+    two-state structures, the kept-propagator walker above), predictions and log-likelihoods with missing rows; and the
+    same model as a built-in ODE body with derived-parameter descriptors (expand/ode.rs:126-185: run-time-compiled) against
+    the RK4 oracle."""
+    import torch
+    from pharmsol_amd import Lin, ode
+
+    rng = np.random.default_rng(47000 + seed)
+    name = list(ODE_TWIN)[int(rng.integers(0, len(ODE_TWIN)))]
+    ns, nk, central = STRUCTS[name]
+    diffeq, states = ODE_TWIN[name]
+    knames = _abi.KERNEL_PARAMETER_NAMES[name]
+    elim = next(k for k in knames if k in ("ke", "k10"))
+    params = [k + "0" if k == elim else k for k in knames] + ["v0"]
+    fac = (Pow("wt", 70.0, 0.75),) if rng.random() < 0.6 else (Lin("wt", 70.0, 0.004),)
+    derived = {elim: Scaled(elim + "0", fac)}
+    if rng.random() < 0.5:
+        derived["v"] = Scaled("v0", (Pow("wt", 70.0, 1.0),))
+        out_vol = "v"
+    else:
+        out_vol = "v0"
+    routes = [bolus("dose", states[0]), infusion("iv", "central")]
+    m = analytical(name=f"cz{seed}", params=params, derived=derived, covariates=["wt"], structure=name, states=states,
+                   outputs=["cp"], routes=routes, out={"cp": Ratio("central", out_vol)})
+    stretch = bool(rng.random() < 0.5)
+    times = np.sort(rng.uniform(0.3, 30.0, int(rng.integers(3, 9))))
+    t_inf, d_inf = float(rng.uniform(0.5, 6)), float(rng.uniform(0.5, 3))
+    with_inf = bool(rng.random() < 0.5)
+    two_occ = bool(rng.random() < 0.3)
+    subs = []
+    n_sub = int(rng.integers(9, 40))
+    for i in range(n_sub):
+        f = float(rng.uniform(0.9, 1.15)) if stretch else 1.0
+        b = Subject.builder(f"s{i}").covariate("wt", 0.0, float(rng.uniform(45, 110)))
+        if rng.random() < 0.5:
+            b = b.covariate("wt", float(rng.uniform(5, 30)), float(rng.uniform(45, 110)))
+        b = b.bolus(0.0, float(rng.uniform(50, 300)), "dose")
+        if with_inf:
+            b = b.infusion(t_inf * f, float(rng.uniform(50, 200)), "iv", d_inf * f)
+        for t in times:
+            b = b.missing_observation(float(t) * f, "cp")
+        if two_occ:
+            b = b.reset().covariate("wt", 0.0, float(rng.uniform(45, 110))).bolus(0.0, 80.0, "dose")
+            for t in (1.0, 4.0, 9.5):
+                b = b.missing_observation(t * f, "cp")
+        subs.append(b.build())
+    n = int(rng.choice([3, 40, 70, 130]))
+    theta = np.concatenate([kernel_theta(name, n, rng), rng.uniform(10, 80, (n, 1))], axis=1)
+    recipe = dict(seed=seed, structure=name, derived=list(derived), stretch=stretch, subjects=n_sub, support=n)
+    flat = m.flatten(Data(subs))
+    pop = runtime.DevicePopulation(flat, 0)
+    pred, st = runtime.predict(m, pop, np.ascontiguousarray(theta))
+    torch.cuda.synchronize()
+    kname = runtime.last_kernel_name()
+    if n >= 40 and ns <= 2:
+        assert kname.startswith("pmx_analytical_classed<dyn>"), (recipe, kname)
+    got, st = pred.cpu().numpy(), st.cpu().numpy()
+    want, wst = oracle.predict(m, flat, theta)
+    np.testing.assert_array_equal(st, wst, err_msg=str(recipe))
+    ok = np.isfinite(want)
+    np.testing.assert_array_equal(np.isfinite(got), ok, err_msg=str(recipe))
+    scale = np.maximum(np.abs(want[ok]), 1e-9 * np.abs(want[ok]).max() + 1e-300)
+    assert (np.abs(got[ok] - want[ok]) / scale).max() < 1e-6, (recipe, kname)
+    # the fused log-likelihood of the same case
+    vals = np.abs(np.where(np.isfinite(want[:, 0]), want[:, 0], 1.0)) * np.exp(rng.normal(0, 0.2, want.shape[0])) + 0.05
+    vals[rng.random(vals.shape) < float(rng.choice([0.0, 0.2]))] = np.nan
+    flat_l = m.flatten(Data(subs))
+    flat_l.ev_value = flat_l.ev_value.copy()
+    flat_l.ev_value[flat_l.ev_kind == _abi.PMX_EV_OBSERVATION] = vals
+    em = AssayErrorModels.empty().add(0, AssayErrorModel.additive(ErrorPoly(0.05, 0.1, 0.0, 0.0), 0.1))
+    pop_l = runtime.DevicePopulation(flat_l, 0)
+    ll, lst = runtime.loglik(m, pop_l, em, np.ascontiguousarray(theta))
+    torch.cuda.synchronize()
+    wll, wlst = oracle.loglik(m, flat_l, em, theta)
+    np.testing.assert_array_equal(lst.cpu().numpy(), wlst, err_msg=str(recipe))
+    okl = np.isfinite(wll)
+    gl = ll.cpu().numpy()
+    np.testing.assert_array_equal(np.isfinite(gl), okl, err_msg=str(recipe))
+    assert (np.abs(gl[okl] - wll[okl]) / np.maximum(np.abs(wll[okl]), 1.0)).max() < 1e-6, (recipe, runtime.last_kernel_name())
+    # the ODE twin: covariates bound at the stage times, so it is its own model - checked against the RK4 oracle
+    mo = ode(name=f"oz{seed}", params=params, derived=derived, covariates=["wt"], diffeq=diffeq, states=states, outputs=["cp"],
+             routes=routes, out={"cp": Ratio("central", out_vol)}, h_max=0.05)
+    flat_o = mo.flatten(Data(subs[:8]))
+    th_o = np.ascontiguousarray(theta[: min(n, 40)])
+    pop_o = runtime.DevicePopulation(flat_o, 0)
+    po, so = runtime.predict(mo, pop_o, th_o)
+    torch.cuda.synchronize()
+    wo, wso = oracle.predict(mo, flat_o, th_o)
+    np.testing.assert_array_equal(so.cpu().numpy(), wso, err_msg=str(recipe))
+    go = po.cpu().numpy()
+    oko = np.isfinite(wo)
+    np.testing.assert_array_equal(np.isfinite(go), oko, err_msg=str(recipe))
+    sc = np.maximum(np.abs(wo[oko]), 1e-9 * np.abs(wo[oko]).max() + 1e-300)
+    assert (np.abs(go[oko] - wo[oko]) / sc).max() < 1e-8, (recipe, runtime.last_kernel_name())
