@@ -123,6 +123,27 @@ def build_case(seed):
     return m, subs, theta, batch, recipe
 
 
+def _denormal_cdf_pairs(flat, pred, obs_off):
+    """(subject, support point) pairs holding a censored row 36.5-39 sigma on the empty side of the prediction: ln(cdf) of
+    a cdf that is a DENORMAL number (erfc(26..27.3) = 1e-300..5e-324) - two or three significant bits in the reference
+    (statrs), the oracle (glibc) and the device (ocml) alike, each rounding differently: sums there agree to ~1e-4 only
+    (fuzz seeds 822, 3714).  The censored folds inside the normal range are pinned at 1e-9 by tests/test_gpu_likelihood.py."""
+    is_obs = flat.ev_kind == _abi.PMX_EV_OBSERVATION
+    y = flat.ev_value[is_obs]
+    cens = flat.ev_censor[is_obs].astype(np.float64)
+    poly = flat.ev_errorpoly[is_obs]
+    c0 = np.where(np.isnan(poly[:, 0]), 0.05, poly[:, 0])  # (the family's error model: additive, poly (0.05, 0.1), lambda 0.1)
+    c1 = np.where(np.isnan(poly[:, 1]), 0.1, poly[:, 1])
+    sigma = np.sqrt((c0 + c1 * y) ** 2 + 0.1 ** 2)
+    with np.errstate(invalid="ignore"):
+        z = (y[:, None] - pred) / sigma[:, None] * cens[:, None]  # BLOQ (+1): far below the prediction = z << 0
+        row_bad = (cens[:, None] != 0) & (z < -36.5) & np.isfinite(z)
+    out = np.zeros((len(obs_off) - 1, pred.shape[1]), dtype=bool)
+    for s_ in range(len(obs_off) - 1):
+        out[s_] = row_bad[obs_off[s_]:obs_off[s_ + 1]].any(axis=0)
+    return out
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("PMX_FUZZ_ANALYTICAL", "120"))))  # (more seeds: set the variable)
 def test_random_analytical_configuration(seed):
     import torch
@@ -152,6 +173,10 @@ def test_random_analytical_configuration(seed):
         if order_ok:
             flat.ev_value = flat.ev_value.copy()
             flat.ev_value[flat.ev_kind == _abi.PMX_EV_OBSERVATION] = vals
+            if seed % 6 == 0:  # BLOQ / ALOQ rows and per-observation error polynomials through the generic / PAIR / lag folds
+                from tests.test_gpu_likelihood import _censor_some
+
+                flat = _censor_some(flat, rng)
             em = AssayErrorModels.empty().add(0, AssayErrorModel.additive(ErrorPoly(0.05, 0.1, 0.0, 0.0), 0.1))
             pop2 = runtime.DevicePopulation(flat, 0)
             ll, lst = runtime.loglik(m, pop2, em, np.ascontiguousarray(theta))
@@ -161,6 +186,8 @@ def test_random_analytical_configuration(seed):
             okl = np.isfinite(wll)
             gl = ll.cpu().numpy()
             np.testing.assert_array_equal(np.isfinite(gl), okl, err_msg=str(recipe))
+            if seed % 6 == 0:
+                okl &= ~_denormal_cdf_pairs(flat, want, pop2.observation_offsets())
             if okl.any():
                 assert (np.abs(gl[okl] - wll[okl]) / np.maximum(np.abs(wll[okl]), 1.0)).max() < 1e-6, recipe
 
