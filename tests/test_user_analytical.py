@@ -317,13 +317,14 @@ def test_seq_eq_and_custom_propagators_on_the_device(n_support):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PMX_FUZZ_USER_TWIN", "1"))))  # (more populations: set it)
 @pytest.mark.parametrize("n_support", [72, 7])
-def test_user_closures_equal_the_descriptor_kernels_on_an_expressible_model(n_support):
+def test_user_closures_equal_the_descriptor_kernels_on_an_expressible_model(n_support, seed):
     """The same model through two device paths: the library's own covariate kernels (host-evaluated factors) and the user
     walker (device-side covariate lookup), both against the oracle, and against each other at rounding level."""
     decl, user = _declarative_twin()
-    rng = np.random.default_rng(6)
-    subs = _twin_population(40, rng)
+    rng = np.random.default_rng(6 + 1000 * seed)
+    subs = _twin_population(40 if seed == 0 else int(rng.integers(3, 70)), rng)
     th = np.stack([rng.uniform(0.8, 2.0, n_support), rng.uniform(0.05, 0.3, n_support), rng.uniform(10, 50, n_support),
                    rng.uniform(0, 1, n_support), rng.uniform(0.4, 1.0, n_support)], axis=1)
     a, _ = _assert_parity(decl, decl.flatten(Data(subs)), th)
