@@ -282,8 +282,10 @@ def test_random_covariate_model(seed):
             derived["v"] = Scaled("v0", (Pow("wt", 70.0, 1.0),))
     else:
         out_vol = vol_in_kernel
+    # (every fourth case: covariates bound at the absolute segment end, the DSL run-time's rule, src/dsl/native.rs:1907-1916)
     m = analytical(name=f"fz{seed}", params=params, derived=derived, covariates=["wt"], structure=name, states=states,
-                   outputs=["cp"], routes=[bolus("dose", states[0]), infusion("iv", "central")], out={"cp": Ratio("central", out_vol)})
+                   outputs=["cp"], routes=[bolus("dose", states[0]), infusion("iv", "central")], out={"cp": Ratio("central", out_vol)},
+                   cov_time="segment_end_abs" if seed % 4 == 3 else "segment_dt")
     subs = []
     n_sub = int(rng.integers(3, 30))
     for i in range(n_sub):
@@ -439,7 +441,8 @@ def test_random_covariate_model_on_a_shared_shape_and_its_ode_twin(seed):
         out_vol = "v0"
     routes = [bolus("dose", states[0]), infusion("iv", "central")]
     m = analytical(name=f"cz{seed}", params=params, derived=derived, covariates=["wt"], structure=name, states=states,
-                   outputs=["cp"], routes=routes, out={"cp": Ratio("central", out_vol)})
+                   outputs=["cp"], routes=routes, out={"cp": Ratio("central", out_vol)},
+                   cov_time="segment_end_abs" if seed % 4 == 3 else "segment_dt")
     stretch = bool(rng.random() < 0.5)
     times = np.sort(rng.uniform(0.3, 30.0, int(rng.integers(3, 9))))
     t_inf, d_inf = float(rng.uniform(0.5, 6)), float(rng.uniform(0.5, 3))
