@@ -1,3 +1,5 @@
+"""Debug helper: re-run one analytical fuzz case (tests/test_gpu_fuzz.py build_case(seed)) on the GPU and show the rows /
+support points where it differs from the oracle.  usage: python tools/dbg_fuzz_case.py <case seed = 1000 + test seed>"""
 import sys; sys.path.insert(0,'.')
 import numpy as np, torch
 import oracle
@@ -25,7 +27,7 @@ print("subjects", sorted(set(subj)))
 for s in sorted(set(subj))[:3]:
     print("subject", s, "obs rows", off[s], off[s+1])
     for o in subs[s].occasions:
-        print("  occ", o.index, [(round(e.time,4), e.kind, round((e.value if e.value==e.value else -1),3), getattr(e,'duration',0)) for e in o.events])
+        print("  occ", o.index, [(type(e).__name__, round(e.time, 6), getattr(e, "amount", None), getattr(e, "duration", None)) for e in o.events])
     r0=off[s]
     for c in cols[:2]:
         print("  got ", got[off[s]:off[s+1], c]); print("  want", want[off[s]:off[s+1], c])
