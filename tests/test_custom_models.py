@@ -135,13 +135,14 @@ def _gpu(model, flat, theta, batch=False):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PMX_FUZZ_CUSTOM_ODE", "1"))))  # (more populations: set it)
 @pytest.mark.parametrize("n_support,batch", [(70, False), (4, False), (0, True)])
-def test_gpu_custom_model_all_lane_mappings(n_support, batch):
+def test_gpu_custom_model_all_lane_mappings(n_support, batch, seed):
     oracle.compile_custom(MM_TWO_OUT, has_init=True)
-    rng = np.random.default_rng(21)
+    rng = np.random.default_rng(21 + 1000 * seed)
     m = ODE.custom(MM_TWO_OUT, nstates=2, nparams=5, nout=2, has_init=True, h_max=0.02)
     subs = []
-    for i in range(40):
+    for i in range(40 if seed == 0 else int(rng.integers(2, 60))):
         s = models.random_subject(rng, multi_occasion=(i % 3 == 0))
         for occ in s.occasions:  # alternate the two outputs
             for k, ev in enumerate(e for e in occ.events if hasattr(e, "outeq")):
