@@ -300,7 +300,8 @@ int32_t pmx_time_predict_device(const pmx_model* model, const pmx_population* po
  * fast kind (three neighbouring windows at >= 6.4 TB/s, or 15 % faster than the slowest seen) or at `search_bytes`; the
  * chunks under the chosen window are kept and all others are returned to the device.  A NEGATIVE `search_bytes` asks
  * for the exhaustive form: every window of an arena of |search_bytes| is timed and the best one kept (about 1 s for
- * 96 GiB; typically 3-4 % faster than the first plateau).  *ms_per_pass receives the pass
+ * 96 GiB; typically 3-4 % faster than the first plateau).  A plain allocation is timed as a candidate too (boxes exist
+ * whose arenas hold no fast window) and returned when it beats the chosen window.  *ms_per_pass receives the pass
  * time measured in the chosen window.  The arena is allocated on the population's device (the caller's current device
  * is restored on return).  Free with pmx_prediction_buffer_destroy. */
 int32_t pmx_prediction_buffer_create(const pmx_model* model, const pmx_population* pop, const double* d_theta,

@@ -5,7 +5,8 @@
 // `arena`).  Nothing in the HIP API says which memory is the fast kind, so this helper measures: it maps
 // an arena out of separately allocated physical chunks (HIP virtual-memory API) window by window, times the real kernel
 // into each, stops inside the first plateau of the fast kind (or at the arena's size limit, with the best window seen),
-// keeps the chunks under the chosen window and gives every other chunk back.
+// keeps the chunks under the chosen window and gives every other chunk back.  A plain allocation is a candidate too
+// (timed first); when it beats the chosen window it is what the caller gets.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -21,6 +22,7 @@
 namespace {
 
 struct Arena {
+  void* plain = nullptr;  // the buffer is a plain hipMalloc allocation (it beat every window): nothing else is set
   void* va = nullptr;
   size_t total = 0, chunk = 0;
   std::vector<hipMemGenericAllocationHandle_t> handles;  // one per chunk
@@ -107,10 +109,25 @@ int32_t pmx_prediction_buffer_create(const pmx_model* model, const pmx_populatio
     release(a);
     return PMX_ERR_OUT_OF_MEMORY;
   }
-  // clocks up, then time the kernel into window after window
+  // clocks up, then a plain allocation as the first candidate (boxes exist whose arenas hold no fast window while an
+  // ordinary allocation runs at the medium speed), then the kernel into window after window
   double ms = 0.0;
   double* w0 = static_cast<double*>(a.va);
   int32_t rc = pmx_time_predict_device(model, pop, d_theta, n_support, w0, n_support, 30, stream, &ms);
+  void* plain = nullptr;
+  double plain_ms = 1e300;
+  // (only where placement matters at all: a pass that moves less than ~1.5 TB/s of predictions is not write-bound)
+  const bool plain_matters = rc == PMX_OK && ms > 0.0 && static_cast<double>(need) / (ms * 1.0e-3) > 1.5e12;
+  if (plain_matters && search_bytes > 0 && hipMalloc(&plain, need) == hipSuccess) {
+    if (pmx_time_predict_device(model, pop, d_theta, n_support, static_cast<double*>(plain), n_support, 6, stream, &plain_ms) != PMX_OK) {
+      (void)hipFree(plain);
+      plain = nullptr;
+      plain_ms = 1e300;
+    }
+  } else {
+    plain = nullptr;
+    (void)hipGetLastError();
+  }
   std::vector<double> t;
   // a pass that moves less than ~1.5 TB/s of predictions is not write-bound: where the matrix sits is moot, take window 0
   const bool write_bound = rc == PMX_OK && ms > 0.0 && static_cast<double>(need) / (ms * 1.0e-3) > 1.5e12;
@@ -173,9 +190,24 @@ int32_t pmx_prediction_buffer_create(const pmx_model* model, const pmx_populatio
   if (debug) std::fprintf(stderr, "[pmx] chosen window %zu\n", best);
   if (!t.empty()) best_ms = t[best];
   if (rc != PMX_OK) {
+    if (plain) (void)hipFree(plain);
     release(a);
     return rc;
   }
+  if (debug && plain) std::fprintf(stderr, "[pmx] plain allocation: %.4f ms\n", plain_ms);
+  if (plain && forced < 0 && plain_ms < 0.99 * best_ms) {  // the plain allocation wins: the whole arena goes back
+    release(a);
+    Arena p;
+    p.plain = plain;
+    {
+      std::lock_guard<std::mutex> lock(g_mu);
+      g_arenas[plain] = std::move(p);
+    }
+    *d_pred = static_cast<double*>(plain);
+    if (ms_per_pass) *ms_per_pass = plain_ms;
+    return PMX_OK;
+  }
+  if (plain) (void)hipFree(plain);
   // give back every chunk outside the chosen window
   for (size_t i = 0; i < a.handles.size(); ++i) {
     if (i >= best && i < best + win_chunks) continue;
@@ -204,6 +236,10 @@ void pmx_prediction_buffer_destroy(double* d_pred) {
     g_arenas.erase(it);
   }
   (void)hipDeviceSynchronize();
+  if (a.plain) {
+    (void)hipFree(a.plain);
+    return;
+  }
   for (size_t i = 0; i < a.handles.size(); ++i) {
     if (!a.mapped[i]) continue;
     (void)hipMemUnmap(static_cast<char*>(a.va) + i * a.chunk, a.chunk);

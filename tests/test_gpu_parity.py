@@ -819,6 +819,8 @@ def test_placed_prediction_buffer(exhaustive):
 
     m, flat, theta = synth.config_c3(300, 64)
     pop = runtime.DevicePopulation(flat, 0)
+    runtime.predict(m, pop, theta)  # (first use: op stream upload, workspaces, torch's allocator pools - not what is measured)
+    torch.cuda.synchronize()
     free0 = torch.cuda.mem_get_info()[0]
     # the matrix is ~1 MB: chunks of 2 MiB, 128 windows
     pred = runtime.place_predictions(m, pop, theta, search_gib=0.25, exhaustive=exhaustive)
