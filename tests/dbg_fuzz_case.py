@@ -1,5 +1,5 @@
 """Debug helper: re-run one analytical fuzz case (tests/test_gpu_fuzz.py build_case(seed)) on the GPU and show the rows /
-support points where it differs from the oracle.  usage: python tools/dbg_fuzz_case.py <case seed = 1000 + test seed>"""
+support points where it differs from the oracle.  usage: python tests/dbg_fuzz_case.py <case seed = 1000 + test seed>"""
 import sys; sys.path.insert(0,'.')
 import numpy as np, torch
 import oracle

@@ -1,5 +1,5 @@
 """Debug helper: re-run the log-likelihood branch of one analytical fuzz case on the GPU and show where it differs from the oracle.
-usage: python tools/dbg_fuzz_ll.py <seed of tests/test_gpu_fuzz.py::test_random_analytical_configuration>"""
+usage: python tests/dbg_fuzz_ll.py <seed of tests/test_gpu_fuzz.py::test_random_analytical_configuration>"""
 import sys
 
 sys.path.insert(0, ".")
