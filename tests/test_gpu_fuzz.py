@@ -132,9 +132,15 @@ def _denormal_cdf_pairs(flat, pred, obs_off):
     y = flat.ev_value[is_obs]
     cens = flat.ev_censor[is_obs].astype(np.float64)
     poly = flat.ev_errorpoly[is_obs]
-    c0 = np.where(np.isnan(poly[:, 0]), 0.05, poly[:, 0])  # (the family's error model: additive, poly (0.05, 0.1), lambda 0.1)
-    c1 = np.where(np.isnan(poly[:, 1]), 0.1, poly[:, 1])
-    sigma = np.sqrt((c0 + c1 * y) ** 2 + 0.1 ** 2)
+    own = ~np.isnan(poly[:, 0])
+    # (the families' error models: output 0 additive, poly (0.05, 0.1), lambda 0.1; output 1 proportional, poly
+    # (0.02, 0.15, 0.001), gamma 1.3; an observation's own polynomial replaces the model's)
+    out1 = flat.ev_io[is_obs] == 1
+    c0 = np.where(own, poly[:, 0], np.where(out1, 0.02, 0.05))
+    c1 = np.where(own, poly[:, 1], np.where(out1, 0.15, 0.1))
+    c2 = np.where(own, poly[:, 2], np.where(out1, 0.001, 0.0))
+    alpha = c0 + c1 * y + c2 * y * y
+    sigma = np.where(out1, 1.3 * alpha, np.sqrt(alpha ** 2 + 0.1 ** 2))
     with np.errstate(invalid="ignore"):
         z = (y[:, None] - pred) / sigma[:, None] * cens[:, None]  # BLOQ (+1): far below the prediction = z << 0
         row_bad = (cens[:, None] != 0) & (z < -36.5) & np.isfinite(z)
@@ -404,6 +410,8 @@ def test_random_classed_design_with_outputs_and_likelihoods(seed):
     okl = np.isfinite(wll)
     gl = ll.cpu().numpy()
     np.testing.assert_array_equal(np.isfinite(gl), okl, err_msg=str(recipe))
+    if flat.ev_censor is not None:
+        okl &= ~_denormal_cdf_pairs(flat, want, pop2.observation_offsets())
     if okl.any():
         assert (np.abs(gl[okl] - wll[okl]) / np.maximum(np.abs(wll[okl]), 1.0)).max() < 1e-6, (recipe, runtime.last_kernel_name())
 
