@@ -12,6 +12,8 @@ from pharmsol_amd import (ODE, Analytical, AssayErrorModel, AssayErrorModels, Da
 from tests import models
 
 pytestmark = pytest.mark.gpu
+# PMX_FUZZ_OFFSET shifts every family's random stream: fresh cases beyond the seeds 0..N-1 of the committed / recorded runs
+OFFSET = int(os.environ.get("PMX_FUZZ_OFFSET", "0"))
 
 STRUCTS = {  # name -> (n states, n kernel params, central state, theta builder)
     "one_compartment": (1, 1, 0), "one_compartment_cl": (1, 2, 0),
@@ -55,7 +57,7 @@ def kernel_theta(name, n, rng):
 
 
 def build_case(seed):
-    rng = np.random.default_rng(seed)
+    rng = np.random.default_rng(seed + OFFSET)
     name = list(STRUCTS)[int(rng.integers(0, len(STRUCTS)))]
     ns, nk, central = STRUCTS[name]
     pm = bool(rng.random() < 0.2)
@@ -208,7 +210,7 @@ ODE_MODELS = {  # name -> (n states, n diffeq params, central)
 def test_random_ode_configuration(seed):
     import torch
 
-    rng = np.random.default_rng(5000 + seed)
+    rng = np.random.default_rng(5000 + seed + OFFSET)
     name = list(ODE_MODELS)[int(rng.integers(0, len(ODE_MODELS)))]
     ns, nk, central = ODE_MODELS[name]
     use_lag, use_fa = bool(rng.random() < 0.4), bool(rng.random() < 0.3)
@@ -269,7 +271,7 @@ def test_random_covariate_model(seed):
     import torch
     from pharmsol_amd import Lin
 
-    rng = np.random.default_rng(9000 + seed)
+    rng = np.random.default_rng(9000 + seed + OFFSET)
     name = list(STRUCTS)[int(rng.integers(0, len(STRUCTS)))]
     ns, nk, central = STRUCTS[name]
     knames = _abi.KERNEL_PARAMETER_NAMES[name]
@@ -338,7 +340,7 @@ def test_random_classed_design_with_outputs_and_likelihoods(seed):
 
     from tests.test_gpu_likelihood import _censor_some
 
-    rng = np.random.default_rng(31000 + seed)
+    rng = np.random.default_rng(31000 + seed + OFFSET)
     name = list(STRUCTS)[int(rng.integers(0, len(STRUCTS)))]
     ns, nk, central = STRUCTS[name]
     nout = int(rng.integers(1, 3))
@@ -433,7 +435,7 @@ def test_random_covariate_model_on_a_shared_shape_and_its_ode_twin(seed):
     import torch
     from pharmsol_amd import Lin, ode
 
-    rng = np.random.default_rng(47000 + seed)
+    rng = np.random.default_rng(47000 + seed + OFFSET)
     name = list(ODE_TWIN)[int(rng.integers(0, len(ODE_TWIN)))]
     ns, nk, central = STRUCTS[name]
     diffeq, states = ODE_TWIN[name]
