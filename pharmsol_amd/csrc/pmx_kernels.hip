@@ -642,7 +642,7 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
 #ifdef PMX_EXP_NO_UPFRONT
       constexpr bool kUpfront = false;
 #else
-      constexpr bool kUpfront = LL && !LAGC && !DYNC;
+      constexpr bool kUpfront = LL && !LAGC && !DYNC && !PERDT;
 #endif
       double up_dt = 0.0, up_v[G], up_l[G], up_y[G], up_w[G];
       (void)up_dt;
