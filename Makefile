@@ -8,7 +8,7 @@ LIB := pharmsol_amd/lib/libpmx_hip.so
 HOSTFLAGS := -O2 -std=c++17 -fPIC -Wall -Wextra -ffp-contract=off -Iinclude
 DEVFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-parameter -Iinclude
 OBJ := $(CSRC)/build/pmx_compile.o $(CSRC)/build/pmx_api.o $(CSRC)/build/pmx_kernels.o $(CSRC)/build/pmx_jit.o $(CSRC)/build/pmx_alloc.o
-DEVHDR := $(CSRC)/pmx_devtypes.hpp $(CSRC)/pmx_device.hpp $(CSRC)/pmx_ode.hpp $(CSRC)/pmx_structures.hpp $(CSRC)/pmx_analytical.hpp include/pmx.h
+DEVHDR := $(CSRC)/pmx_devtypes.hpp $(CSRC)/pmx_device.hpp $(CSRC)/pmx_ode.hpp $(CSRC)/pmx_structures.hpp $(CSRC)/pmx_userlag.hpp $(CSRC)/pmx_analytical.hpp $(CSRC)/pmx_ode_user.hpp include/pmx.h
 
 all: $(LIB) oracle
 
@@ -27,7 +27,7 @@ $(CSRC)/build/pmx_kernels.o: $(CSRC)/pmx_kernels.hip $(CSRC)/pmx_kernels.hpp $(C
 # the device headers a run-time (hiprtc) compile of a user model includes, embedded as string literals
 $(CSRC)/build/pmx_jit_headers.inc: $(DEVHDR) tools/embed_headers.py
 	@mkdir -p $(CSRC)/build
-	python3 tools/embed_headers.py $@ include/pmx.h $(CSRC)/pmx_devtypes.hpp $(CSRC)/pmx_device.hpp $(CSRC)/pmx_ode.hpp $(CSRC)/pmx_structures.hpp $(CSRC)/pmx_analytical.hpp
+	python3 tools/embed_headers.py $@ include/pmx.h $(CSRC)/pmx_devtypes.hpp $(CSRC)/pmx_device.hpp $(CSRC)/pmx_ode.hpp $(CSRC)/pmx_structures.hpp $(CSRC)/pmx_userlag.hpp $(CSRC)/pmx_analytical.hpp $(CSRC)/pmx_ode_user.hpp
 
 $(CSRC)/build/pmx_alloc.o: $(CSRC)/pmx_alloc.cpp include/pmx.h
 	@mkdir -p $(CSRC)/build

@@ -334,9 +334,11 @@ int32_t pmx_predict_batch_device(const pmx_model* model, const pmx_population* p
  * sigma comes from the OBSERVATION through the assay error polynomial of its output equation
  * (AssayErrorModel::sigma, src/data/error_model.rs:1045-1080):
  *   alpha = c0 + c1 y + c2 y^2 + c3 y^3;  additive: sqrt(alpha^2 + lambda^2);  proportional: gamma * alpha
- * It does not depend on the support point, so the library evaluates it once per observation on the host;
- * the device folds each prediction into its subject's sum instead of storing it (output S x P doubles
- * instead of S x O x P).  Censored observations (BLOQ/ALOQ) are not in the flattened descriptor yet. */
+ * It does not depend on the support point, so one small device kernel derives it once per observation whenever the
+ * error models change (stream-ordered before the likelihood kernel); the main kernel folds each prediction into its
+ * subject's sum instead of storing it (output S x P doubles instead of S x O x P).  Censored observations
+ * (pmx_population_desc::ev_censor) take the log CDF / log survival function (prediction.rs:113-117), an observation's
+ * own polynomial (ev_errorpoly) overrides the model's. */
 enum {
   PMX_EM_NONE = 0,
   PMX_EM_ADDITIVE = 1,      /* AssayErrorModel::additive:     sigma = sqrt(alpha(obs)^2 + lambda^2) */
@@ -400,7 +402,28 @@ int32_t pmx_model_create_custom(const pmx_model_desc* desc, const char* source, 
  *                                                     modified in place (p = theta)
  *   eq      (analytical,     the sub-segment LENGTH   x_next[nstates] (copy of x)      AnalyticalEq, analytical/mod.rs:363-364
  *            kernel = PMX_K_CUSTOM)                   p = the solve's vector, rateiv[ndrugs]
- *   dynamics (ODE)           stage time               dx[nstates] (zeros)              DiffEq
+ *   dynamics (ODE)           stage time               dx[nstates] (zeros)              DiffEq, ode/mod.rs:115-132
+ *   dynamics_bolus (ODE)     stage time / bolus time  dx[nstates] (zeros)              DiffEq with its `bolus` argument
+ *
+ * ODE models.  PMX_FN_DYNAMICS | PMX_FN_OUTPUTS (| PMX_FN_INIT) alone == pmx_model_create_custom (theta-indexed lag / fa
+ * through lag_param / fa_param, the fast state-machine kernels).  Adding PMX_FN_ROUTE_LAG / PMX_FN_ROUTE_BIOAVAILABILITY /
+ * PMX_FN_DERIVE selects the general ODE walker (csrc/pmx_ode_user.hpp): `lag` and `fa` are closures of (theta, t, cov)
+ * evaluated per bolus on the device at the reference's times, every lagged bolus is re-sorted per lane
+ * (Occasion::process_events, structs.rs:611-690), `derived` = pmx_derive at the stage / event time.  The reference's
+ * DiffEq also receives the dose being given: `diffeq(x, p, t, dx, bolus, rateiv, cov)` and a bolus event adds
+ * f(x, bolus) - f(x, 0) (both with rateiv = 0, at the bolus' time after the lag shift) to the state (ode/mod.rs:659-686).
+ * A source that defines
+ *
+ *   PMX_DEVICE void pmx_dynamics_bolus(double t, const double* x, const double* p, const double* cov,
+ *                                      const double* rateiv, const double* bolus, const double* derived, double* dx);
+ *
+ * (PMX_FN_DYNAMICS_BOLUS instead of PMX_FN_DYNAMICS) gets exactly that: bolus[ndrugs] is zero during integration and
+ * holds the (fa-scaled) amount at its input for the jump.  With plain pmx_dynamics the jump is `amount` into
+ * bolus_dest[input] (what the jump rule gives for every `ode!` model, expand/ode.rs:394-399).
+ * The solver clock of an occasion starts at the earliest RECORDED event time (Occasion::initial_time, structs.rs:782-793,
+ * ode/mod.rs:348) and only moves forward to the time of the NEXT event (ode/mod.rs:719-721): the occasion's first event
+ * after the lag rewrite is applied at that clock without integration - a lagged bolus that is the first event of its
+ * occasion acts from the clock's start, exactly as in the reference.
  *
  * `cov[c]` = covariate c of the subject's current occasion interpolated AT THAT t on the device (fetch_cov!(cov, t, ..));
  * `derived` = pmx_derive evaluated at the same t first, the way every macro-lowered closure starts
@@ -409,7 +432,6 @@ int32_t pmx_model_create_custom(const pmx_model_desc* desc, const char* source, 
  * theta / derived values; its derive runs at the segment length dt or, PMX_COV_TIME_SEGMENT_END_ABS, at the absolute
  * segment end) or PMX_K_CUSTOM + PMX_FN_EQ.  A closure left out of `functions` falls back to the descriptor's closed
  * form (lag_param / fa_param / init_param / out[]); desc->derived[] is ignored, n_derived <= PMX_MAX_USER_DERIVED.
- * ODE models: PMX_FN_DYNAMICS | PMX_FN_OUTPUTS (| PMX_FN_INIT) == pmx_model_create_custom.
  * The reference fixture tests/analytical_macro_lowering.rs:225-260 (covariate-dependent lag, clamped fa, init and
  * volume) is written this way in tests/test_user_analytical.py. */
 enum {
@@ -420,7 +442,8 @@ enum {
   PMX_FN_ROUTE_LAG = 16,
   PMX_FN_ROUTE_BIOAVAILABILITY = 32,
   PMX_FN_SEQ_EQ = 64,
-  PMX_FN_EQ = 128
+  PMX_FN_EQ = 128,
+  PMX_FN_DYNAMICS_BOLUS = 256
 };
 int32_t pmx_model_create_user(const pmx_model_desc* desc, const char* source, uint32_t functions, pmx_model** out);
 /* The translation unit handed to hiprtc for such a model; free with pmx_free_text. */

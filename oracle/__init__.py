@@ -102,8 +102,9 @@ _user_key = None
 
 
 def _register_user(model) -> None:
-    """Analytical user closures: build the model's source with g++ (the SAME text the device compiles) and register
-    its bodies (pmx_oracle_set_user); a descriptor model clears the registration.  One model at a time: tests only."""
+    """User closures of an Analytical or ODE model: build the model's source with g++ (the SAME text the device
+    compiles) and register its bodies (pmx_oracle_set_user); a descriptor model clears the registration.  One model at
+    a time: tests only."""
     import hashlib
     import tempfile
 
@@ -112,7 +113,7 @@ def _register_user(model) -> None:
     L.pmx_oracle_set_user.argtypes = [C.c_uint32, C.c_void_p]
     L.pmx_oracle_set_user.restype = None
     mask = int(getattr(model, "user_fns", 0) or 0)
-    if not mask or getattr(model, "eq_kind", None) != _abi.PMX_EQ_ANALYTICAL:
+    if not mask or getattr(model, "eq_kind", None) not in (_abi.PMX_EQ_ANALYTICAL, _abi.PMX_EQ_ODE):
         if _user_key is not None:
             L.pmx_oracle_set_user(0, None)
             _user_key = None
@@ -130,7 +131,7 @@ def _register_user(model) -> None:
             f.write('#include <cmath>\nusing namespace std;\n#define PMX_DEVICE extern "C"\n#line 1 "model"\n' + source)
         subprocess.run(["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-o", so, src], check=True)
     cl = C.CDLL(so)
-    fns = (C.c_void_p * 8)()
+    fns = (C.c_void_p * 9)()
     for name, bit in _abi.USER_FUNCTION_BITS.items():
         if mask & bit:
             fns[bit.bit_length() - 1] = C.cast(getattr(cl, name), C.c_void_p)

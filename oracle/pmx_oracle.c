@@ -494,11 +494,16 @@ typedef struct {
  * PMX_FN_* bits of the registered closures; 0 = descriptor model. */
 typedef void (*pmx_user_fn)(double t, const double* x, const double* p, const double* cov, const double* rateiv,
                             const double* derived, double* out);
+/* DiffEq with its bolus argument (ode/mod.rs:115-132: diffeq(x, p, t, dx, bolus, rateiv, cov)) */
+typedef void (*pmx_user_fn8)(double t, const double* x, const double* p, const double* cov, const double* rateiv,
+                             const double* bolus, const double* derived, double* out);
 static uint32_t g_user_mask = 0;
 static pmx_user_fn g_user_outputs = 0, g_user_init = 0, g_user_derive = 0, g_user_lag = 0, g_user_fa = 0, g_user_seq = 0,
-                   g_user_eq = 0;
+                   g_user_eq = 0, g_user_dynamics = 0;
+static pmx_user_fn8 g_user_dynamics_bolus = 0;
 void pmx_oracle_set_user(uint32_t mask, void** fns) {
   g_user_mask = mask;
+  g_user_dynamics = (mask & PMX_FN_DYNAMICS) ? (pmx_user_fn)fns[0] : 0;
   g_user_outputs = (mask & PMX_FN_OUTPUTS) ? (pmx_user_fn)fns[1] : 0;
   g_user_init = (mask & PMX_FN_INIT) ? (pmx_user_fn)fns[2] : 0;
   g_user_derive = (mask & PMX_FN_DERIVE) ? (pmx_user_fn)fns[3] : 0;
@@ -506,15 +511,21 @@ void pmx_oracle_set_user(uint32_t mask, void** fns) {
   g_user_fa = (mask & PMX_FN_ROUTE_BIOAVAILABILITY) ? (pmx_user_fn)fns[5] : 0;
   g_user_seq = (mask & PMX_FN_SEQ_EQ) ? (pmx_user_fn)fns[6] : 0;
   g_user_eq = (mask & PMX_FN_EQ) ? (pmx_user_fn)fns[7] : 0;
+  g_user_dynamics_bolus = (mask & PMX_FN_DYNAMICS_BOLUS) ? (pmx_user_fn8)fns[8] : 0;
 }
 static void cov_values(const ctx_t* c, double t, double* cv);
 static int is_user_analytical(const pmx_model_desc* m) { return m->eq_kind == PMX_EQ_ANALYTICAL && g_user_mask != 0; }
+/* ODE::new(diffeq, lag, fa, init, out) with every closure a registered body (pmx_model_create_user, general ODE walker) */
+static int is_user_ode(const pmx_model_desc* m) {
+  return m->eq_kind == PMX_EQ_ODE && m->kernel == PMX_ODE_CUSTOM && (g_user_mask & (PMX_FN_DYNAMICS | PMX_FN_DYNAMICS_BOLUS)) != 0;
+}
+static int is_user_model(const pmx_model_desc* m) { return is_user_analytical(m) || is_user_ode(m); }
 
 /* the `derive:` block: derived[d] = theta[src] * f0 * f1, covariates at `t`
  * (bindings.rs:98-117 -> fetch_cov!(cov, t, ...) src/lib.rs:433-443) */
 static int eval_derived(const ctx_t* c, const double* theta, double t, double* derived) {
   const pmx_model_desc* m = c->m;
-  if (is_user_analytical(m)) { /* the user's derive closure at t (every macro-lowered closure starts with it) */
+  if (is_user_model(m)) { /* the user's derive closure at t (every macro-lowered closure starts with it) */
     double cv[PMX_MAX_COVARIATES];
     for (int d = 0; d < m->n_derived; d++) derived[d] = 0.0;
     if (g_user_derive) {
@@ -610,14 +621,14 @@ void pmx_oracle_set_custom(void* dynamics, void* outputs, void* init) {
  * (expand/analytical.rs:320-326; e.g. examples/analytical_readme.rs:21-23) */
 static int model_out(const ctx_t* c, const double* x, const double* theta, double t_obs, double* y) {
   const pmx_model_desc* m = c->m;
-  if (m->eq_kind == PMX_EQ_ODE && m->kernel == PMX_ODE_CUSTOM) {
+  if (m->eq_kind == PMX_EQ_ODE && m->kernel == PMX_ODE_CUSTOM && !is_user_ode(m)) {
     double cv[PMX_MAX_COVARIATES];
     cov_values(c, t_obs, cv);
     g_custom_outputs(t_obs, x, theta, m->n_covariates ? cv : 0, 0, 0, y); /* y zeroed by the caller */
     return 0;
   }
   double derived[PMX_MAX_USER_DERIVED];
-  if (is_user_analytical(m) && g_user_outputs) { /* out(x, p, t_obs, cov, y), derive first (expand/analytical.rs:320-326) */
+  if (is_user_model(m) && g_user_outputs) { /* out(x, p, t_obs, cov, y), derive first (expand/analytical.rs:320-326) */
     double cv[PMX_MAX_COVARIATES];
     cov_values(c, t_obs, cv);
     eval_derived(c, theta, t_obs, derived);
@@ -763,6 +774,17 @@ static void ode_rhs(int model, const double* x, const double* p, double* dx) {
  * dx[dest] += rateiv[i] (expand/ode.rs:380-406). */
 static void ode_f(const ctx_t* c, double t, const double* x, const double* p, const double* rate, double* dx) {
   const pmx_model_desc* m = c->m;
+  if (is_user_ode(m)) { /* diffeq(x, p, t, dx, bolus = 0, rateiv, cov), derive first (ode/closure.rs:344-357) */
+    double cv[PMX_MAX_COVARIATES], der[PMX_MAX_USER_DERIVED], zero[PMX_MAX_INPUTS] = {0};
+    cov_values(c, t, cv);
+    eval_derived(c, p, t, der);
+    for (int i = 0; i < m->nstates; i++) dx[i] = 0.0;
+    if (g_user_dynamics_bolus)
+      g_user_dynamics_bolus(t, x, p, m->n_covariates ? cv : 0, rate, zero, (g_user_mask & PMX_FN_DERIVE) ? der : 0, dx);
+    else
+      g_user_dynamics(t, x, p, m->n_covariates ? cv : 0, rate, (g_user_mask & PMX_FN_DERIVE) ? der : 0, dx);
+    return;
+  }
   if (m->kernel == PMX_ODE_CUSTOM) { /* the body adds rateiv itself, like a hand-written closure */
     double cv[PMX_MAX_COVARIATES];
     cov_values(c, t, cv);
@@ -913,7 +935,7 @@ static int simulate_pair(const pmx_model_desc* m, const pmx_population_desc* pop
   ctx_t ctx;
   ctx.m = m;
   ctx.theta = theta;
-  const int user = is_user_analytical(m);
+  const int user = is_user_model(m);
   for (int64_t oc = occ0; oc < occ1; oc++) { /* for occasion in subject.occasions() :494 */
     ctx.cov = sc->cov + (oc - occ0) * ncov;
     int occ_index = pop->occ_index ? pop->occ_index[oc] : (int)(oc - occ0);
@@ -924,7 +946,7 @@ static int simulate_pair(const pmx_model_desc* m, const pmx_population_desc* pop
     if (occ_index == 0) {
       for (int i = 0; i < m->nstates; i++)
         if (m->init_param[i] >= 0) x[i] = theta[m->init_param[i]];
-      if (m->eq_kind == PMX_EQ_ODE && m->kernel == PMX_ODE_CUSTOM && g_custom_init) {
+      if (m->eq_kind == PMX_EQ_ODE && m->kernel == PMX_ODE_CUSTOM && !is_user_ode(m) && g_custom_init) {
         double cv[PMX_MAX_COVARIATES];
         cov_values(&ctx, 0.0, cv);
         g_custom_init(0.0, x, theta, m->n_covariates ? cv : 0, 0, 0, x);
@@ -950,6 +972,11 @@ static int simulate_pair(const pmx_model_desc* m, const pmx_population_desc* pop
       ev[i].src = e0 + i;
     }
     if (!pop->presorted) ev_sort(ev, n); /* Subject::new sorts every occasion, structs.rs:363-369 */
+    /* Occasion::initial_time(): the earliest RECORDED event time - the ODE solver's t0 is taken from the occasion as the
+     * data holds it, before lag moves any bolus (ode/mod.rs:348 `.t0(occasion.initial_time())`, structs.rs:782-793) */
+    double t0_recorded = 0.0;
+    for (int64_t i = 0; i < n; i++)
+      if (i == 0 || ev[i].time < t0_recorded) t0_recorded = ev[i].time;
     { /* add_lagtime, structs.rs:611-643 */
       int shifted = 0;
       for (int64_t i = 0; i < n; i++) {
@@ -1045,21 +1072,32 @@ static int simulate_pair(const pmx_model_desc* m, const pmx_population_desc* pop
           if (w == 0 || sc->bounds[r] != sc->bounds[w - 1]) sc->bounds[w++] = sc->bounds[r];
         nb = w;
       }
-      /* t0 = occasion.initial_time() = earliest event time, structs.rs:782-793 */
-      double t = 0.0;
-      if (n > 0) {
-        t = ev[0].time;
-        for (int64_t i = 1; i < n; i++)
-          if (ev[i].time < t) t = ev[i].time;
-      }
+      /* The solver clock: starts at the occasion's recorded initial time and only ever moves forward to the time of
+       * the NEXT event (`while next_event_time > solver.state().t`, :719-721).  The first event of the re-sorted list is
+       * therefore applied at t0 without integration, whatever its own (lagged) time is. */
+      double t = t0_recorded;
       int bcur = 0;
       for (int64_t i = 0; i < n; i++) {
         const ev_t* e = &ev[i];
         if (e->kind == PMX_EV_BOLUS) {
           /* y += f(y, bolus) - f(y, 0) == amount at the route's destination, :659-686 */
           if ((int)e->io >= m->ndrugs) return PMX_ERR_INPUT_OUT_OF_RANGE;
-          int dest = m->bolus_dest[e->io] >= 0 ? m->bolus_dest[e->io] : (int)e->io;
-          x[dest] += e->value;
+          if (is_user_ode(m) && g_user_dynamics_bolus) {
+            /* state += diffeq(y, t_event, bolus_v, zero_rateiv) - diffeq(y, t_event, zero_bolus, zero_rateiv), :647-686 */
+            double cv[PMX_MAX_COVARIATES], der[PMX_MAX_USER_DERIVED], zero[PMX_MAX_INPUTS] = {0}, bv[PMX_MAX_INPUTS] = {0};
+            double f0[PMX_MAX_STATES], f1[PMX_MAX_STATES];
+            cov_values(&ctx, e->time, cv);
+            eval_derived(&ctx, theta, e->time, der);
+            const double* dp = (g_user_mask & PMX_FN_DERIVE) ? der : 0;
+            bv[e->io] = e->value;
+            for (int k = 0; k < m->nstates; k++) f0[k] = f1[k] = 0.0;
+            g_user_dynamics_bolus(e->time, x, theta, m->n_covariates ? cv : 0, zero, zero, dp, f0);
+            g_user_dynamics_bolus(e->time, x, theta, m->n_covariates ? cv : 0, zero, bv, dp, f1);
+            for (int k = 0; k < m->nstates; k++) x[k] += f1[k] - f0[k]; /* axpy(-1, without, 1) then y += */
+          } else {
+            int dest = m->bolus_dest[e->io] >= 0 ? m->bolus_dest[e->io] : (int)e->io;
+            x[dest] += e->value;
+          }
         } else if (e->kind == PMX_EV_OBSERVATION) { /* :692-715 */
           double y[PMX_MAX_OUT] = {0.0, 0.0, 0.0, 0.0};
           if ((int)e->io >= m->nout) return PMX_ERR_OUTEQ_OUT_OF_RANGE;
@@ -1127,7 +1165,10 @@ static int validate(const pmx_model_desc* m, const pmx_population_desc* pop) {
     }
   } else if (m->eq_kind == PMX_EQ_ODE) {
     if (m->kernel == PMX_ODE_CUSTOM) {
-      if (!g_custom_dynamics || !g_custom_outputs) FAIL(PMX_ERR_INVALID_ARGUMENT, "custom ODE bodies not registered");
+      if (is_user_ode(m)) {
+        if (!g_user_outputs) FAIL(PMX_ERR_INVALID_ARGUMENT, "user ODE model: no outputs closure registered");
+      } else if (!g_custom_dynamics || !g_custom_outputs)
+        FAIL(PMX_ERR_INVALID_ARGUMENT, "custom ODE bodies not registered");
     } else {
       if (ode_nstates(m->kernel) < 0) FAIL(PMX_ERR_INVALID_ARGUMENT, "unknown ODE model %d", m->kernel);
       if (m->nstates < ode_nstates(m->kernel)) FAIL(PMX_ERR_INVALID_ARGUMENT, "ODE model needs more states");

@@ -53,8 +53,9 @@ int32_t pmx_oracle_loglik(const pmx_model_desc* model, const pmx_population_desc
 int32_t pmx_oracle_sigma(const pmx_error_model* em, double observation, double* sigma);
 /* PMX_ODE_CUSTOM: the three user bodies (any may be NULL except dynamics/outputs), see oracle/__init__.py */
 void pmx_oracle_set_custom(void* dynamics, void* outputs, void* init);
-/* User closures of an ANALYTICAL model (pmx_model_create_user): mask = PMX_FN_* bits, fns[bit position] = the gcc-built
- * bodies of the same source the device compiles.  mask = 0 clears the registration (descriptor models). */
+/* User closures of an ANALYTICAL or ODE model (pmx_model_create_user): mask = PMX_FN_* bits, fns[bit position] (9 slots)
+ * = the gcc-built bodies of the same source the device compiles.  mask = 0 clears the registration (descriptor models
+ * and pmx_model_create_custom bodies). */
 void pmx_oracle_set_user(uint32_t mask, void** fns);
 
 /* lognormpdf (likelihood/distributions.rs:31-34) */

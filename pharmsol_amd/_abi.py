@@ -245,7 +245,8 @@ class PmxError(RuntimeError):
 PMX_K_CUSTOM = 100
 PMX_FN_DYNAMICS, PMX_FN_OUTPUTS, PMX_FN_INIT, PMX_FN_DERIVE = 1, 2, 4, 8
 PMX_FN_ROUTE_LAG, PMX_FN_ROUTE_BIOAVAILABILITY, PMX_FN_SEQ_EQ, PMX_FN_EQ = 16, 32, 64, 128
-USER_FUNCTION_BITS = {"pmx_dynamics": PMX_FN_DYNAMICS, "pmx_outputs": PMX_FN_OUTPUTS, "pmx_init": PMX_FN_INIT,
+PMX_FN_DYNAMICS_BOLUS = 256
+USER_FUNCTION_BITS = {"pmx_dynamics": PMX_FN_DYNAMICS, "pmx_dynamics_bolus": PMX_FN_DYNAMICS_BOLUS, "pmx_outputs": PMX_FN_OUTPUTS, "pmx_init": PMX_FN_INIT,
                       "pmx_derive": PMX_FN_DERIVE, "pmx_route_lag": PMX_FN_ROUTE_LAG,
                       "pmx_route_bioavailability": PMX_FN_ROUTE_BIOAVAILABILITY, "pmx_seq_eq": PMX_FN_SEQ_EQ,
                       "pmx_eq": PMX_FN_EQ}

@@ -21,11 +21,10 @@
 
 #include "pmx_device.hpp"
 #include "pmx_structures.hpp"
+#include "pmx_userlag.hpp"
 
 namespace pmx {
 namespace {
-
-constexpr int kUserMaxLagPerOccasion = 64;  // lagged boluses one occasion may hold (host-checked, pmx_api.cpp)
 
 // Policy M:
 //   NS, NP, NIN (ndrugs), NOUT, NCOV, NDER       sizes
@@ -35,41 +34,7 @@ constexpr int kUserMaxLagPerOccasion = 64;  // lagged boluses one occasion may h
 //   HAS_LAG, HAS_FA, HAS_SEQ, HAS_DERIVE, STATIC_COEF (built-in structure whose rate constants never change in a lane)
 //   derive(t, p, cov, der) / lag(t, p, cov, der, lag[NIN]) / fa(.., fa[NIN]) / init(p, cov, der, x) /
 //   out(t, x, p, cov, der, y) / seq(t, theta, cov, pw) / eq(dt, x, pw, cov, rate, der, xn) / kernel_params(pw, der, kp)
-template <class M>
-struct UserCov {
-  double v[M::NCOV > 0 ? M::NCOV : 1];
-};
-template <class M>
-struct UserDer {
-  double v[M::NDER > 0 ? M::NDER : 1];
-};
-
-template <class M>
-__device__ __forceinline__ void user_cov(const DevOps& ops, int64_t occ, double t, UserCov<M>& c) {
-  if constexpr (M::NCOV > 0) {
-#pragma unroll
-    for (int i = 0; i < M::NCOV; ++i) c.v[i] = cov_at(ops, occ, i, t);
-  } else {
-    c.v[0] = 0.0;
-  }
-}
-// covariates at t and the derived values there (`derive` runs first in every macro-lowered closure)
-template <class M>
-__device__ __forceinline__ void user_cov_der(const DevOps& ops, int64_t occ, double t, const double* p, UserCov<M>& c,
-                                             UserDer<M>& d) {
-  user_cov<M>(ops, occ, t, c);
-#pragma unroll
-  for (int i = 0; i < (M::NDER > 0 ? M::NDER : 1); ++i) d.v[i] = 0.0;
-  if constexpr (M::HAS_DERIVE) M::derive(t, p, c.v, d.v);
-}
-
-// The lane's view of the occasion's lagged boluses: landing times, sorted; `idx` = position in the occasion's list.
-struct UserLag {
-  double tau[kUserMaxLagPerOccasion];
-  uint16_t idx[kUserMaxLagPerOccasion];
-  int32_t n, cur;
-  int64_t base;
-};
+// (UserCov / UserDer / UserLag: pmx_userlag.hpp)
 
 template <class M>
 struct UserState {
@@ -153,59 +118,13 @@ __device__ __forceinline__ void user_bolus(const DevOps& ops, int64_t occ, const
   user_add<M>(s.x, input, amount * f);
 }
 
-// RESET of a model with lag: this lane's landing times of the occasion's lagged boluses, sorted (add_lagtime + sort,
-// structs.rs:611-643).  Returns false when a lag time is NaN (the reference panics in its sort).
-template <class M>
-__device__ __forceinline__ bool user_lag_open(const DevOps& ops, int64_t occ, const double* __restrict__ th, UserLag& L) {
-  bool ok = true;
-  L.base = ops.lagb_off[occ];
-  int64_t n = ops.lagb_off[occ + 1] - L.base;
-  if (n > kUserMaxLagPerOccasion) n = kUserMaxLagPerOccasion;  // (the host refuses such populations)
-  L.n = static_cast<int32_t>(n);
-  L.cur = 0;
-#pragma unroll 1
-  for (int32_t j = 0; j < L.n; ++j) {
-    const double t = ops.lagb_time[L.base + j];
-    const int input = ops.lagb_input[L.base + j];
-    UserCov<M> cov;
-    UserDer<M> der;
-    user_cov_der<M>(ops, occ, t, th, cov, der);
-    double lag[M::NIN];
-#pragma unroll
-    for (int i = 0; i < M::NIN; ++i) lag[i] = 0.0;
-    M::lag(t, th, cov.v, der.v, lag);
-    double l = 0.0;
-#pragma unroll
-    for (int i = 0; i < M::NIN; ++i) l = (i == input) ? lag[i] : l;
-    double tau = (l != 0.0) ? (t + l) : t;  // `if l != 0.0 { *bolus.mut_time() += l }`  (:631-634)
-    if (tau != tau) {
-      ok = false;
-      tau = __longlong_as_double(0x7ff0000000000000LL);
-    }
-    int32_t k = j;  // stable insertion: equal landing times keep the list order
-#pragma unroll 1
-    while (k > 0 && L.tau[k - 1] > tau) {
-      L.tau[k] = L.tau[k - 1];
-      L.idx[k] = L.idx[k - 1];
-      --k;
-    }
-    L.tau[k] = tau;
-    L.idx[k] = static_cast<uint16_t>(j);
-  }
-  return ok;
-}
-
-__device__ __forceinline__ double user_lag_next(const UserLag& L) {
-  return (L.cur < L.n) ? L.tau[L.cur] : __longlong_as_double(0x7ff0000000000000LL);
-}
-
 template <class M>
 __device__ __forceinline__ void user_lag_apply(const DevOps& ops, int64_t occ, const double* __restrict__ th,
                                                UserState<M>& s, UserLag& L) {
-  const int32_t j = L.idx[L.cur];
-  const double tau = L.tau[L.cur];
-  L.cur += 1;
-  user_bolus<M>(ops, occ, th, s, tau, ops.lagb_input[L.base + j], ops.lagb_amount[L.base + j]);
+  double tau, amount;
+  int input;
+  user_lag_take<M>(ops, occ, th, L, &tau, &input, &amount);
+  user_bolus<M>(ops, occ, th, s, tau, input, amount);
   s.fresh = true;  // an event: whatever follows is another solve
 }
 
@@ -246,6 +165,9 @@ __device__ __forceinline__ void user_walk_subject(const DevOps& ops, const doubl
   UserLag lagst;
   lagst.n = lagst.cur = 0;
   lagst.base = 0;
+  lagst.big = false;
+  lagst.nxt_tau = inf;
+  lagst.nxt_idx = -1;
   int64_t occ = 0;
   uint8_t st = PMX_PAIR_OK;
   bool bad_lag = false;

@@ -228,7 +228,8 @@ struct pmx_model {
   // custom (hiprtc) models: the code object and its per-device modules
   bool custom = false;
   uint32_t user_fns = 0;  // PMX_FN_* the user's source defines (pmx_model_create_user)
-  bool user_lag = false, user_eq = false;  // analytical user model: any lag closure (user's or descriptor's) / own propagator
+  bool user_lag = false, user_eq = false;  // user model: any lag closure (user's or descriptor's) / own propagator
+  bool user_ode = false;                   // ODE model on the general walker (pmx_ode_user.hpp): lag / fa / derive closures, bolus[]
   std::vector<char> jit_code;
   mutable std::mutex jit_mu;
   mutable std::map<int, pmx::JitModule> jit_modules;
@@ -569,9 +570,39 @@ int32_t check_user_analytical(const pmx_model_desc* d, const char* source, uint3
     }
   return PMX_OK;
 }
+// ODE model with user closures beyond the dynamics (pmx.h "user closures for either back-end", ODE models)
+int32_t check_user_ode(const pmx_model_desc* d, const char* source, uint32_t fns) {
+  if (!d || !source) return fail(PMX_ERR_INVALID_ARGUMENT, "null argument");
+  if (d->kernel != PMX_ODE_CUSTOM) return fail(PMX_ERR_INVALID_ARGUMENT, "ODE models with user closures need kernel = PMX_ODE_CUSTOM");
+  const bool dyn = (fns & PMX_FN_DYNAMICS) != 0, dynb = (fns & PMX_FN_DYNAMICS_BOLUS) != 0;
+  if (dyn == dynb) return fail(PMX_ERR_INVALID_ARGUMENT, "ODE models define pmx_dynamics OR pmx_dynamics_bolus (PMX_FN_DYNAMICS | PMX_FN_DYNAMICS_BOLUS)");
+  if (!(fns & PMX_FN_OUTPUTS)) return fail(PMX_ERR_INVALID_ARGUMENT, "ODE models define pmx_outputs (PMX_FN_OUTPUTS)");
+  if (fns & (PMX_FN_SEQ_EQ | PMX_FN_EQ)) return fail(PMX_ERR_INVALID_ARGUMENT, "PMX_FN_SEQ_EQ / PMX_FN_EQ belong to analytical models");
+  if (d->nstates < 1 || d->nstates > PMX_MAX_STATES) return fail(PMX_ERR_INVALID_ARGUMENT, "nstates out of range");
+  if (d->ndrugs < 1 || d->ndrugs > PMX_MAX_INPUTS) return fail(PMX_ERR_INVALID_ARGUMENT, "ndrugs out of range (1..8 for a model with user closures)");
+  if (d->nout < 1 || d->nout > PMX_MAX_OUT) return fail(PMX_ERR_INVALID_ARGUMENT, "nout out of range");
+  if (d->nparams < 1 || d->nparams > PMX_MAX_PARAMS) return fail(PMX_ERR_INVALID_ARGUMENT, "nparams out of range");
+  if (d->n_covariates < 0 || d->n_covariates > PMX_MAX_COVARIATES) return fail(PMX_ERR_INVALID_ARGUMENT, "n_covariates out of range");
+  if (d->n_derived < 0 || d->n_derived > PMX_MAX_USER_DERIVED) return fail(PMX_ERR_INVALID_ARGUMENT, "n_derived out of range");
+  if (d->n_derived > 0 && !(fns & PMX_FN_DERIVE)) return fail(PMX_ERR_INVALID_ARGUMENT, "n_derived > 0 needs PMX_FN_DERIVE (desc.derived[] is not read for user models)");
+  if (d->n_bind != 0 || d->pmetrics_indexing) return fail(PMX_ERR_INVALID_ARGUMENT, "bind[] / pm indexing do not apply to ODE models with user closures");
+  if (!(d->rk4_h_max > 0.0)) return fail(PMX_ERR_INVALID_ARGUMENT, "rk4_h_max must be > 0");
+  if (d->ode_solver != PMX_SOLVER_RK4 && d->ode_solver != PMX_SOLVER_DOPRI5) return fail(PMX_ERR_INVALID_ARGUMENT, "unknown ode_solver");
+  if (d->ode_solver == PMX_SOLVER_DOPRI5 && !(d->ode_rtol > 0.0 && d->ode_atol > 0.0))
+    return fail(PMX_ERR_INVALID_ARGUMENT, "the adaptive solver needs ode_rtol > 0 and ode_atol > 0");
+  for (int i = 0; i < PMX_MAX_INPUTS; ++i) {
+    if (d->lag_param[i] >= d->nparams || d->fa_param[i] >= d->nparams)
+      return fail(PMX_ERR_INVALID_ARGUMENT, "lag_param / fa_param out of range");
+    if (d->bolus_dest[i] >= d->nstates) return fail(PMX_ERR_INVALID_ARGUMENT, "route destination out of range");
+  }
+  for (int i = 0; i < PMX_MAX_STATES; ++i)
+    if (d->init_param[i] >= d->nparams) return fail(PMX_ERR_INVALID_ARGUMENT, "init_param out of range");
+  return PMX_OK;
+}
 pmx::JitSpec user_spec_of(const pmx_model_desc* d, const char* source, uint32_t fns) {
   pmx::JitSpec sp;
-  sp.analytical = true;
+  sp.analytical = d->eq_kind == PMX_EQ_ANALYTICAL;
+  sp.ode_user = d->eq_kind == PMX_EQ_ODE;
   sp.fns = fns;
   sp.desc = *d;
   sp.source = source;
@@ -587,9 +618,23 @@ int32_t pmx_model_create_user(const pmx_model_desc* d, const char* source, uint3
   *out = nullptr;
   if (!d) return fail(PMX_ERR_INVALID_ARGUMENT, "null argument");
   if (d->eq_kind == PMX_EQ_ODE) {
-    if ((functions & ~static_cast<uint32_t>(PMX_FN_INIT)) != (PMX_FN_DYNAMICS | PMX_FN_OUTPUTS))
-      return fail(PMX_ERR_UNSUPPORTED, "ODE models take PMX_FN_DYNAMICS | PMX_FN_OUTPUTS (| PMX_FN_INIT); lag / fa are theta-indexed (lag_param / fa_param)");
-    return pmx_model_create_custom(d, source, (functions & PMX_FN_INIT) ? 1 : 0, out);
+    if ((functions & ~static_cast<uint32_t>(PMX_FN_INIT)) == (PMX_FN_DYNAMICS | PMX_FN_OUTPUTS) && d->n_derived == 0)
+      return pmx_model_create_custom(d, source, (functions & PMX_FN_INIT) ? 1 : 0, out);  // theta-indexed lag / fa: the state-machine kernels
+    const int32_t rc = check_user_ode(d, source, functions);
+    if (rc != PMX_OK) return rc;
+    auto m = std::make_unique<pmx_model>();
+    m->d = *d;
+    m->custom = true;
+    m->user_ode = true;
+    m->user_fns = functions;
+    m->user_lag = (functions & PMX_FN_ROUTE_LAG) != 0;
+    for (int i = 0; i < PMX_MAX_INPUTS; ++i) m->user_lag |= d->lag_param[i] >= 0;
+    m->has_init = true;  // (RESET ops always carry the occasion-index flag; the policy's init may be empty)
+    std::string log;
+    if (!pmx::jit_compile(user_spec_of(d, source, functions), &m->jit_code, &log))
+      return fail(PMX_ERR_INVALID_ARGUMENT, "hiprtc could not compile the model source:\n" + log);
+    *out = m.release();
+    return PMX_OK;
   }
   if (d->eq_kind != PMX_EQ_ANALYTICAL) return fail(PMX_ERR_INVALID_ARGUMENT, "unknown eq_kind");
   const int32_t rc = check_user_analytical(d, source, functions);
@@ -614,8 +659,10 @@ int32_t pmx_debug_jit_source_user(const pmx_model_desc* d, const char* source, u
   if (!out_text) return fail(PMX_ERR_INVALID_ARGUMENT, "out_text is null");
   *out_text = nullptr;
   if (!d) return fail(PMX_ERR_INVALID_ARGUMENT, "null argument");
-  if (d->eq_kind == PMX_EQ_ODE) return pmx_debug_jit_source(d, source, (functions & PMX_FN_INIT) ? 1 : 0, out_text);
-  const int32_t rc = check_user_analytical(d, source, functions);
+  if (d->eq_kind == PMX_EQ_ODE && (functions & ~static_cast<uint32_t>(PMX_FN_INIT)) == (PMX_FN_DYNAMICS | PMX_FN_OUTPUTS) &&
+      d->n_derived == 0)
+    return pmx_debug_jit_source(d, source, (functions & PMX_FN_INIT) ? 1 : 0, out_text);
+  const int32_t rc = d->eq_kind == PMX_EQ_ODE ? check_user_ode(d, source, functions) : check_user_analytical(d, source, functions);
   if (rc != PMX_OK) return rc;
   const std::string tu = pmx::jit_translation_unit(user_spec_of(d, source, functions));
   char* buf = static_cast<char*>(std::malloc(tu.size() + 1));
@@ -684,6 +731,20 @@ pmx::CompileKey key_for(const pmx_model* m) {
     // covariate models that take the generic walker: equal (length, factors) PROPs of an occasion share a propagator
     if (m->dyn && k.lag_mask == 0 && k.class_g == 0) k.prop_cache_slots = tun.prop_slots >= 0 ? (tun.prop_slots > 3 ? 3 : tun.prop_slots) : 1;  // (one slot: a second costs more occupancy
     // than its extra reuse returns - C5: 1 slot 16.8 ms, 2 slots 19.4 ms, none 20.2 ms; tools/c5 notes in DESIGN.md)
+  } else if (m->user_ode) {
+    // ODE with user lag / fa / derive closures (pmx_ode_user.hpp): covariates are looked up on the device, every PROP
+    // carries its absolute [t0, t1), every input's rate rides along, and - when the model has any lag closure - ALL
+    // boluses leave the stream into one list per occasion that each lane sorts itself
+    k.cov_time_mode = PMX_COV_TIME_SEGMENT_END_ABS;
+    k.rk4_h_max = m->d.rk4_h_max;
+    k.n_rate = m->d.ndrugs > 0 ? m->d.ndrugs : 1;
+    k.rate_input = 0;
+    k.want_times = true;
+    k.user_cov = true;
+    if (m->user_lag) {
+      k.lag_merge = true;
+      for (int i = 0; i < m->d.ndrugs && i < PMX_MAX_INPUTS; ++i) k.lag_mask |= (1u << i);
+    }
   } else {
     k.cov_time_mode = PMX_COV_TIME_SEGMENT_END_ABS;
     k.rk4_h_max = m->d.rk4_h_max;
@@ -953,9 +1014,6 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
   if (pop->hp.max_outeq >= d.nout)
     return fail(PMX_ERR_OUTEQ_OUT_OF_RANGE,
                 "outeq " + std::to_string(pop->hp.max_outeq) + " >= nout " + std::to_string(d.nout));
-  if (model->custom && d.eq_kind == PMX_EQ_ANALYTICAL && ds->max_lagb_per_list > 64)  // pmx_analytical.hpp kUserMaxLagPerOccasion
-    return fail(PMX_ERR_UNSUPPORTED, "an occasion holds " + std::to_string(ds->max_lagb_per_list) +
-                                         " boluses; a model with a lag closure sorts at most 64 per occasion on the device");
   if (pop->hp.n_subjects == 0) return PMX_OK;
 
   pmx::LaunchArgs a{};
@@ -989,7 +1047,7 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
   std::memcpy(a.m.fa_param, d.fa_param, sizeof(d.fa_param));
   for (int i = 0; i < PMX_MAX_INPUTS; ++i) {
     if (d.fa_param[i] >= 0) a.m.has_fa = 1;
-    if (d.lag_param[i] >= 0 && a.m.n_lag_slots < pmx::kMaxLagSlots) {
+    if (d.lag_param[i] >= 0 && a.m.n_lag_slots < pmx::kMaxLagSlots && !model->user_ode) {
       a.m.lag_input[a.m.n_lag_slots] = i;
       a.m.lag_param[a.m.n_lag_slots] = d.lag_param[i];
       a.m.lag_dest[a.m.n_lag_slots] = (d.eq_kind == PMX_EQ_ODE && d.bolus_dest[i] >= 0) ? d.bolus_dest[i] : i;
@@ -1081,20 +1139,24 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
       auto it = model->jit_modules.find(pop->device);
       if (it == model->jit_modules.end()) {
         pmx::JitModule mod;
-        const hipError_t le = pmx::jit_load(model->jit_code, &mod, d.eq_kind == PMX_EQ_ANALYTICAL);
+        const hipError_t le = pmx::jit_load(model->jit_code, &mod, d.eq_kind == PMX_EQ_ANALYTICAL ? pmx::JIT_ANALYTICAL
+                                                                   : (model->user_ode ? pmx::JIT_ODE_USER : pmx::JIT_ODE));
         if (le != hipSuccess) return fail(PMX_ERR_HIP, std::string("loading the compiled model: ") + hipGetErrorString(le));
         it = model->jit_modules.emplace(pop->device, mod).first;
       }
       jm = &it->second;
     }
-    const bool ua = d.eq_kind == PMX_EQ_ANALYTICAL;  // user analytical model: [mode][0][LL][0]
-    const int lag = (!ua && a.m.n_lag_slots > 0) ? 1 : 0, ll = a.ops.ll_obs != nullptr ? 1 : 0, ad = (!ua && a.adaptive) ? 1 : 0;
+    const bool ua = d.eq_kind == PMX_EQ_ANALYTICAL;  // user analytical model: [mode][0][LL][0]; general ODE walker: [mode][0][LL][ADAPT]
+    const int lag = (!ua && !model->user_ode && a.m.n_lag_slots > 0) ? 1 : 0, ll = a.ops.ll_obs != nullptr ? 1 : 0,
+              ad = (!ua && a.adaptive) ? 1 : 0;
     const int mode = a.mode == pmx::MODE_GRID ? 0 : 1;
     static const char* const kNames[2][2][2] = {
         {{"pmx_jit_ode_rk4_grid", "pmx_jit_ode_rk4_grid<lag>"}, {"pmx_jit_ode_rk4_pair", "pmx_jit_ode_rk4_pair<lag>"}},
         {{"pmx_jit_ode_dopri5_grid", "pmx_jit_ode_dopri5_grid<lag>"}, {"pmx_jit_ode_dopri5_pair", "pmx_jit_ode_dopri5_pair<lag>"}}};
     name = kNames[ad][mode][lag];
     if (ua) name = mode == 0 ? "pmx_jit_analytical_grid" : "pmx_jit_analytical_pair";
+    if (model->user_ode) name = mode == 0 ? (ad ? "pmx_jit_ode_user_dopri5_grid" : "pmx_jit_ode_user_rk4_grid")
+                                          : (ad ? "pmx_jit_ode_user_dopri5_pair" : "pmx_jit_ode_user_rk4_pair");
     if (a.S <= 0 || (a.P <= 0 && !a.batch)) {
       e = hipSuccess;
     } else if (mode == 0) {

@@ -380,22 +380,21 @@ int32_t compile_ops(const HostPopulation& hp, const CompileKey& key, OpStream* o
         auto is_lagged = [&](int64_t e) {
           return n_slots > 0 && hp.ev_kind[e] == PMX_EV_BOLUS && hp.ev_io[e] < PMX_MAX_INPUTS && slot_of_input[hp.ev_io[e]] >= 0;
         };
-        double t = 0.0;  // Occasion::initial_time over the events that stay in the list, structs.rs:782-793
-        {
-          bool any = false;
-          for (int64_t e = e0; e < e1; ++e) {
-            if (is_lagged(e)) continue;
-            t = any ? std::min(t, hp.ev_time[e]) : hp.ev_time[e];
-            any = true;
-          }
-        }
+        // The solver clock starts at Occasion::initial_time() of the occasion AS RECORDED - lagged boluses at their
+        // recorded times included (ode/mod.rs:348 takes it from the occasion, not from the lag-rewritten event list;
+        // structs.rs:782-793) - and only moves forward to the time of the next event (ode/mod.rs:719-721).  PROP ops
+        // therefore start there; a lane whose own clock is ahead (boluses that landed before the first remaining event
+        // took it there) starts its piece at its clock (pmx_ode.hpp / pmx_ode_user.hpp).  RESET: op_b = that time.
+        double t = 0.0;
+        for (int64_t e = e0; e < e1; ++e) t = (e == e0) ? hp.ev_time[e] : std::min(t, hp.ev_time[e]);
+        os->op_b[reset_op] = t;
         size_t bcur = 0;
         for (int64_t e = e0; e < e1; ++e) {
           const uint8_t k = hp.ev_kind[e];
           if (is_lagged(e)) continue;
           if (k == PMX_EV_BOLUS) {
             max_input_used = std::max<int32_t>(max_input_used, hp.ev_io[e]);
-            push(OP_BOLUS, hp.ev_io[e], hp.ev_value[e], 0.0, 0, nullptr, oc, 0.0, false);
+            push(OP_BOLUS, hp.ev_io[e], hp.ev_value[e], hp.ev_time[e], 0, nullptr, oc, 0.0, false);  // (op_b: its time, for a user fa / bolus jump)
           } else if (k == PMX_EV_OBSERVATION) {
             push(OP_OBS, hp.ev_io[e], hp.ev_time[e], 0.0, 0, nullptr, oc, hp.ev_time[e], true);
           }

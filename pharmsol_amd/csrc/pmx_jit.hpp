@@ -18,12 +18,18 @@ struct JitSpec {
   // user ANALYTICAL models (pmx_analytical.hpp): which closures `source` defines (PMX_FN_*), and the descriptor the
   // generator turns into code for the closures it leaves out
   bool analytical = false;
+  // user ODE models whose lag / fa / derive are closures too, or whose dynamics takes the bolus vector
+  // (pmx_ode_user.hpp): same two fields
+  bool ode_user = false;
   uint32_t fns = 0;
   pmx_model_desc desc{};
 };
+enum JitKind { JIT_ODE = 0, JIT_ANALYTICAL = 1, JIT_ODE_USER = 2 };
+inline JitKind jit_kind(const JitSpec& s) { return s.analytical ? JIT_ANALYTICAL : (s.ode_user ? JIT_ODE_USER : JIT_ODE); }
 
 // The translation unit handed to hiprtc (user source + policy + the kernel wrappers: 16 for an ODE model - GRID/PAIR x
-// lag x log-likelihood x solver -, 4 for an analytical one - GRID/PAIR x log-likelihood).
+// lag x log-likelihood x solver -, 4 for an analytical one - GRID/PAIR x log-likelihood -, 8 for an ODE model with
+// user lag / fa closures - GRID/PAIR x log-likelihood x solver).
 std::string jit_translation_unit(const JitSpec& spec);
 
 // Source text (pmx_dynamics / pmx_outputs / pmx_init) of a BUILT-IN diffeq body whose parameters / volumes are derived
@@ -39,7 +45,7 @@ struct JitModule {
   hipFunction_t fn[2][2][2][2] = {};  // [mode: 0 GRID, 1 PAIR][LAG][LL][ADAPT]
 };
 // Load a compiled code object on the CURRENT device and resolve the kernel entry points.
-hipError_t jit_load(const std::vector<char>& code, JitModule* out, bool analytical = false);
+hipError_t jit_load(const std::vector<char>& code, JitModule* out, JitKind kind = JIT_ODE);
 void jit_unload(JitModule* m);
 
 }  // namespace pmx

@@ -288,12 +288,17 @@ __device__ __forceinline__ void ode_piece(const DevModel& m, const OdeLane<M>& L
 }
 
 // lag_open_occasion / lag_prop of the ODE back-end: same merge rule, RK4 pieces instead of closed forms.
-// Between an early lagged bolus and the occasion's first remaining event no infusion can be active
-// (infusions are events of the occasion), so those pieces run with zero rates.
+//
+// The solver clock (ode/mod.rs:348,719-721): the reference's solver starts at the occasion's RECORDED initial time
+// `t_rec` (Occasion::initial_time, lagged boluses at their recorded times included) and only advances
+// `while next_event_time > solver.state().t`.  The first event of the lag-rewritten list is applied at that clock
+// without integration; every later event is reached by integrating from the clock if its time lies ahead.  Between an
+// early lagged bolus and the occasion's first remaining event no infusion can be active (infusions are events of the
+// occasion), so those pieces run with zero rates.  Returns the clock on arrival at the first remaining event.
 template <class M, bool ADAPT>
-__device__ __forceinline__ void ode_lag_open_occasion(const DevModel& m, const DevOps& ops, LagState& ls, int64_t occ,
-                                                      double t_first, const OdeLane<M>& L, const double* __restrict__ th,
-                                                      double (&x)[M::NS], AdaptState& as) {
+__device__ __forceinline__ double ode_lag_open_occasion(const DevModel& m, const DevOps& ops, LagState& ls, int64_t occ,
+                                                        double t_first, double t_rec, const OdeLane<M>& L,
+                                                        const double* __restrict__ th, double (&x)[M::NS], AdaptState& as) {
   constexpr int NS = M::NS;
 #pragma unroll
   for (int k = 0; k < kMaxLagSlots; ++k) {
@@ -307,18 +312,24 @@ __device__ __forceinline__ void ode_lag_open_occasion(const DevModel& m, const D
   double zero[M::NR];
 #pragma unroll
   for (int i = 0; i < M::NR; ++i) zero[i] = 0.0;
-  bool started = false;
-  double t = 0.0;
+  bool first = true;
+  double clk = t_rec;
   for (;;) {
     int which;
     const double tau = lag_next(m, ops, ls, which);
     if (!(tau < t_first)) break;
-    if (started) ode_piece<M, ADAPT>(m, L, x, zero, t, tau, as);
-    t = tau;
-    started = true;
+    if (!first && tau > clk) {
+      ode_piece<M, ADAPT>(m, L, x, zero, clk, tau, as);
+      clk = tau;
+    }
+    first = false;
     lag_apply_bolus<NS>(m, ops, ls, which, th, x);
   }
-  if (started && t_first < __longlong_as_double(0x7ff0000000000000LL)) ode_piece<M, ADAPT>(m, L, x, zero, t, t_first, as);
+  if (!first && t_first > clk && t_first < __longlong_as_double(0x7ff0000000000000LL)) {
+    ode_piece<M, ADAPT>(m, L, x, zero, clk, t_first, as);
+    clk = t_first;
+  }
+  return clk;
 }
 
 template <class M, bool ADAPT>
@@ -384,6 +395,7 @@ __device__ __forceinline__ void ode_grid_body(const DevModel& m, const DevOps& o
     AdaptState as;  // adaptive solver: the step-size proposal restarts with every subject
     as.h = m.rk4_h_max;
     as.failed = 0;
+    double clk = 0.0;  // LAG: the lane's solver clock (see ode_lag_open_occasion)
     for (int64_t o = o0; o < o1; ++o) {
       const uint32_t meta = uniform32(ops.op_meta[o]);
       const uint32_t kind = meta & 0xffu;
@@ -393,7 +405,9 @@ __device__ __forceinline__ void ode_grid_body(const DevModel& m, const DevOps& o
         double rs[M::NR];
         ode_rates<M>(m, ops.op_rate, o, ops.n_rate, rs);
         if constexpr (LAG) {
-          ode_lag_prop<M, ADAPT>(m, ops, ls, uniformf64(ops.op_t0[o]), uniformf64(ops.op_t1[o]), L, rs, th, x, as);
+          const double t0 = uniformf64(ops.op_t0[o]), t1 = uniformf64(ops.op_t1[o]);
+          ode_lag_prop<M, ADAPT>(m, ops, ls, (clk > t0) ? clk : t0, t1, L, rs, th, x, as);
+          if (t1 > clk) clk = t1;
         } else if constexpr (ADAPT) {
           ode_piece<M, true>(m, L, x, rs, uniformf64(ops.op_t0[o]), uniformf64(ops.op_t1[o]), as);
         } else {
@@ -427,7 +441,8 @@ __device__ __forceinline__ void ode_grid_body(const DevModel& m, const DevOps& o
         L.occ = static_cast<int64_t>(a);
         ode_reset<M>(L, io, x);
         if constexpr (LAG)
-          ode_lag_open_occasion<M, ADAPT>(m, ops, ls, static_cast<int64_t>(a), uniformf64(ops.op_t0[o]), L, th, x, as);
+          clk = ode_lag_open_occasion<M, ADAPT>(m, ops, ls, static_cast<int64_t>(a), uniformf64(ops.op_t0[o]),
+                                                uniformf64(ops.op_b[o]), L, th, x, as);
       }
     }
     if constexpr (LL) {
@@ -506,6 +521,7 @@ __device__ __forceinline__ void ode_pair_body(const DevModel& m, const DevOps& o
   // LAG: an open PROP (or occasion opening) [t_cur, t_stop) that lagged boluses may still split
   bool in_prop = false;
   double t_cur = 0.0, t_stop = 0.0;
+  double clk = 0.0;  // LAG: the lane's solver clock (see ode_lag_open_occasion)
   // Every phase is bounded and the op phase is a single if / else chain per action: with `continue`s the compiler
   // rotated the stepping branch into an unbounded inner per-lane loop and lanes that needed an op waited for the
   // longest piece in the wave (measured on the first version of this loop: C4 2.4 -> 3.9 ms).
@@ -581,6 +597,7 @@ __device__ __forceinline__ void ode_pair_body(const DevModel& m, const DevOps& o
           lag_apply_bolus<NS>(m, ops, ls, which, th, x);
         } else {
           in_prop = false;
+          if (t_stop > clk) clk = t_stop;
           ++o;
         }
       } else if (idle && o < filled) {
@@ -610,7 +627,7 @@ __device__ __forceinline__ void ode_pair_body(const DevModel& m, const DevOps& o
           ode_rates<M>(m, ops.op_rate, o, ops.n_rate, op_r0, rs);
           if constexpr (LAG) {
             in_prop = true;
-            t_cur = op_t0;
+            t_cur = (clk > op_t0) ? clk : op_t0;
             t_stop = op_t1;
             next_op = false;
           } else if constexpr (ADAPT) {
@@ -657,15 +674,19 @@ __device__ __forceinline__ void ode_pair_body(const DevModel& m, const DevOps& o
                 ls.end[k] = static_cast<int32_t>(ops.lagb_off[occ * m.n_lag_slots + k + 1]);
               }
             }
-            // boluses landing before the occasion's first remaining event open the occasion (zero rates there)
+            // boluses landing before the occasion's first remaining event open the occasion (zero rates there).  The
+            // first of them is the first event of the re-sorted list: applied here, at the clock as it stands (the
+            // occasion's recorded initial time, op_b of the RESET); the rest is reached from the clock.
+            clk = op_h;
             int which;
             const double tau = lag_next(m, ops, ls, which);
             const double t_first = op_t0;
             if (tau < t_first && t_first < inf) {
+              lag_apply_bolus<NS>(m, ops, ls, which, th, x);
   #pragma unroll
               for (int j = 0; j < M::NR; ++j) rs[j] = 0.0;
               in_prop = true;
-              t_cur = tau;
+              t_cur = clk;
               t_stop = t_first;
               next_op = false;
             }

@@ -497,6 +497,48 @@ class ODE(Equation):
         m.rk4_h_max = float(h_max)
         return m.with_nstates(nstates).with_ndrugs(ndrugs).with_nout(nout)
 
+    @staticmethod
+    def user(source: str, *, nstates: int, nparams: int, ndrugs: int = 1, nout: int = 1,
+             covariates: Optional[Sequence[str]] = None, n_derived: int = 0, bolus_dest: Optional[Dict[int, int]] = None,
+             lag: Optional[Dict[int, int]] = None, fa: Optional[Dict[int, int]] = None, h_max: float = 0.02) -> "ODE":
+        """``ODE::new(diffeq, lag, fa, init, out)`` with EVERY closure a function of (theta, t, covariates)
+        (ode/mod.rs:115-132; closure types src/simulator/mod.rs:41-197), index based like the reference's hand-written
+        form.  ``source`` defines ``pmx_dynamics`` - or ``pmx_dynamics_bolus``, the DiffEq with its ``bolus`` argument -
+        and ``pmx_outputs``, and any of ``pmx_init`` / ``pmx_derive`` / ``pmx_route_lag`` / ``pmx_route_bioavailability``
+        (include/pmx.h "user closures").  ``bolus_dest``: input -> state for plain ``pmx_dynamics`` bodies (default:
+        state = input).  ``lag`` / ``fa``: theta-index fall-backs for closures the source leaves out."""
+        m = ODE()
+        m.covariates = list(covariates or [])
+        m.kernel_name = "custom"
+        m.nparams = int(nparams)
+        m.user_derived = [f"d{i}" for i in range(int(n_derived))]
+        m.lag = {str(k): v for k, v in (lag or {}).items()}
+        m.fa = {str(k): v for k, v in (fa or {}).items()}
+        m.user_bolus_dest = dict(bolus_dest or {})
+        m.rk4_h_max = float(h_max)
+        m._set_user_source(source)
+        return m.with_nstates(nstates).with_ndrugs(ndrugs).with_nout(nout)
+
+    user_bolus_dest: Dict[int, int] = {}
+
+    def _set_user_source(self, source: str):
+        fns = _abi.user_functions_of(source)
+        if not (fns & (_abi.PMX_FN_DYNAMICS | _abi.PMX_FN_DYNAMICS_BOLUS)) or not (fns & _abi.PMX_FN_OUTPUTS):
+            raise ValueError("an ODE source defines pmx_dynamics (or pmx_dynamics_bolus) and pmx_outputs")
+        if (fns & _abi.PMX_FN_DYNAMICS) and (fns & _abi.PMX_FN_DYNAMICS_BOLUS):
+            raise ValueError("define pmx_dynamics OR pmx_dynamics_bolus, not both")
+        if fns & (_abi.PMX_FN_SEQ_EQ | _abi.PMX_FN_EQ):
+            raise ValueError("pmx_seq_eq / pmx_eq belong to analytical models")
+        self.source, self.user_fns = str(source), fns
+        self.has_init = bool(fns & _abi.PMX_FN_INIT)
+        self._handle = None
+
+    def desc(self) -> _abi.pmx_model_desc:
+        d = super().desc()
+        for i, st in self.user_bolus_dest.items():
+            d.bolus_dest[int(i)] = int(st)
+        return d
+
     ode_solver = _abi.PMX_SOLVER_RK4
     ode_rtol = 1e-4  # the reference's defaults (ode/mod.rs:126-127)
     ode_atol = 1e-4
@@ -578,12 +620,7 @@ def analytical(*, name: str, params: Sequence[str], structure: Optional[str], st
     _declare(m, name, params, derived, covariates, states, outputs, routes, out, init, lag, fa)
     if source is not None:
         m.user_derived = user_derived
-        consts = ([f"P_{n} = {i}" for i, n in enumerate(m.params)] + [f"D_{n} = {i}" for i, n in enumerate(user_derived)] +
-                  [f"COV_{n} = {i}" for i, n in enumerate(m.covariates)] + [f"X_{n} = {i}" for i, n in enumerate(m.states)] +
-                  [f"Y_{n} = {i}" for i, n in enumerate(m.outputs)] +
-                  [f"R_{n} = {i}" for n, i in dict((r.name, i) for r, i in m._route_inputs()).items()])
-        prelude = "enum { " + ", ".join(consts) + " };\n"
-        m._set_user_source(prelude + source)
+        m._set_user_source(_name_constants(m, user_derived) + source)
     if structure is None:
         if source is None:
             raise ValueError("no structure and no source")
@@ -614,15 +651,51 @@ def analytical(*, name: str, params: Sequence[str], structure: Optional[str], st
     return m
 
 
-def ode(*, name: str, params: Sequence[str], diffeq: str, states: Sequence[str], outputs: Sequence[str],
-        routes: Sequence[Route], out: Dict[str, Ratio], derived=None, covariates=None, init=None, lag=None, fa=None,
-        h_max: float = 0.02) -> ODE:
-    """The ``ode!`` declaration with a built-in ``diffeq`` body (e.g. examples/ode_readme.rs:9-23)."""
+def _name_constants(m: Equation, user_derived: Sequence[str]) -> str:
+    """``enum { P_<param>, D_<derived>, COV_<covariate>, X_<state>, Y_<output>, R_<route> }``: the index constants a
+    ``source=`` text may use the way the macros bind names (symbols.rs:189-239)."""
+    consts = ([f"P_{n} = {i}" for i, n in enumerate(m.params)] + [f"D_{n} = {i}" for i, n in enumerate(user_derived)] +
+              [f"COV_{n} = {i}" for i, n in enumerate(m.covariates)] + [f"X_{n} = {i}" for i, n in enumerate(m.states)] +
+              [f"Y_{n} = {i}" for i, n in enumerate(m.outputs)] +
+              [f"R_{n} = {i}" for n, i in dict((r.name, i) for r, i in m._route_inputs()).items()])
+    return "enum { " + ", ".join(consts) + " };\n"
+
+
+def ode(*, name: str, params: Sequence[str], diffeq: Optional[str] = None, states: Sequence[str], outputs: Sequence[str],
+        routes: Sequence[Route], out: Optional[Dict[str, Ratio]] = None, derived=None, covariates=None, init=None, lag=None,
+        fa=None, h_max: float = 0.02, source: Optional[str] = None) -> ODE:
+    """The ``ode!`` declaration: a built-in ``diffeq`` body by name (e.g. examples/ode_readme.rs:9-23), or ``source=``:
+    C/HIP text with the bodies of the macro's ``diffeq:`` / ``lag:`` / ``fa:`` / ``init:`` / ``out:`` blocks as
+    ``pmx_dynamics`` (routes are injected like the macro does: ``dx[dest] += rateiv[input]``, a bolus lands in its
+    route's destination state, expand/ode.rs:380-406) - or ``pmx_dynamics_bolus``, the hand-written DiffEq that adds
+    ``bolus[..]`` / ``rateiv[..]`` itself - plus ``pmx_route_lag`` / ``pmx_route_bioavailability`` / ``pmx_init`` /
+    ``pmx_outputs`` (/ ``pmx_derive``, then ``derived`` lists the names it writes), compiled for gfx950 at run time.
+    tests/test_full_feature_parity.py re-creates tests/full_feature_macro_parity.rs:10-53 with it."""
     m = ODE()
+    if source is not None:
+        if diffeq is not None:
+            raise ValueError("a source brings its own pmx_dynamics: name no built-in diffeq with it")
+        user_derived = list(derived or [])
+        m.kernel_name = "custom"
+        _declare(m, name, params, None, covariates, states, outputs, routes, out, init, lag, fa)
+        m.user_derived = user_derived
+        m.rk4_h_max = float(h_max)
+        text = _name_constants(m, user_derived) + source
+        fns = _abi.user_functions_of(text)
+        if fns & _abi.PMX_FN_DYNAMICS:
+            # the macro appends the route injection to the diffeq body (expand/ode.rs:380-406): infusion routes only -
+            # a bolus is a jump of `amount` in its destination state (bolus_dest, from the routes)
+            inj = "".join(f"  dx[{m.state_index(r.dest)}] += rateiv[{idx}];\n" for r, idx in m._route_inputs() if r.kind == "infusion")
+            text = text.replace("pmx_dynamics(", "pmx_dynamics_body_(") + (
+                "\nPMX_DEVICE void pmx_dynamics(double t, const double* x, const double* p, const double* cov, "
+                "const double* rateiv, const double* derived, double* dx) {\n"
+                "  pmx_dynamics_body_(t, x, p, cov, rateiv, derived, dx);\n" + inj + "}\n")
+        m._set_user_source(text)
+        return m
     if diffeq not in _abi.ODE_MODELS:
         raise KeyError(f"unknown built-in diffeq '{diffeq}'")
     m.kernel_name = diffeq
-    _declare(m, name, params, derived, covariates, states, outputs, routes, out, init, lag, fa)
+    _declare(m, name, params, derived, covariates, states, outputs, routes, out or {}, init, lag, fa)
     if len(m.states) != _abi.ODE_STATE_COUNT[diffeq]:
         raise ValueError(f"diffeq {diffeq} has {_abi.ODE_STATE_COUNT[diffeq]} states, {len(m.states)} declared")
     m.rk4_h_max = float(h_max)
