@@ -7,7 +7,7 @@ LIB := pharmsol_amd/lib/libpmx_hip.so
 # lines (slope*t + intercept) exactly like the reference; device code keeps FMA contraction.
 HOSTFLAGS := -O2 -std=c++17 -fPIC -Wall -Wextra -ffp-contract=off -Iinclude
 DEVFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-parameter -Iinclude
-OBJ := $(CSRC)/build/pmx_compile.o $(CSRC)/build/pmx_api.o $(CSRC)/build/pmx_kernels.o $(CSRC)/build/pmx_jit.o $(CSRC)/build/pmx_alloc.o
+OBJ := $(CSRC)/build/pmx_compile.o $(CSRC)/build/pmx_api.o $(CSRC)/build/pmx_kernels.o $(CSRC)/build/pmx_jit.o $(CSRC)/build/pmx_alloc.o $(CSRC)/build/pmx_shard.o
 DEVHDR := $(CSRC)/pmx_devtypes.hpp $(CSRC)/pmx_device.hpp $(CSRC)/pmx_ode.hpp $(CSRC)/pmx_structures.hpp $(CSRC)/pmx_userlag.hpp $(CSRC)/pmx_analytical.hpp $(CSRC)/pmx_ode_user.hpp include/pmx.h
 
 all: $(LIB) oracle
@@ -33,12 +33,16 @@ $(CSRC)/build/pmx_alloc.o: $(CSRC)/pmx_alloc.cpp include/pmx.h
 	@mkdir -p $(CSRC)/build
 	$(HIPCC) $(DEVFLAGS) -x hip -c $< -o $@
 
+$(CSRC)/build/pmx_shard.o: $(CSRC)/pmx_shard.cpp include/pmx.h
+	@mkdir -p $(CSRC)/build
+	$(HIPCC) $(DEVFLAGS) -x hip -c $< -o $@
+
 $(CSRC)/build/pmx_jit.o: $(CSRC)/pmx_jit.cpp $(CSRC)/pmx_jit.hpp $(CSRC)/build/pmx_jit_headers.inc
 	$(HIPCC) $(DEVFLAGS) -I$(CSRC)/build -x hip -c $< -o $@
 
 $(LIB): $(OBJ)
 	@mkdir -p pharmsol_amd/lib
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJ) -L/opt/rocm/lib -lhiprtc
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJ) -L/opt/rocm/lib -lhiprtc -ldl
 
 oracle:
 	$(MAKE) -C oracle

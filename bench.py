@@ -9,10 +9,11 @@ points, 8 events per subject (8e8 subject-event-steps per pass).
 N>1: one process per GPU.  `python bench.py --gpus N` launches itself under torch.distributed.run when
 it was not started by it (the parent touches no GPU and exits with the children's code).  Subjects are
 sharded across ranks, theta is replicated; there is no data-path collective (the reference's loop nest,
-likelihood/matrix.rs:79-98, has no exchange step).  `--scaling weak` (default): every rank holds its own
-100k-subject shard of an N x 100k population; `--scaling strong`: ONE 100k x 1000 population (BASELINE
-configs[2]) split N ways.  `--gather` additionally times the optional RCCL all-gather of the prediction
-blocks (outside `value`).
+likelihood/matrix.rs:79-98, has no exchange step).  `--scaling weak` (default): every rank DRAWS its own
+100k-subject shard of an N x 100k population (no rank ever builds the global one); `--scaling strong`: ONE
+100k x 1000 population (BASELINE configs[2]) split N ways by pmx_shard_bounds.  `--gather` additionally times
+passes that end in the optional in-place RCCL all-gather of the prediction blocks (pmx_allgather_predictions over
+the library's own communicator; reported beside `value` as `gather.value_with_gather`, never as `value`).
 
 Contract: W untimed warm-up passes, then exactly K timed passes bracketed by barrier +
 torch.cuda.synchronize() on both sides; MAX over ranks; rank 0 prints ONE JSON line.
@@ -118,7 +119,7 @@ def main():
     import torch.distributed as dist
 
     from pharmsol_amd import synth
-    from pharmsol_amd.distributed import ShardedPopulation
+    from pharmsol_amd.distributed import shard_bounds
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -166,7 +167,7 @@ def main():
         S_global = S_arg if strong else S_arg * world
         model = synth.model_two_cpt_iv()
         theta = synth.theta_c3(P) if args.workload == "c3" else synth.theta_c2()
-        flat_global = synth.population_c23(S_global, ragged=args.ragged)
+        gen = lambda n, shard: synth.population_c23(n, ragged=args.ragged, shard=shard)
         label = f"C{'3' if args.workload == 'c3' else '2'}: two_compartments analytical, %s x {P} support points, 8 events/subject"
         counters_key = "c3_ragged" if args.ragged else args.workload
         if args.ragged:
@@ -179,7 +180,9 @@ def main():
     elif args.workload == "c4":
         S_arg = 50_000 if args.subjects == 100_000 else args.subjects
         S_global = S_arg if strong else S_arg * world
-        model, flat_global, theta_all = synth.config_c4(S_global)
+        model = synth.model_one_cmt_iv_ode()
+        theta_all = None
+        gen = lambda n, shard: synth.config_c4(n, shard=shard)[1:]  # (population, one theta row per subject)
         batch, P = True, 1
         bound, counters_key = "fp64_valu", "c4"
         label = "C4: ode one_cmt_iv RK4 h<=0.02, %s, irregular schedules, one theta per subject (ODE parity is against the RK4 oracle and closed forms: the reference's diffsol BDF is unpinnable here)"
@@ -190,7 +193,7 @@ def main():
         P = 256 if args.support == 1000 else args.support
         model = synth.model_user_covariates()
         theta = synth.theta_user(P)
-        flat_global = synth.population_user(S_global)
+        gen = lambda n, shard: synth.population_user(n, shard=shard)
         bound, counters_key = "fp64_valu", "user"
         label = f"user closures: one_compartment_with_absorption, lag / fa / init / volume as functions of (theta, t, wt, renal), %s x {P} support points"
         dtype_tol = 1e-6
@@ -200,16 +203,25 @@ def main():
         P = 512 if args.support == 1000 else args.support
         model = synth.model_three_cpt_abs_wt()
         theta = synth.theta_c5(P)
-        flat_global = synth.population_c5(S_global, constant_wt=args.constant_cov)
+        gen = lambda n, shard: synth.population_c5(n, constant_wt=args.constant_cov, shard=shard)
         bound, counters_key = "fp64_valu", "c5"
         label = f"C5: three_compartments_with_absorption + {'subject-constant' if args.constant_cov else 'time-varying'} wt covariate, %s x {P} support points"
         dtype_tol = 1e-6
     label = label % (f"{S_global} subjects split over {world} GPU(s)" if strong else f"{S_arg} subjects/GPU")
-    sh = ShardedPopulation(flat_global, rank, world)
-    flat = sh.local
-    if batch:
-        s0, s1 = sh.bounds[rank]
-        theta = theta_all[s0:s1]
+    # This rank's subjects.  weak: its OWN draw of S_arg subjects (shard `rank` of the N x S_arg population; nobody builds
+    # the global one).  strong: ONE population of S_arg subjects (a single GPU's normal load, cheap to build on every
+    # rank), cut by the library's events-balanced rule (pmx_shard_bounds) - the rank keeps its slice only.
+    if strong and world > 1:
+        g = gen(S_arg, 0)
+        flat_global, theta_all = g if batch else (g, None)
+        s0, s1 = shard_bounds(flat_global, world)[rank]
+        flat = flat_global.subject_slice(s0, s1)
+        if batch:
+            theta = theta_all[s0:s1]
+        del flat_global, g
+    else:
+        g = gen(S_arg, rank)
+        flat, theta = g if batch else (g, theta)
     k = theta.shape[1]
     steps_per_pass_local = flat.n_events * (1 if batch else P)
 
@@ -226,7 +238,6 @@ def main():
         n_obs = flat.n_observations
     else:
         from pharmsol_amd import runtime
-        from pharmsol_amd.distributed import all_gather_predictions
 
         if args.loglik:
             assert not batch, "--loglik is defined for the matrix shape (subjects x support points)"
@@ -249,7 +260,22 @@ def main():
         n_obs = pop.n_observations
         out_shape = (n_obs,) if batch else ((pop.n_subjects, P) if args.loglik else (n_obs, P))
         ld = max(args.ld, P) if (args.ld and not batch and not args.loglik) else None
-        want_placement = not batch and not args.loglik and args.place_gib > 0 and ld is None and n_obs * P * 8 > (1 << 28)
+        # (N > 1: no placement search - eight ranks each timing 100 GiB of arena windows would say more about the search
+        # than about the path; every rank writes into a plain allocation, what a caller's own buffer gets)
+        want_placement = (world == 1 and not batch and not args.loglik and args.place_gib > 0 and ld is None and
+                          n_obs * P * 8 > (1 << 28))
+        want_gather = world > 1 and args.gather and not batch and not args.loglik
+        full = comm = rows_all = None
+        if want_gather:
+            # every rank's row count -> the row blocks of the full tensor; this rank's kernel writes straight into its block
+            from pharmsol_amd.distributed import Communicator
+
+            cnt = torch.tensor([n_obs], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+            allc = [torch.zeros_like(cnt) for _ in range(world)]
+            dist.all_gather(allc, cnt)
+            starts_ = np.concatenate([[0], np.cumsum([int(c.item()) for c in allc])]).astype(np.int64)
+            rows_all = [(int(starts_[r]), int(starts_[r + 1])) for r in range(world)]
+            comm = Communicator(device_index)
         em_c = em.to_c(model) if em is not None else None
         status = None if args.no_status else torch.zeros((pop.n_subjects,) if batch else (pop.n_subjects, P),
                                                          dtype=torch.uint8, device=dev)
@@ -329,6 +355,10 @@ def main():
                 placed = "best of %d candidate allocations (%s)" % (len(alloc_log), type(e).__name__)
             del plain
             torch.cuda.empty_cache()
+        elif want_gather:
+            full = torch.empty((rows_all[-1][1], P), dtype=torch.float64, device=dev)
+            pred = full[rows_all[rank][0]:rows_all[rank][1]]
+            placed = "this rank's row block of the full [%d x %d] tensor" % (rows_all[-1][1], P)
         else:
             pred = torch.empty(out_shape, dtype=torch.float64, device=dev)
         spin_up()
@@ -375,19 +405,36 @@ def main():
 
     # ---------------------------------------------------------------- optional all-gather (outside `value`)
     gather = None
-    if world > 1 and args.gather and not batch and not dry:
+    if not dry and world > 1 and args.gather and full is not None:
         try:
+            from pharmsol_amd.distributed import all_gather_predictions
+
+            class _Rows:  # what all_gather_predictions reads of a ShardedPopulation
+                rows, n_observations_total = rows_all, rows_all[-1][1]
+
+            def gather_pass():
+                one_pass()
+                all_gather_predictions(full, _Rows, comm=comm)
+
+            for _ in range(max(1, args.warmup)):
+                gather_pass()
             torch.cuda.synchronize()
             barrier()
             g0 = time.perf_counter()
-            full = all_gather_predictions(pred, sh)
-            torch.cuda.synchronize()
+            for _ in range(args.steps):
+                gather_pass()
             barrier()
-            gms = (time.perf_counter() - g0) * 1e3
-            gather = {"ms": gms, "GB_per_rank_out": full.numel() * 8 / 1e9, "backend": backend}
-            del full
+            torch.cuda.synchronize()
+            t_g = torch.tensor([time.perf_counter() - g0], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t_g, op=dist.ReduceOp.MAX)
+            gsec = float(t_g.item())
+            gather = {"ms_per_step_with_gather": gsec / args.steps * 1e3,
+                      "value_with_gather": steps_per_pass * args.steps / gsec,
+                      "GB_received_per_rank": (full.numel() - pred.numel()) * 8 / 1e9,
+                      "collective": "pmx_allgather_predictions: in-place ncclAllGather (equal blocks) / grouped ncclBroadcast (unequal)",
+                      "rccl_ranks": world}
         except Exception as e:  # never let the optional leg kill the measured line
-            gather = {"error": repr(e)[:200]}
+            gather = {"error": repr(e)[:300]}
 
     # ---------------------------------------------------------------- parity sample + CPU baseline (rank 0)
     cpu_baseline = None

@@ -257,6 +257,45 @@ int32_t pmx_device_count(void);
 int32_t pmx_population_create(const pmx_population_desc* desc, int32_t device, pmx_population** out);
 void pmx_population_destroy(pmx_population* pop);
 
+/* ---- sharding across GPUs ------------------------------------------------------------------------
+ * The reference's population loop (likelihood/matrix.rs:79-98: rayon over subjects, serial over support points) has no
+ * cross-iteration state: the path shards by SUBJECT, theta replicated, with no data-path collective.  One process (or
+ * host thread) per GPU:
+ *
+ *   pmx_shard_bounds(desc, n, bounds);                         // the same answer on every rank
+ *   pmx_population_create_shard(desc, bounds[r], bounds[r + 1], device_r, &pop_r);
+ *   pmx_predict_device / pmx_loglik_device(model, pop_r, ...)  // rank r's rows: [rows[r], rows[r + 1]) of the full matrix
+ *
+ * bounds[n_shards + 1]: contiguous subject ranges holding equal shares of the EVENTS (= subject-event-steps per
+ * support point), so ragged populations balance by work, not by head count. */
+int32_t pmx_shard_bounds(const pmx_population_desc* desc, int32_t n_shards, int64_t* bounds);
+/* rows[n_shards + 1]: first prediction row of every shard (rows[n_shards] = all observations). */
+int32_t pmx_shard_rows(const pmx_population_desc* desc, int32_t n_shards, const int64_t* bounds, int64_t* rows);
+/* pmx_population_create over subjects [subject_begin, subject_end) of `desc`, without the caller re-basing its arrays. */
+int32_t pmx_population_create_shard(const pmx_population_desc* desc, int64_t subject_begin, int64_t subject_end,
+                                    int32_t device, pmx_population** out);
+
+/* The one optional exchange: every rank's prediction rows on every device (a caller that post-processes the whole
+ * matrix on each GPU; NPAG-style callers consume rows where they were produced and never need it).  RCCL over xGMI,
+ * one communicator rank per GPU:
+ *
+ *   rank 0: pmx_comm_unique_id(id) -> the caller ships the 128 bytes to the other ranks (MPI, a socket, torch.distributed ...)
+ *   every rank: pmx_comm_create(id, n_ranks, rank, device, &comm)          // collective: ncclCommInitRank
+ *   every rank: d_full = [rows[n_ranks] x ld] doubles; pmx_predict_device(..., d_full + rows[rank] * ld, ld, ...)
+ *   every rank: pmx_allgather_predictions(comm, d_full, rows, ld, stream)  // in place, stream-ordered, not synchronised
+ *
+ * Equal row blocks travel as ONE in-place ncclAllGather; unequal ones (events-balanced shards) as one grouped set of
+ * in-place broadcasts, one per owner - no padding, no staging copy.  librccl.so is opened on first use
+ * (PMX_ERR_NO_DEVICE when it cannot be). */
+#define PMX_COMM_ID_BYTES 128
+typedef struct pmx_comm pmx_comm; /* opaque */
+int32_t pmx_comm_unique_id(uint8_t* id /* [PMX_COMM_ID_BYTES] */);
+int32_t pmx_comm_create(const uint8_t* id, int32_t n_ranks, int32_t rank, int32_t device, pmx_comm** out);
+void pmx_comm_destroy(pmx_comm* comm);
+int32_t pmx_comm_size(const pmx_comm* comm);
+int32_t pmx_comm_rank(const pmx_comm* comm);
+int32_t pmx_allgather_predictions(pmx_comm* comm, double* d_full, const int64_t* rows, int64_t ld, void* stream);
+
 /* Sizes a caller needs to allocate outputs. */
 int64_t pmx_population_n_subjects(const pmx_population* pop);
 int64_t pmx_population_n_observations(const pmx_population* pop); /* rows of pred */

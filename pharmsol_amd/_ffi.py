@@ -25,6 +25,15 @@ SYMBOLS = [
     ("pmx_sizeof_struct", C.c_int64, [C.c_char_p]),
     ("pmx_device_count", C.c_int32, []),
     ("pmx_population_create", C.c_int32, [_PD, C.c_int32, C.POINTER(C.c_void_p)]),
+    ("pmx_population_create_shard", C.c_int32, [_PD, C.c_int64, C.c_int64, C.c_int32, C.POINTER(C.c_void_p)]),
+    ("pmx_shard_bounds", C.c_int32, [_PD, C.c_int32, C.c_void_p]),
+    ("pmx_shard_rows", C.c_int32, [_PD, C.c_int32, C.c_void_p, C.c_void_p]),
+    ("pmx_comm_unique_id", C.c_int32, [C.c_void_p]),
+    ("pmx_comm_create", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    ("pmx_comm_destroy", None, [C.c_void_p]),
+    ("pmx_comm_size", C.c_int32, [C.c_void_p]),
+    ("pmx_comm_rank", C.c_int32, [C.c_void_p]),
+    ("pmx_allgather_predictions", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     ("pmx_population_destroy", None, [C.c_void_p]),
     ("pmx_population_n_subjects", C.c_int64, [C.c_void_p]),
     ("pmx_population_n_observations", C.c_int64, [C.c_void_p]),

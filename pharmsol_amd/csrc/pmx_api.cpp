@@ -170,6 +170,11 @@ int ode_nparams(int model) {
 
 }  // namespace
 
+namespace pmx {
+// the calling thread's error text, for the other translation units of the C ABI (pmx_shard.cpp)
+int32_t set_error(int32_t code, const std::string& msg) { return fail(code, msg); }
+}  // namespace pmx
+
 // What the HOST-pointer entry points (pmx_predict, pmx_predict_batch, pmx_loglik, pmx_loglik_batch) keep between
 // calls, per population: device buffers for theta / output / status (grown, never shrunk), a private stream pair and
 // two pinned bounce buffers.  An NPAG loop calls these entry points thousands of times; allocating, page-locking and
@@ -289,6 +294,50 @@ int32_t pmx_population_create(const pmx_population_desc* desc, int32_t device, p
   if (rc != PMX_OK) return fail(rc, err);
   *out = pop.release();
   return PMX_OK;
+}
+
+int32_t pmx_population_create_shard(const pmx_population_desc* desc, int64_t subject_begin, int64_t subject_end,
+                                    int32_t device, pmx_population** out) {
+  g_err.clear();
+  if (!out) return fail(PMX_ERR_INVALID_ARGUMENT, "out is null");
+  *out = nullptr;
+  if (!desc || !desc->subj_occ_off || !desc->occ_ev_off) return fail(PMX_ERR_INVALID_ARGUMENT, "null population descriptor");
+  if (subject_begin < 0 || subject_end < subject_begin || subject_end > desc->n_subjects)
+    return fail(PMX_ERR_INVALID_ARGUMENT, "subject range out of bounds");
+  // the descriptor of subjects [begin, end): the caller's arrays addressed in place, the three CSR offset arrays re-based
+  const int64_t s0 = subject_begin, s1 = subject_end;
+  const int64_t o0 = desc->subj_occ_off[s0], o1 = desc->subj_occ_off[s1];
+  const int64_t e0 = desc->occ_ev_off[o0], e1 = desc->occ_ev_off[o1];
+  std::vector<int64_t> subj_occ(static_cast<size_t>(s1 - s0) + 1), occ_ev(static_cast<size_t>(o1 - o0) + 1), knot_off;
+  for (int64_t s = s0; s <= s1; ++s) subj_occ[static_cast<size_t>(s - s0)] = desc->subj_occ_off[s] - o0;
+  for (int64_t o = o0; o <= o1; ++o) occ_ev[static_cast<size_t>(o - o0)] = desc->occ_ev_off[o] - e0;
+  pmx_population_desc d = *desc;
+  d.n_subjects = s1 - s0;
+  d.n_occasions = o1 - o0;
+  d.n_events = e1 - e0;
+  d.subj_occ_off = subj_occ.data();
+  d.occ_ev_off = occ_ev.data();
+  if (desc->occ_index) d.occ_index = desc->occ_index + o0;
+  if (desc->ev_time) d.ev_time = desc->ev_time + e0;
+  if (desc->ev_value) d.ev_value = desc->ev_value + e0;
+  if (desc->ev_duration) d.ev_duration = desc->ev_duration + e0;
+  if (desc->ev_kind) d.ev_kind = desc->ev_kind + e0;
+  if (desc->ev_io) d.ev_io = desc->ev_io + e0;
+  if (desc->ev_errorpoly) d.ev_errorpoly = desc->ev_errorpoly + 4 * e0;
+  if (desc->ev_censor) d.ev_censor = desc->ev_censor + e0;
+  const int32_t nc = desc->n_covariates;
+  if (nc > 0) {
+    if (!desc->cov_knot_off || !desc->cov_knot_time || !desc->cov_knot_value)
+      return fail(PMX_ERR_INVALID_ARGUMENT, "covariate arrays missing");
+    const int64_t c0 = o0 * nc, c1 = o1 * nc, k0 = desc->cov_knot_off[c0];
+    knot_off.resize(static_cast<size_t>(c1 - c0) + 1);
+    for (int64_t c = c0; c <= c1; ++c) knot_off[static_cast<size_t>(c - c0)] = desc->cov_knot_off[c] - k0;
+    d.cov_knot_off = knot_off.data();
+    d.cov_knot_time = desc->cov_knot_time + k0;
+    d.cov_knot_value = desc->cov_knot_value + k0;
+    if (desc->cov_fixed) d.cov_fixed = desc->cov_fixed + c0;
+  }
+  return pmx_population_create(&d, device, out);
 }
 
 void pmx_population_destroy(pmx_population* pop) {

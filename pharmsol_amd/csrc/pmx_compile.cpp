@@ -273,16 +273,22 @@ int32_t compile_ops(const HostPopulation& hp, const CompileKey& key, OpStream* o
         // walked exactly like before.  ev_keep = indices of the remaining events, still sorted.
         for (auto& v : lagb) v.clear();
         double t_first = std::numeric_limits<double>::infinity();
+        uint32_t k_first = 3u;  // kind of the first remaining event (PMX_EV_*; 3 = none)
         for (int64_t e = e0; e < e1; ++e) {
           const bool lagged = hp.ev_kind[e] == PMX_EV_BOLUS && hp.ev_io[e] < PMX_MAX_INPUTS && slot_of_input[hp.ev_io[e]] >= 0;
           if (lagged) {
             max_input_used = std::max<int32_t>(max_input_used, hp.ev_io[e]);
             lagb[slot_of_input[hp.ev_io[e]]].push_back({hp.ev_time[e], hp.ev_value[e], static_cast<int32_t>(hp.ev_io[e])});
-          } else if (t_first == std::numeric_limits<double>::infinity()) {
+          } else if (k_first == 3u) {
             t_first = hp.ev_time[e];
+            k_first = hp.ev_kind[e];
           }
         }
         os->op_t0[reset_op] = t_first;
+        // ODE: which event is FIRST in the re-sorted list decides what is applied at the solver clock without integration
+        // (pmx_ode.hpp "the solver clock"); at equal times a bolus sorts behind an observation and in front of an infusion
+        // (event.rs:292-304).  Bits 25-26 of the RESET op = kind of the first remaining event.
+        os->op_meta[reset_op] |= k_first << 25;
         for (int32_t k = 0; k < n_slots; ++k) {
           for (const auto& tb : lagb[k]) {
             os->lagb_time.push_back(tb.first);

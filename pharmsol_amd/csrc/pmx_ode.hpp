@@ -287,6 +287,16 @@ __device__ __forceinline__ void ode_piece(const DevModel& m, const OdeLane<M>& L
   for (int32_t k = 0; k < n; ++k) rk4_step<M>(L, x, rs, t0 + static_cast<double>(k) * h, h);
 }
 
+// A lagged bolus of slot `which` lands exactly on the time of the occasion's first remaining event (kind k_first): is it
+// in front of that event in the re-sorted list?  Observation < Bolus < Infusion at equal times, and the sort is stable
+// (event.rs:292-304, structs.rs:669-671): against another bolus it keeps its recorded place - earlier iff its lag is > 0.
+__device__ __forceinline__ bool lag_lands_first(const LagState& ls, int which, uint32_t k_first) {
+  double lg = 0.0;
+#pragma unroll
+  for (int k = 0; k < kMaxLagSlots; ++k) lg = (k == which) ? ls.lag[k] : lg;
+  return k_first == PMX_EV_INFUSION || (k_first == PMX_EV_BOLUS && lg > 0.0);
+}
+
 // lag_open_occasion / lag_prop of the ODE back-end: same merge rule, RK4 pieces instead of closed forms.
 //
 // The solver clock (ode/mod.rs:348,719-721): the reference's solver starts at the occasion's RECORDED initial time
@@ -297,7 +307,7 @@ __device__ __forceinline__ void ode_piece(const DevModel& m, const OdeLane<M>& L
 // occasion), so those pieces run with zero rates.  Returns the clock on arrival at the first remaining event.
 template <class M, bool ADAPT>
 __device__ __forceinline__ double ode_lag_open_occasion(const DevModel& m, const DevOps& ops, LagState& ls, int64_t occ,
-                                                        double t_first, double t_rec, const OdeLane<M>& L,
+                                                        double t_first, uint32_t k_first, double t_rec, const OdeLane<M>& L,
                                                         const double* __restrict__ th, double (&x)[M::NS], AdaptState& as) {
   constexpr int NS = M::NS;
 #pragma unroll
@@ -324,6 +334,14 @@ __device__ __forceinline__ double ode_lag_open_occasion(const DevModel& m, const
     }
     first = false;
     lag_apply_bolus<NS>(m, ops, ls, which, th, x);
+  }
+  if (first) {  // a bolus landing exactly ON the first remaining event's time may still be the first event of the list
+    int which;
+    const double tau = lag_next(m, ops, ls, which);
+    if (tau == t_first && lag_lands_first(ls, which, k_first)) {
+      first = false;
+      lag_apply_bolus<NS>(m, ops, ls, which, th, x);
+    }
   }
   if (!first && t_first > clk && t_first < __longlong_as_double(0x7ff0000000000000LL)) {
     ode_piece<M, ADAPT>(m, L, x, zero, clk, t_first, as);
@@ -442,7 +460,7 @@ __device__ __forceinline__ void ode_grid_body(const DevModel& m, const DevOps& o
         ode_reset<M>(L, io, x);
         if constexpr (LAG)
           clk = ode_lag_open_occasion<M, ADAPT>(m, ops, ls, static_cast<int64_t>(a), uniformf64(ops.op_t0[o]),
-                                                uniformf64(ops.op_b[o]), L, th, x, as);
+                                                (meta >> 25) & 3u, uniformf64(ops.op_b[o]), L, th, x, as);
       }
     }
     if constexpr (LL) {
@@ -681,7 +699,7 @@ __device__ __forceinline__ void ode_pair_body(const DevModel& m, const DevOps& o
             int which;
             const double tau = lag_next(m, ops, ls, which);
             const double t_first = op_t0;
-            if (tau < t_first && t_first < inf) {
+            if ((tau < t_first || (tau == t_first && lag_lands_first(ls, which, (meta >> 25) & 3u))) && t_first < inf) {
               lag_apply_bolus<NS>(m, ops, ls, which, th, x);
   #pragma unroll
               for (int j = 0; j < M::NR; ++j) rs[j] = 0.0;

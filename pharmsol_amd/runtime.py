@@ -43,13 +43,18 @@ class DeviceModel:
 
 
 class DevicePopulation:
-    def __init__(self, flat: FlatPopulation, device: int = 0):
+    def __init__(self, flat: FlatPopulation, device: int = 0, subjects: Optional[Tuple[int, int]] = None):
+        """``subjects=(s0, s1)``: only that subject range of ``flat`` (``pmx_population_create_shard``: one rank's shard
+        of a population every rank holds on the host, no re-based copy)."""
         L = _ffi.lib()
         self.flat = flat
         self.device = int(device)
         d = flat.desc()
         h = C.c_void_p()
-        _ffi.check(L.pmx_population_create(C.byref(d), self.device, C.byref(h)))
+        if subjects is None:
+            _ffi.check(L.pmx_population_create(C.byref(d), self.device, C.byref(h)))
+        else:
+            _ffi.check(L.pmx_population_create_shard(C.byref(d), int(subjects[0]), int(subjects[1]), self.device, C.byref(h)))
         self.handle = h
         self.n_subjects = int(L.pmx_population_n_subjects(h))
         self.n_observations = int(L.pmx_population_n_observations(h))

@@ -46,6 +46,12 @@ class SplitMix64:
         return np.exp(np.log(lo) + self.uniform(n) * (np.log(hi) - np.log(lo)))
 
 
+def _shard_seed(seed: int, shard: int) -> int:
+    """Seed of shard `shard` of a weak-scaling run (bench.py --gpus N: every rank draws its OWN subjects; shard 0 is the
+    single-GPU population)."""
+    return (seed ^ (shard * 0xD1B54A32D192ED03)) & _M64
+
+
 # ---------------------------------------------------------------------------- models
 def model_two_cpt_iv():
     """`two_compartments`, out = x[central]/v, theta = [ke, kcp, kpc, v] (examples/analytical_vs_ode.rs:180-197)."""
@@ -116,10 +122,10 @@ def theta_user(n_support: int = 256) -> np.ndarray:
     return np.exp(np.log(lo) + u * (np.log(hi) - np.log(lo)))
 
 
-def population_user(n_subjects: int) -> FlatPopulation:
+def population_user(n_subjects: int, shard: int = 0) -> FlatPopulation:
     """The fixture's subject (tests/analytical_macro_lowering.rs:35-51: oral bolus at 1 h, 2 h infusion from 6 h, seven
     observations, wt and renal as two-knot lines) varied per subject: doses, recorded sampling times, covariate values."""
-    rng = SplitMix64(SEED ^ 0x0B5E)
+    rng = SplitMix64(_shard_seed(SEED ^ 0x0B5E, shard))
     S, E = n_subjects, 9
     obs_t = np.array([0.25, 0.75, 1.5, 3.0, 6.5, 7.0, 8.0])
     scale = 0.5 + rng.uniform(S)
@@ -149,16 +155,16 @@ def population_user(n_subjects: int) -> FlatPopulation:
 _C23_OBS_T = np.array([0.5, 1.0, 2.0, 4.0, 8.0, 12.0, 24.0])
 
 
-def population_c23(n_subjects: int, ragged: bool = False) -> FlatPopulation:
+def population_c23(n_subjects: int, ragged: bool = False, shard: int = 0) -> FlatPopulation:
     """C2/C3 schedule: infusion(t=0, amt=500*(1+0.001*(s mod 1000)), dur=0.5) + 7 missing observations.
     ``ragged``: every subject's sampling times are jittered by up to +-10 % (a clinical dataset with recorded
     times instead of protocol times): no two subjects share a design, no step is a multiple of another."""
     S = n_subjects
     E = 8
-    s = np.arange(S)
+    s = np.arange(S) + shard * S  # (shard r of a weak-scaling run = subjects [r S, (r + 1) S) of the N x S population)
     t = np.tile(np.concatenate([[0.0], _C23_OBS_T]), S)
     if ragged:
-        jit = 1.0 + 0.2 * (SplitMix64(SEED ^ 0x7A66).uniform(S * E) - 0.5)
+        jit = 1.0 + 0.2 * (SplitMix64(_shard_seed(SEED ^ 0x7A66, shard)).uniform(S * E) - 0.5)
         jit[0::E] = 1.0
         t = t * jit
     v = np.full(S * E, np.nan)
@@ -193,9 +199,9 @@ def config_c3(n_subjects: int = 100_000, n_support: int = 1000):
     return model_two_cpt_iv(), population_c23(n_subjects), theta_c3(n_support)
 
 
-def config_c4(n_subjects: int = 50_000, h_max: float = 0.02) -> Tuple[object, FlatPopulation, np.ndarray]:
+def config_c4(n_subjects: int = 50_000, h_max: float = 0.02, shard: int = 0) -> Tuple[object, FlatPopulation, np.ndarray]:
     """`ode!` one_cmt_iv, per-subject theta (batch shape), E_s ~ U{6..40}: 1-6 infusions + observations."""
-    rng = SplitMix64()
+    rng = SplitMix64(_shard_seed(SEED, shard))
     S = n_subjects
     n_ev = 6 + (rng.next_u64(S) % np.uint64(35)).astype(np.int64)  # 6..40
     n_inf = 1 + (rng.next_u64(S) % np.uint64(6)).astype(np.int64)  # 1..6
@@ -248,10 +254,10 @@ def theta_c5(n_support: int = 512, rng: SplitMix64 = None) -> np.ndarray:
     return np.asarray(out[:n_support])
 
 
-def population_c5(n_subjects: int, rng: SplitMix64 = None, constant_wt: bool = False) -> FlatPopulation:
+def population_c5(n_subjects: int, rng: SplitMix64 = None, constant_wt: bool = False, shard: int = 0) -> FlatPopulation:
     """oral bolus(0, 100..500) q24h x3 + 10 observations; `wt`: 2-4 linear knots per subject in [50,110] kg
     (``constant_wt``: one knot, i.e. a subject-constant covariate, the usual allometric-scaling case)."""
-    rng = rng or SplitMix64(SEED ^ 0x5C)
+    rng = rng or SplitMix64(_shard_seed(SEED ^ 0x5C, shard))
     S = n_subjects
     E = 13
     obs_t = np.array([1.0, 2.0, 4.0, 8.0, 12.0, 23.5, 26.0, 36.0, 50.0, 72.0])

@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 
 import oracle
 from pharmsol_amd import Data, synth
-from pharmsol_amd.distributed import ShardedPopulation, all_gather_predictions, shard_bounds
+from pharmsol_amd.distributed import ShardedPopulation, all_gather_predictions, full_prediction_tensor, shard_bounds, shard_rows
 from tests import models
 
 
@@ -39,7 +39,13 @@ def _worker(rank, world, port, q):
         local, _ = oracle.predict(m, sh.local, theta, nthreads=1)
         r0, r1 = sh.local_rows
         assert local.shape == (r1 - r0, theta.shape[0])
-        full = all_gather_predictions(torch.from_numpy(local), sh).numpy()
+        # the rank's rows go straight into its block of the full tensor; the blocks (of unequal size here) are exchanged
+        # in place: no padding, no concatenation
+        full_t, mine = full_prediction_tensor(sh, theta.shape[0])
+        full_t.fill_(float("nan"))
+        mine.copy_(torch.from_numpy(local))
+        full = all_gather_predictions(full_t, sh).numpy()
+        assert full_t.data_ptr() == torch.from_numpy(full).data_ptr()
         # whole-job step count: sum over ranks (what bench.py reports as `value` numerator)
         steps = torch.tensor([sh.local_steps_per_support], dtype=torch.int64)
         dist.all_reduce(steps)
@@ -64,6 +70,57 @@ def test_two_rank_gloo_shard_and_gather():
     for rank, full, steps in results:
         np.testing.assert_array_equal(full, want)  # every rank holds the full tensor, rows in subject order
         assert steps == flat.n_events
+
+
+def test_c_abi_shard_bounds_follow_the_events_balanced_rule():
+    """pmx_shard_bounds / pmx_shard_rows against a numpy restatement of the rule: rank r starts at the first subject whose
+    predecessors hold at least r/n of all events (a searchsorted on the running event count)."""
+    rng = np.random.default_rng(3)
+    for flat in (_ragged_population()[1], synth.config_c4(777)[1], synth.population_c5(100), synth.population_c23(5)):
+        ev = flat.events_per_subject().astype(np.float64)
+        csum = np.concatenate([[0.0], np.cumsum(ev)])
+        off = flat.observation_offsets()
+        for world in (1, 2, 3, 5, 8, 16):
+            cuts = [0]
+            for r in range(1, world):
+                cuts.append(min(max(int(np.searchsorted(csum, csum[-1] * r / world, side="left")), cuts[-1]), flat.n_subjects))
+            cuts.append(flat.n_subjects)
+            b = shard_bounds(flat, world)
+            assert b == [(cuts[r], cuts[r + 1]) for r in range(world)]
+            assert shard_rows(flat, b) == [(int(off[s0]), int(off[s1])) for s0, s1 in b]
+    # a population without events is split by head count; bad arguments are refused
+    import ctypes as C
+
+    from pharmsol_amd import _abi, _ffi
+    empty = synth.population_c23(0)
+    assert shard_bounds(empty, 3) == [(0, 0)] * 3
+    d = flat.desc()
+    out = np.zeros(4, dtype=np.int64)
+    assert _ffi.lib().pmx_shard_bounds(C.byref(d), 0, out.ctypes.data) == _abi.PMX_ERR_INVALID_ARGUMENT
+    bad = np.array([0, 3, 2, flat.n_subjects], dtype=np.int64)
+    assert _ffi.lib().pmx_shard_rows(C.byref(d), 3, bad.ctypes.data, out.ctypes.data) == _abi.PMX_ERR_INVALID_ARGUMENT
+
+
+def test_c_abi_collective_entry_points_fail_loudly_without_a_device():
+    """pmx_comm_* / pmx_population_create_shard on a box without a GPU: argument checks first, then PMX_ERR_NO_DEVICE - no
+    silent CPU path."""
+    import ctypes as C
+
+    from pharmsol_amd import _abi, _ffi
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    L = _ffi.lib()
+    flat = synth.population_c23(10)
+    d = flat.desc()
+    h = C.c_void_p()
+    assert L.pmx_population_create_shard(C.byref(d), 4, 2, 0, C.byref(h)) == _abi.PMX_ERR_INVALID_ARGUMENT
+    assert L.pmx_population_create_shard(C.byref(d), 0, 11, 0, C.byref(h)) == _abi.PMX_ERR_INVALID_ARGUMENT
+    assert L.pmx_population_create_shard(C.byref(d), 2, 7, 0, C.byref(h)) == _abi.PMX_ERR_NO_DEVICE
+    ident = (C.c_uint8 * 128)()
+    assert L.pmx_comm_create(ident, 2, 2, 0, C.byref(h)) == _abi.PMX_ERR_INVALID_ARGUMENT  # rank out of range
+    assert L.pmx_comm_create(ident, 2, 1, 0, C.byref(h)) == _abi.PMX_ERR_NO_DEVICE
+    rows = np.array([0, 5], dtype=np.int64)
+    assert L.pmx_allgather_predictions(None, None, rows.ctypes.data, 4, None) == _abi.PMX_ERR_INVALID_ARGUMENT
 
 
 def test_shard_bounds_cover_and_balance():
@@ -122,3 +179,63 @@ def test_bench_launches_its_own_ranks_from_the_plain_command_line(scaling):
     total_subjects = 1000 if scaling == "strong" else 2000
     assert d["config"]["steps_per_pass"] == total_subjects * 8 * 8  # all ranks' subject-event-steps per pass
     assert d["config"]["subjects_per_gpu"] == (500 if scaling == "strong" else 1000)
+
+
+# --------------------------------------------------------------------------- GPU (one device)
+@pytest.mark.gpu
+def test_shard_populations_write_the_rows_of_the_whole_population():
+    """pmx_population_create_shard for three events-balanced shards of a ragged, multi-occasion, covariate-free population
+    and of C5 (covariate knots re-based): each shard's kernel writes its row block of one full tensor; the result equals
+    the whole population's pass bit for bit."""
+    from pharmsol_amd import runtime
+
+    for m, flat, theta in (_ragged_population(), (synth.model_three_cpt_abs_wt(), synth.population_c5(300), synth.theta_c5(40))):
+        theta = np.ascontiguousarray(theta[:40] if theta.shape[0] > 40 else theta)
+        whole, _ = runtime.predict(m, runtime.DevicePopulation(flat, 0), theta)
+        n = 3
+        b = shard_bounds(flat, n)
+        rows = shard_rows(flat, b)
+        full = torch.full_like(whole, float("nan"))
+        for r in range(n):
+            pop = runtime.DevicePopulation(flat, 0, subjects=b[r])
+            assert pop.n_subjects == b[r][1] - b[r][0] and pop.n_observations == rows[r][1] - rows[r][0]
+            if pop.n_observations:
+                runtime.predict(m, pop, theta, pred=full[rows[r][0]:rows[r][1]])
+        torch.cuda.synchronize()
+        assert torch.equal(full, whole)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("force_broadcast", [False, True])
+def test_rccl_communicator_and_in_place_allgather_on_one_rank(force_broadcast, monkeypatch):
+    """The RCCL calls under the C ABI with a world of ONE rank (all a single-GPU box can host): ncclGetUniqueId,
+    ncclCommInitRank, the in-place ncclAllGather and - forced - the grouped ncclBroadcast form, stream-ordered behind the
+    kernel that wrote the block.  (Ranks > 1 first meet hardware in the driver's multi-GPU run.)"""
+    import ctypes as C
+
+    from pharmsol_amd import _ffi, runtime
+
+    if force_broadcast:
+        monkeypatch.setenv("PMX_DEBUG_ALLGATHER_BROADCAST", "1")
+    L = _ffi.lib()
+    ident = (C.c_uint8 * 128)()
+    _ffi.check(L.pmx_comm_unique_id(ident))
+    assert any(ident)
+    h = C.c_void_p()
+    _ffi.check(L.pmx_comm_create(ident, 1, 0, 0, C.byref(h)))
+    try:
+        assert L.pmx_comm_size(h) == 1 and L.pmx_comm_rank(h) == 0
+        m, flat, theta = synth.config_c3(500, 64)
+        pop = runtime.DevicePopulation(flat, 0)
+        want, _ = runtime.predict(m, pop, theta)
+        full = torch.full((pop.n_observations, 64), float("nan"), dtype=torch.float64, device="cuda:0")
+        runtime.predict(m, pop, theta, pred=full)
+        rows = np.array([0, pop.n_observations], dtype=np.int64)
+        _ffi.check(L.pmx_allgather_predictions(h, full.data_ptr(), rows.ctypes.data, 64, torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        assert torch.equal(full, want)
+        bad = np.array([1, pop.n_observations], dtype=np.int64)
+        from pharmsol_amd import _abi
+        assert L.pmx_allgather_predictions(h, full.data_ptr(), bad.ctypes.data, 64, None) == _abi.PMX_ERR_INVALID_ARGUMENT
+    finally:
+        L.pmx_comm_destroy(h)

@@ -366,9 +366,15 @@ def _assert_parity(model, flat, theta, batch=False, kernel=None, tol=1e-6):
     np.testing.assert_array_equal(st, wst)
     ok = np.isfinite(want)
     np.testing.assert_array_equal(np.isfinite(got), ok)
-    scale = np.maximum(np.abs(want[ok]), 1e-12 * np.abs(want[ok]).max() + 1e-300)
-    err = (np.abs(got[ok] - want[ok]) / scale).max()
-    assert err <= tol, f"max rel err {err:.3e}"
+    scale = np.maximum(np.abs(want), 1e-12 * np.abs(want[ok]).max() + 1e-300)
+    rel = np.where(ok, np.abs(got - want) / scale, 0.0)
+    err = rel.max()
+    if not err <= tol:
+        w = np.unravel_index(np.argmax(rel), rel.shape)
+        off = flat.observation_offsets()
+        subj = int(np.searchsorted(off, w[0], side="right") - 1)
+        raise AssertionError(f"max rel err {err:.3e} at row {w[0]} (subject {subj}, its row {w[0] - off[subj]}), column {w[1:]}: "
+                             f"got {got[w]!r} want {want[w]!r}; theta {theta[w[1] if len(w) > 1 else subj]!r}")
     return got, want
 
 
