@@ -110,6 +110,7 @@ struct DeviceStream {
   pmx::CompileKey key;
   pmx::DevOps dev{};
   pmx::DevClassPlan cls{};
+  pmx::DevSteps steps{};  // fused step programs of the lean generic walker (analytical streams without lag / covariates)
   int64_t n_classed_subjects = 0;
   // host copies for the log-likelihood's per-chunk observation blocks
   std::vector<int64_t> h_chunk_row;      // [n_chunks*G]
@@ -880,6 +881,13 @@ int32_t get_stream(pmx_population* pop, const pmx::CompileKey& key, DeviceStream
     if ((rc = upload(hp.cov_first_t, &ds->dev.cov_first_t, &ds->allocs)) != PMX_OK) return rc;
     if ((rc = upload(hp.cov_first_v, &ds->dev.cov_first_v, &ds->allocs)) != PMX_OK) return rc;
   }
+  if (key.eq_kind == PMX_EQ_ANALYTICAL && !key.user_cov && key.lag_mask == 0 && os.op_fac.empty()) {
+    std::vector<int64_t> off;
+    std::vector<double> rec;
+    pmx::build_step_stream(os, &off, &rec);
+    if ((rc = upload(off, &ds->steps.subj_step_off, &ds->allocs)) != PMX_OK) return rc;
+    if ((rc = upload(rec, &ds->steps.step_rec, &ds->allocs)) != PMX_OK) return rc;
+  }
   if (key.class_g > 0) {
     pmx::ClassPlan cp;
     const Tunables tun = tunables();  // (tuning experiments)
@@ -1121,6 +1129,14 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
   a.stream = stream;
   a.cls = ds->cls;
   a.use_classes = ds->cls.n_chunks > 0 ? 1 : 0;
+  {
+    // the lean walker serves the plain models: rate constants and volumes fixed per lane, no lag, no pm_ pad slot
+    bool plain = d.eq_kind == PMX_EQ_ANALYTICAL && !model->dyn && !model->custom && a.m.n_lag_slots == 0 && !d.pmetrics_indexing &&
+                 std::getenv("PMX_DISABLE_STEPS") == nullptr;
+    for (int o = 0; o < d.nout && o < PMX_MAX_OUT; ++o)
+      if (a.m.out[o].vol_src == PMX_SRC_DERIVED && d.derived[a.m.out[o].vol_index].n_factors > 0) plain = false;
+    if (plain) a.steps = ds->steps;
+  }
   // the stream's codes were written for key.prop_cache_slots slots; the kernel decodes them with the same number
   a.prop_slots = ds->prop_cache_used > 0 ? ds->key.prop_cache_slots : 0;
   a.dyn_tile = tunables().dyn_tile;  // (0 = the default tile; 64 and 256 measured the same with one slot)

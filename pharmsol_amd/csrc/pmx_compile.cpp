@@ -553,6 +553,49 @@ inline uint64_t mix64(uint64_t h, uint64_t v) {
 }
 }  // namespace
 
+void build_step_stream(const OpStream& os, std::vector<int64_t>* subj_step_off, std::vector<double>* rec) {
+  const int64_t S = static_cast<int64_t>(os.subj_op_off.size()) - 1;
+  subj_step_off->assign(static_cast<size_t>(S) + 1, 0);
+  rec->clear();
+  rec->reserve(static_cast<size_t>(os.n_ops) * 2 + 4);
+  auto push = [&](uint64_t meta, double a, double b) {
+    double w;
+    std::memcpy(&w, &meta, 8);
+    rec->push_back(w);
+    rec->push_back(a);
+    rec->push_back(b);
+    rec->push_back(0.0);
+  };
+  int64_t n_steps = 0;
+  for (int64_t s = 0; s < S; ++s) {
+    int64_t last = -1;  // this subject's last step, if it can still take an observation
+    for (int64_t o = os.subj_op_off[s]; o < os.subj_op_off[s + 1]; ++o) {
+      const uint32_t meta = os.op_meta[o];
+      const uint32_t kind = meta & 0xffu, io = (meta >> 8) & 0xffffu;
+      if (kind == OP_OBS) {
+        const uint64_t tag = (1ull << 24) | (static_cast<uint64_t>(io & 3u) << 25);
+        if (last >= 0) {
+          uint64_t w;
+          std::memcpy(&w, &(*rec)[static_cast<size_t>(last) * 4], 8);
+          w |= tag;
+          std::memcpy(&(*rec)[static_cast<size_t>(last) * 4], &w, 8);
+          last = -1;
+        } else {
+          push(static_cast<uint64_t>(OP_OBS) | tag, 0.0, 0.0);
+          ++n_steps;
+        }
+      } else {
+        // kind | io | the PROP's ladder rung (bits 27-29 of the op, pmx_compile.cpp ladder_code)
+        push(static_cast<uint64_t>(kind) | (static_cast<uint64_t>(io) << 8) | (static_cast<uint64_t>(meta) & (7ull << 27)), os.op_a[o],
+             os.op_b[o]);
+        last = n_steps++;
+      }
+    }
+    (*subj_step_off)[static_cast<size_t>(s) + 1] = n_steps;
+  }
+  push(static_cast<uint64_t>(OP_OBS), 0.0, 0.0);  // padding: the walker requests one record past a subject's last step
+}
+
 uint32_t ladder_code(double dt, double* prev, double* span) {
   uint32_t code = 0;
   if (*prev > 0.0 && dt > 0.0) {

@@ -172,6 +172,12 @@ uint32_t ladder_code(double dt, double* prev, double* span);
 void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, int32_t min_class_size, ClassPlan* out,
                       bool ladder = true, bool spread = false, bool loose_classes = false);
 
+// Fused per-subject step programs for the lean generic walker (pmx_kernels.hpp DevSteps): every OBS op rides on the step
+// in front of it (bit 24 + outeq in bits 25-26, like the class plan's programs); an observation with nothing in front of
+// it in its subject, or a second one at the same instant, is a step of kind OP_OBS.  rec = [n_steps + 1][4] doubles
+// {meta bits, a, b, 0} (the last record is padding).  Analytical streams without lag only.
+void build_step_stream(const OpStream& os, std::vector<int64_t>* subj_step_off, std::vector<double>* rec);
+
 // Validate + copy + sort (Occasion::sort, structs.rs:669-671) + build covariate segments.
 // Returns PMX_OK or an error with `err` filled.
 int32_t build_host_population(const pmx_population_desc* d, HostPopulation* out, std::string* err);

@@ -386,6 +386,136 @@ __global__ __launch_bounds__(kBlock, (!LAG && LaneModel<KID>::NS <= 2) ? 4 : ((!
 }
 
 // ------------------------------------------------------------------------------------
+// LEAN GRID walker (analytical, plain models): the subjects no class holds - populations without a shared program shape -
+// walked from FUSED step records (DevSteps).  Same lane mapping and arithmetic as pmx_analytical_grid<KID, false, false>;
+// what goes is everything that kernel carries for the cases it also serves (covariate factors, lag cursors, pm_ pads,
+// per-output descriptor look-ups): an observation costs no trip of its own, a step is ONE packed scalar fetch, requested
+// a step ahead (the kernel the round-2 profile showed scalar-bound: ~88 SALU + 3 dependent s_loads per event), the
+// prediction's address is a scalar row base + the lane's constant byte offset.
+// ------------------------------------------------------------------------------------
+template <int KID, bool LL>
+__global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx_analytical_steps(
+    DevModel m, DevOps ops, DevSteps sp, const double* __restrict__ theta, int64_t P, int64_t S, int32_t s_chunk,
+    int32_t n_ptiles, double* __restrict__ pred, int64_t ld, uint8_t* __restrict__ status,
+    const int32_t* __restrict__ subj_list, int32_t zero_status) {
+  using LM = LaneModel<KID>;
+  constexpr int NS = LM::NS;
+  const int64_t b = blockIdx.x;
+  const int32_t ptile = static_cast<int32_t>(b % n_ptiles);
+  const int64_t chunk = b / n_ptiles;
+  const uint32_t tile = blockDim.x;
+  const int64_t p = static_cast<int64_t>(ptile) * tile + threadIdx.x;
+  const bool lane_ok = p < P;
+  const int64_t pc = lane_ok ? p : (P - 1);  // idle lanes shadow the last support point; their stores are masked
+  const double* __restrict__ th = theta + pc * m.nparams;
+  const uint32_t poff = static_cast<uint32_t>(pc) * 8u;  // the lane's byte offset inside a prediction row
+  const double nanv = __longlong_as_double(0x7ff8000000000000LL);
+
+  LM L;
+  lane_setup<KID, false>(m, th, L);
+  const uint8_t st_lane = L.ok ? PMX_PAIR_OK : PMX_PAIR_COMPLEX_ROOTS;
+  const double inv_vol0 = L.ok ? L.inv_vol[0] : nanv;  // (a lane with complex roots: every prediction NaN)
+  const int out_state0 = m.out[0].state;
+  double ex[LM::S::NE];  // the lane's exponentials of the last PROP (ladder)
+#pragma unroll
+  for (int i = 0; i < LM::S::NE; ++i) ex[i] = 0.0;
+
+  const auto c_step_off = as_const(sp.subj_step_off);
+  const auto c_obs_off = as_const(ops.subj_obs_off);
+  const auto c_rec = as_const(reinterpret_cast<const uint64_t*>(sp.step_rec));
+
+  const int64_t s_begin = chunk * s_chunk;
+  const int64_t s_end = (s_begin + s_chunk < S) ? (s_begin + s_chunk) : S;
+  for (int64_t si = s_begin; si < s_end; ++si) {
+    const int64_t s = subj_list ? static_cast<int64_t>(as_const(subj_list)[si]) : si;
+    const int64_t o0 = c_step_off[s];
+    const int64_t o1 = c_step_off[s + 1];
+    int64_t row = c_obs_off[s];
+    char* rowp = reinterpret_cast<char*>(pred + row * ld);  // wave-uniform: stays in scalar registers
+    double x[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) x[i] = 0.0;
+    double ll_acc = 0.0, nanacc = 0.0;
+    if (zero_status == 1 && status != nullptr) {  // (see pmx_analytical_grid)
+      const uint32_t zl = threadIdx.x & 63u;
+      const int64_t zp = static_cast<int64_t>(ptile) * tile + (threadIdx.x & ~63u) + 8 * zl;
+      if (zl < 8u && zp < P) *reinterpret_cast<uint64_t*>(status + s * P + zp) = 0ull;
+    }
+    // the record of step o is requested while step o - 1 is worked on
+    auto recp = c_rec + 4 * o0;
+    uint64_t w_n = recp[0], a_n = recp[1], b_n = recp[2];
+    const int32_t n_steps = static_cast<int32_t>(o1 - o0);  // (32-bit trip count: the 64-bit compare is a vector instruction)
+    for (int32_t k = 0; k < n_steps; ++k) {
+      uint64_t w = w_n, ab = a_n, bb = b_n;
+      asm volatile("" : "+s"(w), "+s"(ab), "+s"(bb));  // (the wait for this step's record sits here, the next request behind it)
+      recp += 4;
+      w_n = recp[0];
+      a_n = recp[1];
+      b_n = recp[2];
+      const uint32_t meta = static_cast<uint32_t>(w);
+      const uint32_t kind = meta & 0xffu;
+      const int io = static_cast<int>((meta >> 8) & 0xffffu);
+      const double a = __longlong_as_double(static_cast<int64_t>(ab));
+      if (kind == OP_PROP) {
+        const double r = __longlong_as_double(static_cast<int64_t>(bb));
+        const uint32_t rung = (meta >> 27) & 7u;
+        if (rung == 0u) {
+          LM::S::exps(L.coef, a, ex);
+        } else if (rung != 1u) {
+          ladder_pow<LM::S::NE>(ex, rung);
+        }
+        step_from_exps<LM::ST>(L.coef, ex, x, r);
+      } else if (kind == OP_BOLUS) {
+        double amt = a;
+        if (m.has_fa) amt = a * fa_of(m, th, io);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) x[i] += (i == io) ? amt : 0.0;
+      } else if (kind == OP_RESET) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) x[i] = io ? L.xinit[i] : 0.0;
+      }  // (OP_OBS: an observation with no step to ride on - the first op of nothing, or a second one at the same instant)
+      if ((meta >> 24) & 1u) {
+        const int oq = static_cast<int>((meta >> 25) & 3u);
+        int out_state = out_state0;
+        double inv_vol = inv_vol0;
+        if (oq != 0) {  // outputs beyond the first: rare (see pmx_analytical_classed)
+          out_state = m.out[oq].state;
+          const int vp = m.out_vol_theta[oq];
+          double v = 1.0;
+          if (vp >= 0) v = th[vp];
+          double iv = 1.0 / v;
+          asm volatile("" : "+v"(iv));
+          inv_vol = L.ok ? iv : nanv;
+        }
+        double xs = x[0];
+#pragma unroll
+        for (int i = 1; i < NS; ++i) xs = (out_state == i) ? x[i] : xs;  // (wave-uniform condition: scalar selects)
+        const double y = xs * inv_vol;
+        if constexpr (LL) {
+          ll_accumulate(as_const(ops.ll_obs) + row * 4, y, ll_acc);
+          ++row;
+        } else {
+          nanacc = fma(y, 0.0, nanacc);  // 0 * y is NaN iff y is not finite: resolved once per subject
+          if (lane_ok) __builtin_nontemporal_store(y, reinterpret_cast<double*>(rowp + poff));
+          rowp += ld * 8;
+        }
+      }
+    }
+    uint8_t st = st_lane;
+    if constexpr (LL) {
+      if (st == PMX_PAIR_OK && !isfinite(ll_acc)) st = PMX_PAIR_NONFINITE;  // NonFiniteLikelihood (prediction.rs:119-124)
+      if (lane_ok) ops.ll_out[s * ops.ll_ld + p] = (st == PMX_PAIR_OK || st == PMX_PAIR_NONFINITE) ? ll_acc : nanv;
+    } else {
+      if (st == PMX_PAIR_OK && nanacc != nanacc) st = PMX_PAIR_NONFINITE;
+    }
+    if (status != nullptr && lane_ok && (st != PMX_PAIR_OK || zero_status == 2)) {
+      if (zero_status == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clearing store above lands first
+      status[s * P + p] = st;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // CLASSED GRID kernel (analytical): one propagator per (lane, program step), applied to a
 // register-resident batch of G subjects that share a dosing/sampling design (pmx_compile.hpp
 // ClassPlan).  Per (subject, support point) the arithmetic is the generic kernel's; what goes away
@@ -1227,6 +1357,18 @@ hipError_t launch_analytical(const LaunchArgs& a, const char** name) {
     }
     const int64_t n_chunks = (n_walk + s_chunk - 1) / s_chunk;
     const int64_t blocks = n_chunks * n_ptiles;
+    if constexpr (!DYN && !LAG) {
+      if (a.steps.step_rec != nullptr) {  // plain model: the lean walker over fused step records
+        *name = (list != nullptr) ? *name : "pmx_analytical_steps";
+        if (a.ops.ll_obs != nullptr)
+          hipLaunchKernelGGL((pmx_analytical_steps<KID, true>), dim3(static_cast<uint32_t>(blocks)), dim3(threads), 0, st, a.m, a.ops,
+                             a.steps, a.theta, a.P, n_walk, s_chunk, n_ptiles, a.pred, a.ld, a.status, list, a.cls.zero_status);
+        else
+          hipLaunchKernelGGL((pmx_analytical_steps<KID, false>), dim3(static_cast<uint32_t>(blocks)), dim3(threads), 0, st, a.m, a.ops,
+                             a.steps, a.theta, a.P, n_walk, s_chunk, n_ptiles, a.pred, a.ld, a.status, list, a.cls.zero_status);
+        return hipGetLastError();
+      }
+    }
     if (a.ops.ll_obs != nullptr)
       hipLaunchKernelGGL((pmx_analytical_grid<KID, DYN, LAG, true>), dim3(static_cast<uint32_t>(blocks)), dim3(threads), lds, st,
                          a.m, a.ops, a.theta, a.P, n_walk, s_chunk, n_ptiles, a.pred, a.ld, a.status, list, a.cls.zero_status,

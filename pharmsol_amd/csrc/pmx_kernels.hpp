@@ -41,6 +41,15 @@ struct DevClassPlan {
                         // 1 = clear with 8-byte stores, then write failures only; 2 = write every pair's byte
 };
 
+// Fused per-subject step programs for the lean generic walker (pmx_analytical_steps): what the class plan builds per
+// CLASS, built per SUBJECT - every OBS op folded into the step in front of it, one packed 32-byte record per step
+// {meta (u64 bits: kind | io << 8 | obs-after << 24 | outeq << 25 | ladder rung << 27), a, b, 0}, one record of padding
+// behind the last step (the walker requests step o + 1 while it works on step o).
+struct DevSteps {
+  const int64_t* subj_step_off;  // [S+1]
+  const double* step_rec;        // [(n_steps + 1) * 4]
+};
+
 enum LaneMode : int32_t { MODE_GRID = 0, MODE_PAIR = 1 };
 
 struct LaunchArgs {
@@ -63,6 +72,7 @@ struct LaunchArgs {
   int32_t dyn_tile;     // DYN GRID with kept propagators: support points per block (0 = the default tile)
   int32_t tune_cpb;     // > 0: chunks per block of the classed kernel forced by PMX_TUNE_CPB (tuning experiments)
   DevClassPlan cls;
+  DevSteps steps;       // analytical GRID, plain models (no covariate factors, no lag, no pm_ indexing): nullptr = none
   const int32_t* subj_list;  // GRID: walk these subjects instead of 0..S-1 (nullptr = all)
   int64_t n_list;
   void* stream;
