@@ -35,7 +35,7 @@ int32_t fail(int32_t code, const std::string& msg) {
 // std::getenv per launch is measurable on the 11 us C2 pass.  pmx_debug_reload_env() re-reads them (tuning scripts
 // and tests that flip a switch inside one process).
 struct Tunables {
-  bool disable_ladder = false, disable_classing = false;
+  bool disable_ladder = false, disable_classing = false, ll_old = false;
   int32_t steps_per_trip = 0, grid_min_p = 0, min_class = 0, cpb = 0;
   int32_t spread = -1, loose = -1;  // -1 = library default
   int32_t prop_slots = -1, dyn_tile = 0;
@@ -55,6 +55,7 @@ struct Tunables {
     };
     disable_ladder = flag("PMX_DISABLE_LADDER");
     disable_classing = flag("PMX_DISABLE_CLASSING");
+    ll_old = flag("PMX_TUNE_LL_OLD");
     steps_per_trip = num("PMX_TUNE_STEPS_PER_TRIP");
     grid_min_p = num("PMX_TUNE_GRID_MIN_P");
     min_class = num("PMX_TUNE_MIN_CLASS");
@@ -898,6 +899,17 @@ int32_t get_stream(pmx_population* pop, const pmx::CompileKey& key, DeviceStream
     if (cp.n_chunks > 0) {
       if ((rc = upload(cp.prog_meta, &ds->cls.prog_meta, &ds->allocs)) != PMX_OK) return rc;
       if ((rc = upload(cp.prog_dt, &ds->cls.prog_dt, &ds->allocs)) != PMX_OK) return rc;
+      {
+        std::vector<double> prec((cp.prog_meta.size() + 1) * 2, 0.0);
+        for (size_t i = 0; i < cp.prog_meta.size(); ++i) {
+          const uint64_t w = cp.prog_meta[i];
+          std::memcpy(&prec[2 * i], &w, 8);
+          prec[2 * i + 1] = cp.prog_dt[i];
+        }
+        if ((rc = upload(prec, &ds->cls.prog_rec, &ds->allocs)) != PMX_OK) return rc;
+        if ((rc = upload(cp.chunk_rate_mask, &ds->cls.chunk_rate_mask, &ds->allocs)) != PMX_OK) return rc;
+        if ((rc = upload(cp.cls_fast_mask, &ds->cls.cls_fast_mask, &ds->allocs)) != PMX_OK) return rc;
+      }
       if ((rc = upload(cp.prog_t0, &ds->cls.prog_t0, &ds->allocs)) != PMX_OK) return rc;
       if ((rc = upload(cp.prog_t1, &ds->cls.prog_t1, &ds->allocs)) != PMX_OK) return rc;
       if ((rc = upload(cp.cls_prog_off, &ds->cls.cls_prog_off, &ds->allocs)) != PMX_OK) return rc;
@@ -1021,6 +1033,9 @@ int32_t acquire_ll_slot(const pmx_model* model, pmx_population* pop, DeviceStrea
     a.chunk_n = ds->cls.chunk_n;
     a.chunk_nobs = ds->d_chunk_nobs;
     a.chunk_obs_off = ds->d_chunk_obs_off;
+    a.chunk_cls = ds->cls.chunk_cls;
+    a.cls_prog_off = ds->cls.cls_prog_off;
+    a.prog_meta = ds->cls.prog_meta;
     a.n_chunks = ds->cobs_size > 0 ? ds->cls.n_chunks : 0;
     a.G = ds->cls.G;
     a.cobs = slot->d_cobs;
@@ -1170,6 +1185,7 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
     grid_min_p = (a.use_classes && 2 * ds->n_classed_subjects >= a.S) ? 8 : 48;
   if (const int32_t g = tunables().grid_min_p; g > 0) grid_min_p = g;  // tuning experiments
   a.tune_cpb = tunables().cpb;
+  a.tune_ll_old = tunables().ll_old ? 1 : 0;
   if (!batch && P >= grid_min_p) {
     a.mode = pmx::MODE_GRID;
     a.n_ptiles = static_cast<int32_t>((P + 255) / 256);

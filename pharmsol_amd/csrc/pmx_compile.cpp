@@ -762,6 +762,16 @@ void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, i
       cp->prog_t1.push_back(step_t1[static_cast<size_t>(i)]);
     }
     cp->cls_prog_off.push_back(static_cast<int64_t>(cp->prog_meta.size()));
+    {
+      uint64_t fast = 0;
+      for (int64_t i = 0; i < L && i < 63; ++i) {
+        const uint32_t sm = step_meta[static_cast<size_t>(i)];
+        const bool prop = (sm & 0xffu) == OP_PROP, obs0 = ((sm >> 24) & 1u) != 0u && ((sm >> 25) & 3u) == 0u;
+        const uint32_t rung = (sm >> 27) & 7u;
+        if (prop && obs0 && rung >= 1u && rung <= 4u && (sm >> 31) == 0u) fast |= 1ull << i;
+      }
+      cp->cls_fast_mask.push_back(fast);
+    }
     // Which members share a chunk is free (any G subjects of the class may share a propagator).  `spread`: member j of
     // chunk c is the (c + j * n_chunks)-th subject of the class, so the G rows a block writes at one step are far
     // apart while neighbouring blocks write neighbouring subjects: G slowly advancing write fronts instead of every
@@ -809,6 +819,16 @@ void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, i
           cp->val[base + static_cast<size_t>(st) * G + j] = v;
           if (loose && kind == OP_PROP) cp->dtv[base + static_cast<size_t>(st) * G + j] = os.op_a[s0 + i];
         }
+      }
+      {
+        uint64_t mask = 0;
+        for (int64_t st = 0; st < L; ++st) {
+          bool any = false;
+          for (int32_t j = 0; j < n; ++j) any |= cp->val[base + static_cast<size_t>(st) * G + j] != 0.0;
+          if (any) mask |= 1ull << (st < 63 ? st : 63);
+        }
+        if (L > 63) mask |= 1ull << 63;  // (steps past the mask's width always fetch their values)
+        cp->chunk_rate_mask.push_back(mask);
       }
       cp->n_classed_subjects += n;
     }

@@ -142,12 +142,18 @@ struct ClassPlan {
   // the time of the occasion's first event that stays in the list - what a lane compares its lagged bolus times with
   std::vector<double> prog_t0, prog_t1;
   std::vector<int64_t> cls_prog_off;   // [n_classes+1]
+  std::vector<uint64_t> cls_fast_mask; // [n_classes] bit s (s < 63): step s is a PROP on the exponential ladder (rung 1..4) with
+                                       // an observation of output 0 fused into it - the steps the log-likelihood kernel runs
+                                       // as straight-line code when, in the chunk at hand, nobody infuses and every row is plain
   std::vector<int32_t> chunk_cls;      // [n_chunks]
   std::vector<int32_t> chunk_n;        // [n_chunks] live members (<= G)
   std::vector<int64_t> chunk_val_off;  // [n_chunks + 1] offset of the chunk's value block in `val` (+ the total)
   std::vector<int32_t> chunk_subj;     // [n_chunks*G] subject ids, -1 = padding
   std::vector<int64_t> chunk_row;      // [n_chunks*G] first prediction row of each member
   std::vector<double> val;             // per chunk: [program length][G]  BOLUS amount / PROP rate
+  std::vector<uint64_t> chunk_rate_mask;  // [n_chunks] bit k: step k of the chunk's program carries a non-zero value for
+                                       // some live member (an infusion running / a bolus); bit 63 also stands for every
+                                       // step from 63 on.  A clear bit = a PROP step nobody infuses in: F only, no val fetch
   // Chunks [0, n_chunks_exact) belong to classes whose members share the whole program, step lengths included: one
   // propagator per step serves all G members.  Chunks [n_chunks_exact, n_chunks) belong to LOOSE classes: same op
   // kinds, inputs and outputs in the same order, but every member has its own step lengths (recorded sampling

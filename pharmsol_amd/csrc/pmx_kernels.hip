@@ -1058,6 +1058,333 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
 }
 
 // ------------------------------------------------------------------------------------
+// CLASSED log-likelihood kernel, exact classes of plain models - the entry NPAG calls (log_likelihood_matrix,
+// likelihood/matrix.rs:52-106).  Same arithmetic per (subject, support point) as pmx_analytical_classed<KID, true>; what
+// is different is how a step gets its scalars.  That kernel was scalar-fetch-latency bound (round 2: ~60 % of the issue
+// slots): every step began by requesting five scalar blocks and waiting for all of them.  Here
+//   * a step's {meta, dt} is ONE 16-byte record, requested a step AHEAD (DevClassPlan::prog_rec);
+//   * its observation block (G observed values + G weights) is requested at the top of the step and first touched after
+//     the state update - the propagator arithmetic covers the fetch;
+//   * its value block (G rates) is not fetched at all for a step in which no live member of the chunk has an infusion
+//     running (DevClassPlan::chunk_rate_mask): such a step builds F only and advances with apply0.
+// ------------------------------------------------------------------------------------
+#ifndef PMX_LL_WAVES
+#define PMX_LL_WAVES 3
+#endif
+// Hand-issued scalar requests for one step of a chunk: its observation block ([G] observed values, [G] weights) and
+// its program record.  (A request the compiler does not know of: the caller waits with s_waitcnt lgkmcnt(0) by hand.)
+template <int G>
+struct ObsRequest;
+template <>
+struct ObsRequest<8> {
+  typedef uint32_t V __attribute__((ext_vector_type(16)));
+  static __device__ __forceinline__ void issue(V& y, V& w, uint64_t& rec, const double* blk, const double* recp) {
+    asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx16 %1, %3, 0x40\n\ts_load_dwordx2 %2, %4, 0x0"
+                 : "=&s"(y), "=&s"(w), "=&s"(rec)
+                 : "s"(blk), "s"(recp)
+                 : "memory");
+  }
+};
+template <>
+struct ObsRequest<4> {
+  typedef uint32_t V __attribute__((ext_vector_type(8)));
+  static __device__ __forceinline__ void issue(V& y, V& w, uint64_t& rec, const double* blk, const double* recp) {
+    asm volatile("s_load_dwordx8 %0, %3, 0x0\n\ts_load_dwordx8 %1, %3, 0x20\n\ts_load_dwordx2 %2, %4, 0x0"
+                 : "=&s"(y), "=&s"(w), "=&s"(rec)
+                 : "s"(blk), "s"(recp)
+                 : "memory");
+  }
+};
+template <int KID, bool CENS>
+__global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? PMX_LL_WAVES : 2) void pmx_analytical_classed_ll(
+    DevModel m, DevOps ops, DevClassPlan cp, const double* __restrict__ theta, int64_t P, int32_t n_ptiles,
+    uint8_t* __restrict__ status) {
+  using LM = LaneModel<KID>;
+  constexpr int NS = LM::NS;
+  constexpr int G = ClassBatch<KID>::G;
+  const int64_t b = blockIdx.x;
+  const int64_t group = b / (8 * n_ptiles);
+  const int32_t local = static_cast<int32_t>(b % (8 * n_ptiles));
+  const int32_t ptile = local / 8;
+  const int64_t cblock = group * 8 + (local % 8);
+  const int64_t n_cblocks = static_cast<int64_t>(gridDim.x) / n_ptiles;
+  const int64_t c_end = cp.n_chunks_exact;
+  if (cblock >= c_end) return;
+  const uint32_t lane = threadIdx.x & 63u;
+  const int64_t p = static_cast<int64_t>(ptile) * kBlock + threadIdx.x;
+  const bool lane_ok = p < P;
+  const int64_t pc = lane_ok ? p : (P - 1);
+  const double* __restrict__ th = theta + pc * m.nparams;
+  const double nanv = __longlong_as_double(0x7ff8000000000000LL);
+
+  typename LM::S::Coef coef;
+  double inv_vol0;
+  bool lane_good;
+  // The lane's initial state lives in registers for the whole launch.  Fetched inside the RESET step (behind `if (init)`)
+  // the load is still pending at the join as far as the waitcnt pass can tell, and its s_waitcnt vmcnt(0) lands on the
+  // COMMON path: every chunk then begins by waiting for the previous chunk's ll_out stores (loads and stores share one
+  // in-order counter) - measured: the 800 MB of C3's output cost their full 0.13 ms on top of the arithmetic.
+  double xinit[NS];
+  {
+    LM L;
+    lane_setup<KID, false>(m, th, L);
+    coef = L.coef;
+    lane_good = L.ok;
+    inv_vol0 = L.ok ? L.inv_vol[0] : nanv;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) xinit[i] = L.xinit[i];
+  }
+  const auto prog_rec = as_const(reinterpret_cast<const uint64_t*>(cp.prog_rec));
+  const auto cls_prog_off = as_const(cp.cls_prog_off);
+  const auto chunk_cls = as_const(cp.chunk_cls);
+  const auto chunk_n = as_const(cp.chunk_n);
+  const auto chunk_val_off = as_const(cp.chunk_val_off);
+  const auto chunk_subj = as_const(cp.chunk_subj);
+  const auto chunk_row = as_const(cp.chunk_row);
+  const auto val = as_const(cp.val);
+  const auto cobs = as_const(cp.cobs);
+  (void)chunk_row;
+#ifdef PMX_LL_STAGGER
+  {
+    // Every wave runs the same program on chunks of the same length, so the waves of the chip reach their chunk ends -
+    // eight 512-byte stores each - together: the memory system takes the bursts while nobody computes.  The co-resident
+    // waves of a SIMD start a fraction of a chunk apart (hardware wave slot -> phase), and stay apart.
+    const uint32_t slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 15u;  // HW_REG_HW_ID[3:0] = wave slot in its SIMD
+    const uint32_t phase = slot % 3u;
+    for (uint32_t i = 0; i < phase * PMX_LL_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
+
+  for (int64_t c = cblock; c < c_end; c += n_cblocks) {
+    const int32_t cls = chunk_cls[c];
+    const int32_t n_live = chunk_n[c];
+    int64_t voff = chunk_val_off[c];
+    const int64_t pb = cls_prog_off[cls];
+    const int32_t n_steps = static_cast<int32_t>(cls_prog_off[cls + 1] - pb);
+    const uint64_t rate_mask = as_const(cp.chunk_rate_mask)[c];
+    const int64_t cbase = as_const(cp.chunk_obs_off)[c];
+    int64_t cobs_off = cbase + 2 * G;  // (behind the chunk's [G] constant sums and [G] flags)
+    if (cp.zero_status == 1 && status != nullptr) {  // (see pmx_analytical_classed)
+      const int zj = static_cast<int>(lane >> 3);
+      int64_t zsid = -1;
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const int64_t sj = chunk_subj[c * G + j];
+        zsid = (zj == j && j < n_live) ? sj : zsid;
+      }
+      const int64_t zp = static_cast<int64_t>(ptile) * kBlock + (threadIdx.x & ~63u) + 8 * (lane & 7u);
+      if (zsid >= 0 && zp < P) *reinterpret_cast<uint64_t*>(status + zsid * P + zp) = 0ull;
+    }
+    double ll_acc[G], x[G][NS];
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      ll_acc[j] = 0.0;
+#pragma unroll
+      for (int i = 0; i < NS; ++i) x[j][i] = 0.0;
+    }
+    uint32_t bad = 0;
+    double ex[LM::S::NE];
+#pragma unroll
+    for (int i = 0; i < LM::S::NE; ++i) ex[i] = 0.0;
+    int32_t kobs = 0;
+    // the straight-line steps of THIS chunk: on the ladder with a plain row of output 0 behind them (class), nobody
+    // infusing (chunk), every live member's row plain under the bound error model (chunk x error model)
+    const uint64_t fast_mask = as_const(cp.cls_fast_mask)[cls] & ~rate_mask &
+                               static_cast<uint64_t>(__double_as_longlong(cobs[cbase + G + 1])) & 0x7fffffffffffffffull;
+    const int out_state0 = m.out[0].state - m.pm;
+    auto recp = prog_rec + 2 * pb;
+    int32_t k = 0;
+    while (k < n_steps) {
+      const uint64_t run_bits = (k < 63) ? (fast_mask >> k) : 0ull;
+      if (run_bits & 1ull) {
+        // ---- a run of straight-line steps: x' = F x, fold the row.  The output's state is picked OUTSIDE the loop (one
+        // copy of the loop per state) and the ladder is a one-sided branch, so a step is straight-line code that updates
+        // every value in place; the record of the next step and this step's observation block are requested at its top.
+        int32_t run = __builtin_ctzll(~run_bits);
+        if (run > n_steps - k) run = n_steps - k;
+        auto fast_run = [&](auto st_c) {
+          constexpr int ST = decltype(st_c)::value;
+          // The NEXT step's record and observation block are requested a whole step ahead, by hand: left to the
+          // compiler the requests sink to the end of the step (their only use is the next trip), a dozen instructions in
+          // front of the wait.  A request the compiler does not know of is waited for by hand as well - at the top of
+          // every trip and once behind the loop (the last, unused request must not land in registers given to others).
+          using Req = ObsRequest<G>;
+          typename Req::V yn, wn;
+          uint64_t w_n;
+          Req::issue(yn, wn, w_n, cp.cobs + cobs_off, cp.prog_rec + 2 * (pb + k));
+#pragma unroll 1
+          for (int32_t i = 0; i < run; ++i) {
+            // (the wait names the requested registers as operands: nothing may read them in front of it)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(yn), "+s"(wn), "+s"(w_n)::"memory");
+            typename Req::V yc = yn, wc = wn;
+            uint64_t w = w_n;
+            asm volatile("" : "+s"(yc), "+s"(wc), "+s"(w));
+            cobs_off += 2 * G;
+            Req::issue(yn, wn, w_n, cp.cobs + cobs_off, cp.prog_rec + 2 * (pb + k + i + 1));
+            double ov_y[G], ov_w[G];
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+              ov_y[j] = __longlong_as_double(static_cast<int64_t>((static_cast<uint64_t>(yc[2 * j + 1]) << 32) | yc[2 * j]));
+              ov_w[j] = __longlong_as_double(static_cast<int64_t>((static_cast<uint64_t>(wc[2 * j + 1]) << 32) | wc[2 * j]));
+            }
+            const uint32_t rung = (static_cast<uint32_t>(w) >> 27) & 7u;  // 1..4
+            if (rung != 1u) {
+#pragma unroll
+              for (int e = 0; e < LM::S::NE; ++e) {
+                const double bse = ex[e];
+                const double sq = bse * bse;
+                double r = sq;
+                if (rung != 2u) r = sq * ((rung == 3u) ? bse : sq);
+                ex[e] = r;
+              }
+            }
+            typename LM::S::Prop pr;
+            LM::S::from_exps_f(coef, ex, pr);
+#pragma unroll
+            for (int j = 0; j < G; ++j) LM::S::apply0(pr, x[j]);
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+              const double d = fma(-inv_vol0, x[j][ST], ov_y[j]);
+              ll_acc[j] = fma(-(d * ov_w[j]), d, ll_acc[j]);
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(yn), "+s"(wn), "+s"(w_n)::"memory");
+          recp += 2 * run;
+        };
+        if (out_state0 == 0) fast_run(std::integral_constant<int, 0>{});
+        if constexpr (NS > 1) {
+          if (out_state0 == 1) fast_run(std::integral_constant<int, 1>{});
+        }
+        if constexpr (NS > 2) {
+          if (out_state0 == 2) fast_run(std::integral_constant<int, 2>{});
+        }
+        if constexpr (NS > 3) {
+          if (out_state0 == 3) fast_run(std::integral_constant<int, 3>{});
+        }
+        kobs += run;
+        voff += static_cast<int64_t>(run) * G;
+        k += run;
+        continue;
+      }
+      // ---- any other step: the general form
+      const uint64_t w = recp[0], dtb = recp[1];
+      recp += 2;
+      const uint32_t meta = static_cast<uint32_t>(w);
+      const uint32_t kind = meta & 0xffu;
+      const int io = static_cast<int>((meta >> 8) & 0xffffu);
+      const bool has_val = ((rate_mask >> (k < 63 ? k : 63)) & 1ull) != 0ull;
+      if (kind == OP_PROP) {
+        const uint32_t rung = (meta >> 27) & 7u;
+        if (rung == 0u) {
+          LM::S::exps(coef, __longlong_as_double(static_cast<int64_t>(dtb)), ex);
+        } else if (rung != 1u) {
+          ladder_pow<LM::S::NE>(ex, rung);
+        }
+        typename LM::S::Prop pr;
+        LM::S::from_exps_f(coef, ex, pr);
+#pragma unroll
+        for (int j = 0; j < G; ++j) LM::S::apply0(pr, x[j]);
+        if (has_val) {  // wave-uniform: somebody infuses - the response to the members' rates on top
+          LM::S::from_exps_j(coef, ex, pr);
+#pragma unroll
+          for (int j = 0; j < G; ++j) LM::S::add_j(pr, x[j], val[voff + j]);
+        }
+      } else if (kind == OP_BOLUS) {
+        double f = fa_of(m, th, io);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(f)::"memory");  // (the lane's fa is consumed HERE, not behind the join)
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+          const double a = val[voff + j] * f;
+#pragma unroll
+          for (int i = 0; i < NS; ++i) x[j][i] += (i == io - m.pm) ? a : 0.0;
+        }
+      } else if (kind == OP_RESET) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+          const double xi = io ? xinit[i] : 0.0;
+#pragma unroll
+          for (int j = 0; j < G; ++j) x[j][i] = xi;
+        }
+      }
+      if ((meta >> 24) & 1u) {  // the observation fused into this step
+        const auto ov = cobs + cobs_off;
+        double ov_y[G], ov_w[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+          ov_y[j] = ov[j];
+          ov_w[j] = ov[G + j];
+        }
+        const int oq = static_cast<int>((meta >> 25) & 3u);
+        int out_state = out_state0;
+        double inv_vol = inv_vol0;
+        if (oq != 0) {  // outputs beyond the first: rare (see pmx_analytical_classed for why it is written this way)
+          out_state = m.out[oq].state - m.pm;
+          const int vp = m.out_vol_theta[oq];
+          double v = 1.0;
+          if (vp >= 0) v = th[vp];
+          double iv = 1.0 / v;
+          asm volatile("" : "+v"(iv));
+          inv_vol = lane_good ? iv : nanv;
+        }
+        auto fold = [&](auto st_c) {
+          constexpr int ST = decltype(st_c)::value;
+#pragma unroll
+          for (int j = 0; j < G; ++j) {
+            const int64_t wb = __double_as_longlong(ov_w[j]);
+            if (wb != 0) {  // wave-uniform; weight 0 = missing observation (or chunk padding)
+              if (CENS && wb < 0) {  // censored / residual-model row: the generic fold on its full record
+                ll_accumulate(as_const(ops.ll_obs) + (chunk_row[c * G + j] + kobs) * 4, x[j][ST] * inv_vol, ll_acc[j]);
+              } else {
+                const double d = fma(-inv_vol, x[j][ST], ov_y[j]);
+                ll_acc[j] = fma(-(d * ov_w[j]), d, ll_acc[j]);
+              }
+            }
+          }
+        };
+        if (out_state == 0) fold(std::integral_constant<int, 0>{});
+        if constexpr (NS > 1) {
+          if (out_state == 1) fold(std::integral_constant<int, 1>{});
+        }
+        if constexpr (NS > 2) {
+          if (out_state == 2) fold(std::integral_constant<int, 2>{});
+        }
+        if constexpr (NS > 3) {
+          if (out_state == 3) fold(std::integral_constant<int, 3>{});
+        }
+        cobs_off += 2 * G;
+        ++kobs;
+      }
+      voff += G;
+      ++k;
+    }
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      if (j < n_live) {
+        const int64_t sid = chunk_subj[c * G + j];
+        const double llj = ll_acc[j] + cobs[cbase + j];  // + the member's constants
+        if (!isfinite(llj)) bad |= (1u << j);  // NonFiniteLikelihood (prediction.rs:119-124)
+#if !defined(PMX_ABL_NOSTORE)
+        if (lane_ok) ops.ll_out[sid * ops.ll_ld + p] = llj;  // (NaN already for a lane with complex roots)
+#else
+        if (lane_ok && llj == 1.2345e300) ops.ll_out[sid * ops.ll_ld + p] = llj;
+#endif
+      }
+    }
+    if (status != nullptr && (cp.zero_status == 2 || __any(((bad != 0u || !lane_good) && lane_ok) ? 1 : 0))) {
+      if (cp.zero_status == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clearing store above lands first
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        if (j < n_live) {
+          const int64_t sid = chunk_subj[c * G + j];
+          const uint8_t st = !lane_good ? PMX_PAIR_COMPLEX_ROOTS : (((bad >> j) & 1u) ? PMX_PAIR_NONFINITE : PMX_PAIR_OK);
+          if (lane_ok && (st != PMX_PAIR_OK || cp.zero_status == 2)) status[sid * P + p] = st;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // PAIR kernel (analytical): lane = (subject, support point), divergent schedules
 // ------------------------------------------------------------------------------------
 template <int KID, bool DYN, bool LAG, bool LL>
@@ -1320,7 +1647,22 @@ hipError_t launch_analytical(const LaunchArgs& a, const char** name) {
         if (n_exact > 0) {
           if (LAG) *name = ll ? "pmx_analytical_classed<ll,lag>" : "pmx_analytical_classed<lag>";
           else if (ll) *name = "pmx_analytical_classed<ll>";
-          if (!ll) launch_cls(F{}, F{}, F{}, n_exact);
+          bool done = false;
+          if constexpr (!LAG && !DYN) {
+            if (ll && a.cls.prog_rec != nullptr && a.tune_ll_old == 0) {  // exact classes of a plain model: the pipelined kernel
+              int64_t cpb = 1;
+              const int64_t cblocks = blocks_for(n_exact, false, &cpb);
+              if (cens)
+                hipLaunchKernelGGL((pmx_analytical_classed_ll<KID, true>), dim3(static_cast<uint32_t>(cblocks * a.n_ptiles)),
+                                   dim3(grid_threads(a.P)), 0, st, a.m, a.ops, a.cls, a.theta, a.P, a.n_ptiles, a.status);
+              else
+                hipLaunchKernelGGL((pmx_analytical_classed_ll<KID, false>), dim3(static_cast<uint32_t>(cblocks * a.n_ptiles)),
+                                   dim3(grid_threads(a.P)), 0, st, a.m, a.ops, a.cls, a.theta, a.P, a.n_ptiles, a.status);
+              done = true;
+            }
+          }
+          if (done) {
+          } else if (!ll) launch_cls(F{}, F{}, F{}, n_exact);
           else if (cens) launch_cls(T{}, F{}, T{}, n_exact);
           else launch_cls(T{}, F{}, F{}, n_exact);
         }
@@ -1513,7 +1855,21 @@ __global__ __launch_bounds__(256) void pmx_ll_prepare_chunks(LLPrepareArgs a) {
       if (all) plain |= (1ull << k);
     }
     a.cobs[base + a.G] = __longlong_as_double(static_cast<int64_t>(plain));
-    for (int32_t j = 1; j < a.G; ++j) a.cobs[base + a.G + j] = 0.0;
+    // ... and the same mask indexed by program STEP (bit s < 63: step s carries an observation that is plain for every
+    // live member), for the kernel that picks its straight-line steps by step number (pmx_analytical_classed_ll)
+    uint64_t plain_step = 0;
+    {
+      const int32_t cl = a.chunk_cls[ch];
+      int32_t k = 0;
+      for (int64_t o = a.cls_prog_off[cl], s = 0; o < a.cls_prog_off[cl + 1]; ++o, ++s) {
+        if ((a.prog_meta[o] >> 24) & 1u) {
+          if (s < 63 && k < 63 && ((plain >> k) & 1ull)) plain_step |= 1ull << s;
+          ++k;
+        }
+      }
+    }
+    a.cobs[base + a.G + 1] = __longlong_as_double(static_cast<int64_t>(plain_step));
+    for (int32_t j = 2; j < a.G; ++j) a.cobs[base + a.G + j] = 0.0;
   }
   for (int32_t j = threadIdx.x; j < a.G; j += 256) {
     double csum = 0.0;

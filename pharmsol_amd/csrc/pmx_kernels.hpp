@@ -23,6 +23,10 @@ struct DevClassPlan {
   const int32_t* chunk_subj;
   const int64_t* chunk_row;  // [n_chunks*G] first prediction row of each member (0 for padding)
   const double* val;
+  const double* prog_rec;           // the programs again, packed for the log-likelihood kernel: [n_prog_steps + 1][2] =
+                                    //   {meta (u64 bits), dt} - ONE scalar fetch per step, requested a step ahead
+  const uint64_t* chunk_rate_mask;  // [n_chunks] ClassPlan::chunk_rate_mask
+  const uint64_t* cls_fast_mask;    // [n_classes] ClassPlan::cls_fast_mask
   const double* dtv;                // loose chunks: each member's own PROP lengths, laid out like val
   const double* facp;               // covariate models: [..][G][n_fac] covariate factors of each member's PROP ...
   const double* faco;               // ... and of the observation fused into the step
@@ -71,6 +75,7 @@ struct LaunchArgs {
   int32_t prop_slots;   // DYN GRID: LDS slots for kept propagators (OpStream::prop_cache_used; 0 = none)
   int32_t dyn_tile;     // DYN GRID with kept propagators: support points per block (0 = the default tile)
   int32_t tune_cpb;     // > 0: chunks per block of the classed kernel forced by PMX_TUNE_CPB (tuning experiments)
+  int32_t tune_ll_old;  // != 0: PMX_TUNE_LL_OLD - the round-2 log-likelihood kernel for exact classes (A/B)
   DevClassPlan cls;
   DevSteps steps;       // analytical GRID, plain models (no covariate factors, no lag, no pm_ indexing): nullptr = none
   const int32_t* subj_list;  // GRID: walk these subjects instead of 0..S-1 (nullptr = all)
@@ -100,6 +105,10 @@ struct LLPrepareArgs {
   int64_t n_chunks;
   int32_t G;
   double* cobs;
+  // the chunks' programs (flag slot 1 of a chunk's block = the plain-row mask indexed by program STEP)
+  const int32_t* chunk_cls;
+  const int64_t* cls_prog_off;
+  const uint32_t* prog_meta;
   void* stream;
 };
 hipError_t launch_ll_prepare(const LLPrepareArgs& a);

@@ -213,6 +213,8 @@ struct Structure<S_ONE> {
     x[0] = x[0] * p.e + p.j * r;
   }
   __device__ __forceinline__ static void apply0(const Prop& p, double (&x)[NS]) { x[0] = x[0] * p.e; }
+  // x += J r: the response to an infusion rate on top of a state already advanced with apply0
+  __device__ __forceinline__ static void add_j(const Prop& p, double (&x)[NS], double r) { x[0] += p.j * r; }
 };
 
 template <>
@@ -257,6 +259,7 @@ struct Structure<S_ONE_ABS> {
     x[0] = g * p.ea;
     x[1] = x[1] * p.ee + p.g * g;
   }
+  __device__ __forceinline__ static void add_j(const Prop& p, double (&x)[NS], double r) { x[1] += p.j * r; }
 };
 
 // ---------------------------------------------------------------- two compartments
@@ -362,6 +365,10 @@ struct Structure<S_TWO> {
     x[0] = n0;
     x[1] = n1;
   }
+  __device__ __forceinline__ static void add_j(const Prop& q, double (&x)[NS], double r) {
+    x[0] += q.p.j0 * r;
+    x[1] += q.p.j1 * r;
+  }
 };
 
 template <>
@@ -426,6 +433,10 @@ struct Structure<S_TWO_ABS> {
     x[0] = g * q.ea;
     x[1] = n0;
     x[2] = n1;
+  }
+  __device__ __forceinline__ static void add_j(const Prop& q, double (&x)[NS], double r) {
+    x[1] += q.p.j0 * r;
+    x[2] += q.p.j1 * r;
   }
 };
 
@@ -709,6 +720,10 @@ struct Structure<S_THREE> {
     x[1] = y1;
     x[2] = y2;
   }
+  __device__ __forceinline__ static void add_j(const Prop& q, double (&x)[NS], double r) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) x[i] += q.p.j[i] * r;
+  }
 };
 
 template <>
@@ -782,6 +797,10 @@ struct Structure<S_THREE_ABS> {
     x[1] = y0;
     x[2] = y1;
     x[3] = y2;
+  }
+  __device__ __forceinline__ static void add_j(const Prop& q, double (&x)[NS], double r) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) x[1 + i] += q.p.j[i] * r;
   }
 };
 

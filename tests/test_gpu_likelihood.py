@@ -89,7 +89,7 @@ def test_ragged_population_generic_and_pair_kernels():
     flat = m.flatten(Data(subs))
     theta = synth.theta_c3(70)
     flat = with_observed_values(m, flat, theta[:1], rng)
-    assert_ll_parity(m, flat, EM_ADD, theta, expect_kernel="pmx_analytical_grid")
+    assert_ll_parity(m, flat, EM_ADD, theta, expect_kernel="pmx_analytical_steps")
     assert_ll_parity(m, flat, EM_PROP, theta[:5], expect_kernel="pmx_analytical_pair")
 
 

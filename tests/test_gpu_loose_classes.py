@@ -117,7 +117,7 @@ def test_loose_classes_can_be_switched_off(monkeypatch):
     _ffi.lib().pmx_debug_reload_env()  # the switches are read once per process; this re-reads them
     try:
         model = synth.model_two_cpt_iv()
-        check(model, synth.population_c23(200, ragged=True), synth.theta_c3(64), "pmx_analytical_grid")
+        check(model, synth.population_c23(200, ragged=True), synth.theta_c3(64), "pmx_analytical_steps")
     finally:
         monkeypatch.delenv("PMX_TUNE_LOOSE")
         _ffi.lib().pmx_debug_reload_env()

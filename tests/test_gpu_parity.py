@@ -213,7 +213,7 @@ def test_ragged_population_with_empty_and_doseless_subjects():
     m = models.handwritten_analytical("two_compartments", 0, 4)
     flat = m.flatten(Data(subjects))
     th = synth.theta_c3(97)
-    assert_parity(m, flat, th, TOL_ANALYTICAL, expect_kernel="pmx_analytical_grid")
+    assert_parity(m, flat, th, TOL_ANALYTICAL, expect_kernel="pmx_analytical_steps")
     assert_parity(m, flat, th[:3], TOL_ANALYTICAL, expect_kernel="pmx_analytical_pair")
     th_b = synth.theta_c3(len(subjects))
     assert_parity(m, flat, th_b, TOL_ANALYTICAL, batch=True, expect_kernel="pmx_analytical_pair")
@@ -335,7 +335,7 @@ def test_bioavailability_alone_and_on_ode():
     subs = _lag_subjects(rng, 30)
     m = Analytical.new("one_compartment", {0: Ratio(0, 1)}, nparams=3, fa={0: 2}).with_nstates(1).with_ndrugs(1).with_nout(1)
     th = np.stack([rng.uniform(0.05, 0.5, 64), rng.uniform(5, 50, 64), rng.uniform(0.2, 1.0, 64)], axis=1)
-    assert_parity(m, m.flatten(Data(subs)), th, TOL_ANALYTICAL, expect_kernel="pmx_analytical_grid")
+    assert_parity(m, m.flatten(Data(subs)), th, TOL_ANALYTICAL, expect_kernel="pmx_analytical_steps")
     # below the generic walker's GRID/PAIR crossover (48 support points) the same model takes the PAIR kernel
     assert_parity(m, m.flatten(Data(subs)), th[:40], TOL_ANALYTICAL, expect_kernel="pmx_analytical_pair")
     mo = ODE.new("one_cmt_iv", {0: Ratio(0, 1)}, nparams=3, h_max=0.01).with_nstates(1).with_ndrugs(1).with_nout(1)
@@ -476,7 +476,7 @@ def test_exponential_ladder_designs(structure, nparams, central):
     if structure == "two_compartments_with_absorption":
         th = np.concatenate([synth.theta_c3(64)[:, :1], rng.uniform(0.8, 3.0, (64, 1)), synth.theta_c3(64)[:, 1:]], axis=1)
     assert_parity(m, flat, th, 2e-11, expect_kernel="pmx_analytical_classed")  # (+ the generic kernel on the ragged five)
-    assert_parity(m, m.flatten(Data(subs[24:])), th, 2e-11, expect_kernel="pmx_analytical_grid")
+    assert_parity(m, m.flatten(Data(subs[24:])), th, 2e-11, expect_kernel="pmx_analytical_steps")
 
 
 def test_pmetrics_one_based_wrappers():
@@ -688,8 +688,8 @@ def test_small_support_grids_pick_the_measured_lane_mapping():
     subs = [models.random_subject(rng) for _ in range(40)]
     mr = models.handwritten_analytical("two_compartments", 0, 4).with_ndrugs(1)
     fr = mr.flatten(Data(subs))
-    for n, kernel in ((20, "pmx_analytical_pair"), (47, "pmx_analytical_pair"), (48, "pmx_analytical_grid"),
-                      (100, "pmx_analytical_grid"), (130, "pmx_analytical_grid")):
+    for n, kernel in ((20, "pmx_analytical_pair"), (47, "pmx_analytical_pair"), (48, "pmx_analytical_steps"),
+                      (100, "pmx_analytical_steps"), (130, "pmx_analytical_steps")):
         assert_parity(mr, fr, synth.theta_c3(n), TOL_ANALYTICAL, expect_kernel=kernel)
 
 
