@@ -76,7 +76,7 @@ def parse_args(argv=None):
                     help="untimed back-to-back passes before the warm-up, to bring the device clocks up after set-up")
     ap.add_argument("--place-gib", type=float, default=96.0,
                     help="size limit of the arena searched for a fast window for the prediction matrix "
-                         "(runtime.place_predictions; capped at 40 %% of the free device memory); 0 = plain first allocation")
+                         "(runtime.place_predictions; capped at 75 %% of the free device memory); 0 = plain first allocation")
     ap.add_argument("--alloc-tries", type=int, default=8,
                     help="plain allocations timed as placement candidates beside the arena's windows (the first one is "
                          "reported as frac_first_allocation)")

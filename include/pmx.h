@@ -510,8 +510,11 @@ int32_t pmx_loglik_device(const pmx_model* model, const pmx_population* pop, con
 /* log_likelihood_batch(eq, &data, &parameters, &error_models) (likelihood/mod.rs:119-177): subject s under ITS OWN
  * parameter row theta[s] (n_subjects rows); ll[n_subjects], status[n_subjects].  Like the reference, a subject whose
  * simulation or likelihood fails does not fail the call: its entry is -inf (`Err(_) => f64::NEG_INFINITY`,
- * likelihood/mod.rs:137-140) and its status byte says why.  The device form leaves NaN in the failed entries (nothing
- * can be rewritten after the fact on a stream); map status != PMX_PAIR_OK to -inf on the caller's side. */
+ * likelihood/mod.rs:137-140) and its status byte says why.  That includes a subject with an observation on an output
+ * that has no error model (em[q].kind = PMX_EM_NONE): ResidualErrorModels::total_log_likelihood gives it -inf and the
+ * call succeeds (residual_error.rs:413-425) - here its rows poison its sum (PMX_PAIR_NONFINITE), where pmx_loglik fails
+ * the whole call with PMX_ERR_ERROR_MODEL like log_likelihood_matrix.  The device form leaves NaN in the failed entries
+ * (nothing can be rewritten after the fact on a stream); map status != PMX_PAIR_OK to -inf on the caller's side. */
 int32_t pmx_loglik_batch(const pmx_model* model, const pmx_population* pop, const pmx_error_model* em,
                          const double* theta, double* ll, uint8_t* status);
 int32_t pmx_loglik_batch_device(const pmx_model* model, const pmx_population* pop, const pmx_error_model* em,

@@ -22,6 +22,7 @@
 namespace {
 
 struct Arena {
+  int dev = 0;            // the device the buffer lives on (destroy switches to it: VMM calls and the sync act on the CURRENT device)
   void* plain = nullptr;  // the buffer is a plain hipMalloc allocation (it beat every window): nothing else is set
   void* va = nullptr;
   size_t total = 0, chunk = 0;
@@ -72,6 +73,7 @@ int32_t pmx_prediction_buffer_create(const pmx_model* model, const pmx_populatio
   size_t n_chunks = search_bytes > 0 ? static_cast<size_t>(search_bytes) / chunk : 0;
   if (n_chunks < win_chunks) n_chunks = win_chunks;
   Arena a;
+  a.dev = dev;
   a.chunk = chunk;
   a.total = n_chunks * chunk;
   if (hipMemAddressReserve(&a.va, a.total, 0, nullptr, 0) != hipSuccess) return PMX_ERR_OUT_OF_MEMORY;
@@ -137,6 +139,7 @@ int32_t pmx_prediction_buffer_create(const pmx_model* model, const pmx_populatio
   // holds no search dispatches).  PMX_TUNE_PLACE_FULL=1: time every window of the arena (landscape studies).
   long forced = -1;
   if (const char* e = std::getenv("PMX_TUNE_PLACE_WINDOW")) forced = std::atol(e);
+  if (forced >= 0 && static_cast<size_t>(forced) + win_chunks > n_chunks) forced = -1;  // (past the arena: search instead of mapping all of it first)
   if (forced >= 0 && !map_up_to(static_cast<size_t>(forced) + win_chunks)) forced = -1;
   const bool full = exhaustive || std::getenv("PMX_TUNE_PLACE_FULL") != nullptr;
   size_t best = 0;
@@ -198,6 +201,7 @@ int32_t pmx_prediction_buffer_create(const pmx_model* model, const pmx_populatio
   if (plain && forced < 0 && plain_ms < 0.99 * best_ms) {  // the plain allocation wins: the whole arena goes back
     release(a);
     Arena p;
+    p.dev = dev;
     p.plain = plain;
     {
       std::lock_guard<std::mutex> lock(g_mu);
@@ -235,6 +239,17 @@ void pmx_prediction_buffer_destroy(double* d_pred) {
     a = std::move(it->second);
     g_arenas.erase(it);
   }
+  // on the buffer's own device: kernels still writing the window must be waited for THERE before the memory goes away,
+  // and hipMemUnmap / hipMemRelease / hipFree act on the current device (a multi-GPU process calls this from anywhere)
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  if (prev != a.dev) (void)hipSetDevice(a.dev);
+  struct Restore {
+    int from, to;
+    ~Restore() {
+      if (to >= 0 && to != from) (void)hipSetDevice(to);
+    }
+  } restore{a.dev, prev};
   (void)hipDeviceSynchronize();
   if (a.plain) {
     (void)hipFree(a.plain);

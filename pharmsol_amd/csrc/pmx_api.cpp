@@ -780,7 +780,14 @@ pmx::CompileKey key_for(const pmx_model* m) {
       k.class_g = (st == pmx::S_ONE || st == pmx::S_ONE_ABS || st == pmx::S_TWO) ? 8 : 4;  // == ClassBatch<KID>::G
     }
     // covariate models that take the generic walker: equal (length, factors) PROPs of an occasion share a propagator
-    if (m->dyn && k.lag_mask == 0 && k.class_g == 0) k.prop_cache_slots = tun.prop_slots >= 0 ? (tun.prop_slots > 3 ? 3 : tun.prop_slots) : 1;  // (one slot: a second costs more occupancy
+    if (m->dyn && k.lag_mask == 0 && k.class_g == 0) {
+      k.prop_cache_slots = tun.prop_slots >= 0 ? (tun.prop_slots > 3 ? 3 : tun.prop_slots) : 1;
+      // the kept propagators live in LDS, [slot][component][256 lanes]: stay inside the 64 KB a block may take without an
+      // opt-in attribute (the stream's cache codes are written for THIS number of slots, so it is fixed here)
+      static const int kPropDoubles[6] = {2, 4, 6, 9, 12, 16};  // sizeof(Structure<ST>::Prop) / 8, ST = S_ONE .. S_THREE_ABS
+      const int per_slot = kPropDoubles[st] * 8 * 256;
+      while (k.prop_cache_slots > 0 && k.prop_cache_slots * per_slot > (64 << 10)) --k.prop_cache_slots;
+    }  // (one slot: a second costs more occupancy
     // than its extra reuse returns - C5: 1 slot 16.8 ms, 2 slots 19.4 ms, none 20.2 ms; tools/c5 notes in DESIGN.md)
   } else if (m->user_ode) {
     // ODE with user lag / fa / derive closures (pmx_ode_user.hpp): covariates are looked up on the device, every PROP
@@ -960,7 +967,7 @@ int32_t get_stream(pmx_population* pop, const pmx::CompileKey& key, DeviceStream
 // Pick (or fill) the slot holding the sigma tables for `em`.  On return the slot is pinned (host_users) and `stream`
 // is ordered after the slot's last use; the caller launches its kernel and then calls release_ll_slot.
 int32_t acquire_ll_slot(const pmx_model* model, pmx_population* pop, DeviceStream* ds, const pmx_error_model* em,
-                        void* stream, DeviceStream::LLCache** out) {
+                        void* stream, DeviceStream::LLCache** out, bool batch = false) {
   const int nout = model->d.nout;
   const auto& hp = pop->hp;
   std::lock_guard<std::mutex> lock(pop->mu);
@@ -982,7 +989,11 @@ int32_t acquire_ll_slot(const pmx_model* model, pmx_population* pop, DeviceStrea
   for (int q = 0; q < 32; ++q) {
     if (!((pop->valued_outeq_mask >> q) & 1u)) continue;
     if (q >= nout) return fail(PMX_ERR_OUTEQ_OUT_OF_RANGE, "observation outeq >= nout");
-    if (em[q].kind < PMX_EM_ADDITIVE || em[q].kind > PMX_EM_RES_EXPONENTIAL)
+    // log_likelihood_matrix: MissingErrorModel fails the call (error_model.rs:1045-1080 through matrix.rs:83,104).
+    // log_likelihood_batch: ResidualErrorModels::total_log_likelihood gives such a SUBJECT -inf and the call succeeds
+    // (residual_error.rs:413-425): the table fill poisons the rows of that output (pmx_ll_prepare_obs), the subject's sum
+    // comes out NaN with PMX_PAIR_NONFINITE, the batch entry points map that to -inf.
+    if (!batch && (em[q].kind < PMX_EM_ADDITIVE || em[q].kind > PMX_EM_RES_EXPONENTIAL))
       return fail(PMX_ERR_ERROR_MODEL, "MissingErrorModel: output " + std::to_string(q) + " has observations but no error model");
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1165,7 +1176,7 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
     }
   } slot_guard{pop, &slot, stream};
   if (llreq != nullptr) {
-    rc = acquire_ll_slot(model, pop, ds, llreq->em, stream, &slot);
+    rc = acquire_ll_slot(model, pop, ds, llreq->em, stream, &slot, batch != 0);
     if (rc != PMX_OK) return rc;
     a.ops.ll_obs = slot->d_obs;
     a.ops.ll_out = llreq->d_ll;
@@ -1348,6 +1359,17 @@ int32_t ws_copy_out(HostWorkspace* ws, void* dst, size_t dst_pitch, const void* 
   return PMX_OK;
 }
 
+// Every exit path of a host-pointer entry point leaves nothing in flight: the caller may free or reuse theta and its
+// (possibly page-locked) outputs as soon as the call returns - also when it returns an error half-way - and the next
+// call reuses the workspace buffers.
+struct WsDrain {
+  HostWorkspace* ws;
+  ~WsDrain() {
+    (void)hipStreamSynchronize(ws->compute);
+    (void)hipStreamSynchronize(ws->copy);
+  }
+};
+
 // the per-pair status bytes: "did any pair fail" comes back as ONE flag reduced on the device (the array itself is only
 // copied when the caller asked for it: 100 MB for C3)
 int32_t ws_finish_status(HostWorkspace* ws, uint8_t* status, size_t n_status, bool* any_failed) {
@@ -1377,6 +1399,7 @@ int32_t predict_host(const pmx_model* model, const pmx_population* cpop, const d
   int32_t rc = ws_get(pop, &ws);
   if (rc != PMX_OK) return rc;
   std::lock_guard<std::mutex> turn(ws->mu);
+  WsDrain drain{ws};
   const int64_t rows_theta = batch ? S : P;
   const int64_t Pd = batch ? 1 : P;  // the device matrix is dense; the caller's padding columns are never touched
   const size_t n_status = static_cast<size_t>(batch ? S : S * P);
@@ -1411,6 +1434,7 @@ int32_t loglik_host(const pmx_model* model, const pmx_population* cpop, const pm
   int32_t rc = ws_get(pop, &ws);
   if (rc != PMX_OK) return rc;
   std::lock_guard<std::mutex> turn(ws->mu);
+  WsDrain drain{ws};
   const int64_t Pd = batch ? 1 : P;
   const size_t theta_bytes = static_cast<size_t>(batch ? S : P) * model->d.nparams * sizeof(double);
   const size_t ll_bytes = static_cast<size_t>(S) * Pd * sizeof(double);

@@ -1783,6 +1783,16 @@ __global__ __launch_bounds__(256) void pmx_ll_prepare_obs(LLPrepareArgs a) {
   if (y == y) {  // a valued observation (missing ones keep weight 0)
     const int q = a.obs_outeq[r];
     const pmx_error_model& e = a.em[q < PMX_MAX_OUT ? q : 0];
+    if (e.kind < PMX_EM_ADDITIVE || e.kind > PMX_EM_RES_EXPONENTIAL) {
+      // no error model for this output (only the batch entry points get here: log_likelihood_batch scores such a subject
+      // -inf instead of failing, residual_error.rs:413-425): the row poisons its subject's sum
+      const double nanq = __longlong_as_double(0x7ff8000000000000LL);
+      a.obs4[r * 4 + 0] = nanq;
+      a.obs4[r * 4 + 1] = nanq;
+      a.obs4[r * 4 + 2] = 1.0;
+      a.obs4[r * 4 + 3] = 0.0;
+      return;
+    }
     double c0 = e.c[0], c1 = e.c[1], c2 = e.c[2], c3 = e.c[3];
     if (a.obs_poly != nullptr) {  // the observation's own polynomial wins (error_model.rs:1051-1054)
       const double p0 = a.obs_poly[r * 4];
