@@ -945,12 +945,44 @@ int32_t get_stream(pmx_population* pop, const pmx::CompileKey& key, DeviceStream
         int64_t at = 0;
         for (int64_t c = 0; c < cp.n_chunks; ++c) {
           off[static_cast<size_t>(c)] = at;
-          at += (static_cast<int64_t>(ds->h_chunk_nobs[static_cast<size_t>(c)]) * 2 + 2) * cp.G;
+          // {[G] constant sums, [G] flags, [observation][value | weight][G], [G] constant sums again (tail copy: the
+          // log-likelihood kernel's request a step ahead of a chunk's last step brings them in for its epilogue)}
+          at += (static_cast<int64_t>(ds->h_chunk_nobs[static_cast<size_t>(c)]) * 2 + 3) * cp.G;
         }
         off[static_cast<size_t>(cp.n_chunks)] = at;  // sentinel
         ds->cobs_size = at;
         if ((rc = upload(ds->h_chunk_nobs, &ds->d_chunk_nobs, &ds->allocs)) != PMX_OK) return rc;
         if ((rc = upload(off, &ds->d_chunk_obs_off, &ds->allocs)) != PMX_OK) return rc;
+        {
+          // one 64-byte record per chunk for pmx_analytical_classed_ll (pmx_kernels.hpp DevClassPlan::chunk_hdr): everything
+          // the kernel needs of a chunk in ONE scalar fetch.  32-bit offsets and 16-bit counts: a plan outside those
+          // limits simply keeps the round-2 kernel (chunk_hdr stays null).
+          bool fits = cp.G <= 8 && at < (int64_t{1} << 32) && static_cast<int64_t>(cp.val.size()) < (int64_t{1} << 32) &&
+                      static_cast<int64_t>(cp.prog_meta.size()) < (int64_t{1} << 32);
+          for (size_t cl = 0; cl + 1 < cp.cls_prog_off.size() && fits; ++cl)
+            fits = cp.cls_prog_off[cl + 1] - cp.cls_prog_off[cl] < 65536;
+          if (fits) {
+            std::vector<uint32_t> hdr((static_cast<size_t>(cp.n_chunks) + 1) * 16, 0);
+            for (int64_t c = 0; c < cp.n_chunks; ++c) {
+              uint32_t* q = &hdr[static_cast<size_t>(c) * 16];
+              const int32_t cl = cp.chunk_cls[static_cast<size_t>(c)];
+              q[0] = static_cast<uint32_t>(cp.chunk_n[static_cast<size_t>(c)]) |
+                     (static_cast<uint32_t>(cp.cls_prog_off[cl + 1] - cp.cls_prog_off[cl]) << 16);
+              q[1] = static_cast<uint32_t>(cp.cls_prog_off[cl]);
+              q[2] = static_cast<uint32_t>(cp.chunk_val_off[static_cast<size_t>(c)]);
+              q[3] = static_cast<uint32_t>(off[static_cast<size_t>(c)]);
+              const uint64_t rm = cp.chunk_rate_mask[static_cast<size_t>(c)], fm = cp.cls_fast_mask[cl];
+              q[4] = static_cast<uint32_t>(rm);
+              q[5] = static_cast<uint32_t>(rm >> 32);
+              q[6] = static_cast<uint32_t>(fm);
+              q[7] = static_cast<uint32_t>(fm >> 32);
+              for (int32_t j = 0; j < cp.G; ++j) q[8 + j] = static_cast<uint32_t>(cp.chunk_subj[static_cast<size_t>(c) * cp.G + j]);
+            }
+            const uint32_t* d_hdr = nullptr;
+            if ((rc = upload(hdr, &d_hdr, &ds->allocs)) != PMX_OK) return rc;
+            ds->cls.chunk_hdr = d_hdr;
+          }
+        }
       }
       ds->cls.n_chunks = cp.n_chunks;
       ds->cls.n_chunks_exact = cp.n_chunks_exact;

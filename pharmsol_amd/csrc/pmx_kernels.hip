@@ -1060,41 +1060,52 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
 // ------------------------------------------------------------------------------------
 // CLASSED log-likelihood kernel, exact classes of plain models - the entry NPAG calls (log_likelihood_matrix,
 // likelihood/matrix.rs:52-106).  Same arithmetic per (subject, support point) as pmx_analytical_classed<KID, true>; what
-// is different is how a step gets its scalars.  That kernel was scalar-fetch-latency bound (round 2: ~60 % of the issue
-// slots): every step began by requesting five scalar blocks and waiting for all of them.  Here
-//   * a step's {meta, dt} is ONE 16-byte record, requested a step AHEAD (DevClassPlan::prog_rec);
-//   * its observation block (G observed values + G weights) is requested at the top of the step and first touched after
-//     the state update - the propagator arithmetic covers the fetch;
-//   * its value block (G rates) is not fetched at all for a step in which no live member of the chunk has an infusion
-//     running (DevClassPlan::chunk_rate_mask): such a step builds F only and advances with apply0.
+// is different is how a wave gets its scalars.  Stamped with s_memtime (tools/ll_stamps.py), the round-2 shape spent 46 %
+// of its wave time in the chunk epilogue and 7 % in the chunk header - dependent scalar fetches of data that streams
+// from HBM once (subject ids, offsets), one after the other, each a full memory latency - and waited on five scalar
+// blocks at the top of every step.  Here
+//   * everything a chunk needs is ONE 128-byte record (DevClassPlan::chunk_hdr: program, offsets, masks, the G subject
+//     ids), requested a chunk ahead - at the start of the previous chunk's epilogue;
+//   * a step's {meta, dt} is one 16-byte record and its observation block (G observed values + G weights) one pair of
+//     wide fetches, both requested a whole step ahead, by hand (the compiler sinks such requests to their use);
+//   * the members' constant sums sit BEHIND the chunk's last observation block (cobs tail copy): the request a step
+//     ahead of the last step brings them in for the epilogue;
+//   * runs of steps that are on the exponential ladder, carry a row of output 0 and see no infusion in this chunk are
+//     straight-line code (one basic block per step, every value updated in place); a missing observation's weight 0
+//     makes its term vanish, so without censored rows (CENS = false) every row qualifies;
+//   * a step in which no live member has an infusion running builds F only and advances with apply0;
+//   * the lane's initial state and every other per-lane value is in registers before the chunk loop: no vector load
+//     (and so no s_waitcnt vmcnt behind the previous chunk's stores) on the common path.
 // ------------------------------------------------------------------------------------
-#ifndef PMX_LL_WAVES
-#define PMX_LL_WAVES 3
+#ifdef PMX_LL_STAMPS
+__device__ uint64_t g_ll_stamps[5];  // diagnostic build only (tools/ll_stamps.py): cycles per phase, summed over waves
 #endif
-// Hand-issued scalar requests for one step of a chunk: its observation block ([G] observed values, [G] weights) and
-// its program record.  (A request the compiler does not know of: the caller waits with s_waitcnt lgkmcnt(0) by hand.)
+// Scalar fetches that stay where they are written.  Left to the compiler a request whose only use is the next trip of a
+// loop sinks to the end of the trip, a dozen instructions in front of its wait; a VOLATILE fetch is not moved by the
+// optimiser, and a scheduling barrier behind it keeps the instruction scheduler from moving it either.  (The waits are the
+// compiler's own: it knows these registers are pending.  An earlier form issued the fetches from inline assembly - faster
+// to write, but the register allocator may spill or copy an output it believes is already there.)
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+template <class V>
+__device__ __forceinline__ V sload_here(const void* p_) {
+  const void* p = reinterpret_cast<const void*>(uniform64(reinterpret_cast<int64_t>(p_)));  // (wave-uniform: a scalar address)
+  return *(const volatile __attribute__((address_space(4))) V*)(p);
+}
 template <int G>
 struct ObsRequest;
 template <>
 struct ObsRequest<8> {
-  typedef uint32_t V __attribute__((ext_vector_type(16)));
-  static __device__ __forceinline__ void issue(V& y, V& w, uint64_t& rec, const double* blk, const double* recp) {
-    asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx16 %1, %3, 0x40\n\ts_load_dwordx2 %2, %4, 0x0"
-                 : "=&s"(y), "=&s"(w), "=&s"(rec)
-                 : "s"(blk), "s"(recp)
-                 : "memory");
-  }
+  typedef u32x16 V;
 };
 template <>
 struct ObsRequest<4> {
-  typedef uint32_t V __attribute__((ext_vector_type(8)));
-  static __device__ __forceinline__ void issue(V& y, V& w, uint64_t& rec, const double* blk, const double* recp) {
-    asm volatile("s_load_dwordx8 %0, %3, 0x0\n\ts_load_dwordx8 %1, %3, 0x20\n\ts_load_dwordx2 %2, %4, 0x0"
-                 : "=&s"(y), "=&s"(w), "=&s"(rec)
-                 : "s"(blk), "s"(recp)
-                 : "memory");
-  }
+  typedef u32x8 V;
 };
+
+#ifndef PMX_LL_WAVES
+#define PMX_LL_WAVES 3
+#endif
 template <int KID, bool CENS>
 __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? PMX_LL_WAVES : 2) void pmx_analytical_classed_ll(
     DevModel m, DevOps ops, DevClassPlan cp, const double* __restrict__ theta, int64_t P, int32_t n_ptiles,
@@ -1102,6 +1113,7 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? PMX_LL_WAVES : 
   using LM = LaneModel<KID>;
   constexpr int NS = LM::NS;
   constexpr int G = ClassBatch<KID>::G;
+  using Req = ObsRequest<G>;
   const int64_t b = blockIdx.x;
   const int64_t group = b / (8 * n_ptiles);
   const int32_t local = static_cast<int32_t>(b % (8 * n_ptiles));
@@ -1120,11 +1132,7 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? PMX_LL_WAVES : 
   typename LM::S::Coef coef;
   double inv_vol0;
   bool lane_good;
-  // The lane's initial state lives in registers for the whole launch.  Fetched inside the RESET step (behind `if (init)`)
-  // the load is still pending at the join as far as the waitcnt pass can tell, and its s_waitcnt vmcnt(0) lands on the
-  // COMMON path: every chunk then begins by waiting for the previous chunk's ll_out stores (loads and stores share one
-  // in-order counter) - measured: the 800 MB of C3's output cost their full 0.13 ms on top of the arithmetic.
-  double xinit[NS];
+  double xinit[NS];  // (in registers for the whole launch: see the header comment)
   {
     LM L;
     lane_setup<KID, false>(m, th, L);
@@ -1134,44 +1142,72 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? PMX_LL_WAVES : 
 #pragma unroll
     for (int i = 0; i < NS; ++i) xinit[i] = L.xinit[i];
   }
-  const auto prog_rec = as_const(reinterpret_cast<const uint64_t*>(cp.prog_rec));
-  const auto cls_prog_off = as_const(cp.cls_prog_off);
-  const auto chunk_cls = as_const(cp.chunk_cls);
-  const auto chunk_n = as_const(cp.chunk_n);
-  const auto chunk_val_off = as_const(cp.chunk_val_off);
-  const auto chunk_subj = as_const(cp.chunk_subj);
   const auto chunk_row = as_const(cp.chunk_row);
   const auto val = as_const(cp.val);
   const auto cobs = as_const(cp.cobs);
   (void)chunk_row;
-#ifdef PMX_LL_STAGGER
-  {
-    // Every wave runs the same program on chunks of the same length, so the waves of the chip reach their chunk ends -
-    // eight 512-byte stores each - together: the memory system takes the bursts while nobody computes.  The co-resident
-    // waves of a SIMD start a fraction of a chunk apart (hardware wave slot -> phase), and stay apart.
-    const uint32_t slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 15u;  // HW_REG_HW_ID[3:0] = wave slot in its SIMD
-    const uint32_t phase = slot % 3u;
-    for (uint32_t i = 0; i < phase * PMX_LL_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+  const int out_state0 = m.out[0].state - m.pm;
+  const char* hdr_base = reinterpret_cast<const char*>(cp.chunk_hdr);
+  // the lane's slot in its row of the output, ll_out[sid][p], and the row pitch in bytes - the pitch parked in a VECTOR
+  // register: as a scalar it does not survive the register pressure of the step loop, and re-fetched from the kernel
+  // arguments in front of every store (s_load + s_waitcnt, which also waits for the header request in flight) it made
+  // the epilogue half of the wave's time (tools/ll_stamps.py)
+  char* const ll_lane = reinterpret_cast<char*>(ops.ll_out + p);
+  uint32_t ll_pitch = static_cast<uint32_t>(ops.ll_ld * 8);  // (host-checked: fits 32 bits)
+  asm volatile("" : "+v"(ll_pitch));
+
+#ifdef PMX_LL_STAMPS
+  uint64_t tp[5] = {0, 0, 0, 0, 0};  // diagnostic build only: shader cycles per phase (header, slow steps, fast runs, epilogue, whole wave)
+  const uint64_t t_wave0 = __builtin_amdgcn_s_memtime();
+#define PMX_STAMP(i, t_prev)                              \
+  {                                                       \
+    const uint64_t t_now_ = __builtin_amdgcn_s_memtime(); \
+    tp[i] += t_now_ - t_prev;                             \
+    t_prev = t_now_;                                      \
   }
+#else
+#define PMX_STAMP(i, t_prev)
 #endif
 
+  // the NEXT chunk's header record, requested a chunk ahead
+  u32x16 h_n = sload_here<u32x16>(hdr_base + cblock * 64);
   for (int64_t c = cblock; c < c_end; c += n_cblocks) {
-    const int32_t cls = chunk_cls[c];
-    const int32_t n_live = chunk_n[c];
-    int64_t voff = chunk_val_off[c];
-    const int64_t pb = cls_prog_off[cls];
-    const int32_t n_steps = static_cast<int32_t>(cls_prog_off[cls + 1] - pb);
-    const uint64_t rate_mask = as_const(cp.chunk_rate_mask)[c];
-    const int64_t cbase = as_const(cp.chunk_obs_off)[c];
+#ifdef PMX_LL_STAMPS
+    uint64_t t_ph = __builtin_amdgcn_s_memtime();
+#endif
+    u32x16 h = h_n;
+    asm volatile("" : "+s"(h));
+#ifdef PMX_LL_HDR_EARLY
+    {
+      const int64_t c_next = (c + n_cblocks < c_end) ? (c + n_cblocks) : c;
+      h_n = sload_here<u32x16>(hdr_base + c_next * 64);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
+    // {n_live | n_steps << 16, program offset, val offset, cobs offset, rate mask, class fast mask, subject ids}
+    const int32_t n_live = static_cast<int32_t>(h[0] & 0xffffu);
+    const int32_t n_steps = static_cast<int32_t>(h[0] >> 16);
+    const int64_t pb = static_cast<int64_t>(h[1]);
+    int64_t voff = static_cast<int64_t>(h[2]);
+    const int64_t cbase = static_cast<int64_t>(h[3]);
+    const uint64_t rate_mask = (static_cast<uint64_t>(h[5]) << 32) | h[4];
+    uint64_t fast_mask = ((static_cast<uint64_t>(h[7]) << 32) | h[6]) & ~rate_mask & 0x7fffffffffffffffull;
+    // the G subject ids wait for the epilogue in ONE vector register (lane j holds member j's): eight scalar registers
+    // less across the step loop, whose straight-line runs hold two observation blocks at a time
+    int32_t sid_park = 0;
+#pragma unroll
+    for (int j = 0; j < G; ++j) sid_park = (static_cast<int>(lane) == j) ? static_cast<int32_t>(h[8 + j]) : sid_park;
     int64_t cobs_off = cbase + 2 * G;  // (behind the chunk's [G] constant sums and [G] flags)
+    if constexpr (CENS) {
+      // censored / residual-model rows take the general fold: only the steps whose row is plain for every live member
+      // (the mask by program step, pmx_ll_prepare_chunks) run straight-line.  (a dependent fetch: this variant is the rare one)
+      fast_mask &= static_cast<uint64_t>(__double_as_longlong(cobs[cbase + G + 1]));
+    }
     if (cp.zero_status == 1 && status != nullptr) {  // (see pmx_analytical_classed)
       const int zj = static_cast<int>(lane >> 3);
       int64_t zsid = -1;
 #pragma unroll
-      for (int j = 0; j < G; ++j) {
-        const int64_t sj = chunk_subj[c * G + j];
-        zsid = (zj == j && j < n_live) ? sj : zsid;
-      }
+      for (int j = 0; j < G; ++j) zsid = (zj == j && j < n_live) ? static_cast<int64_t>(static_cast<int32_t>(h[8 + j])) : zsid;
       const int64_t zp = static_cast<int64_t>(ptile) * kBlock + (threadIdx.x & ~63u) + 8 * (lane & 7u);
       if (zsid >= 0 && zp < P) *reinterpret_cast<uint64_t*>(status + zsid * P + zp) = 0ull;
     }
@@ -1187,40 +1223,51 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? PMX_LL_WAVES : 
 #pragma unroll
     for (int i = 0; i < LM::S::NE; ++i) ex[i] = 0.0;
     int32_t kobs = 0;
-    // the straight-line steps of THIS chunk: on the ladder with a plain row of output 0 behind them (class), nobody
-    // infusing (chunk), every live member's row plain under the bound error model (chunk x error model)
-    const uint64_t fast_mask = as_const(cp.cls_fast_mask)[cls] & ~rate_mask &
-                               static_cast<uint64_t>(__double_as_longlong(cobs[cbase + G + 1])) & 0x7fffffffffffffffull;
-    const int out_state0 = m.out[0].state - m.pm;
-    auto recp = prog_rec + 2 * pb;
+    bool csum_in = false;  // the members' constant sums (the block behind the chunk's last observation block) are in the sums
+    const double* recs = cp.prog_rec + 2 * pb;
     int32_t k = 0;
+    PMX_STAMP(0, t_ph)
     while (k < n_steps) {
       const uint64_t run_bits = (k < 63) ? (fast_mask >> k) : 0ull;
       if (run_bits & 1ull) {
         // ---- a run of straight-line steps: x' = F x, fold the row.  The output's state is picked OUTSIDE the loop (one
         // copy of the loop per state) and the ladder is a one-sided branch, so a step is straight-line code that updates
-        // every value in place; the record of the next step and this step's observation block are requested at its top.
+        // every value in place; the record of the NEXT step and its observation block are requested at the step's top.
         int32_t run = __builtin_ctzll(~run_bits);
         if (run > n_steps - k) run = n_steps - k;
+        typename Req::V yn, wn;
+        uint64_t w_n;
         auto fast_run = [&](auto st_c) {
           constexpr int ST = decltype(st_c)::value;
-          // The NEXT step's record and observation block are requested a whole step ahead, by hand: left to the
-          // compiler the requests sink to the end of the step (their only use is the next trip), a dozen instructions in
-          // front of the wait.  A request the compiler does not know of is waited for by hand as well - at the top of
-          // every trip and once behind the loop (the last, unused request must not land in registers given to others).
-          using Req = ObsRequest<G>;
-          typename Req::V yn, wn;
-          uint64_t w_n;
-          Req::issue(yn, wn, w_n, cp.cobs + cobs_off, cp.prog_rec + 2 * (pb + k));
+#ifndef PMX_LL_OV_SAME_STEP
+          yn = sload_here<typename Req::V>(cp.cobs + cobs_off);
+          wn = sload_here<typename Req::V>(cp.cobs + cobs_off + G);
+#endif
+          w_n = sload_here<uint64_t>(recs + 2 * k);
 #pragma unroll 1
           for (int32_t i = 0; i < run; ++i) {
-            // (the wait names the requested registers as operands: nothing may read them in front of it)
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(yn), "+s"(wn), "+s"(w_n)::"memory");
+#ifndef PMX_LL_OV_SAME_STEP
             typename Req::V yc = yn, wc = wn;
             uint64_t w = w_n;
-            asm volatile("" : "+s"(yc), "+s"(wc), "+s"(w));
+            asm volatile("" : "+s"(yc), "+s"(wc), "+s"(w));  // (this step's block and record are in; the next ones go out behind here)
             cobs_off += 2 * G;
-            Req::issue(yn, wn, w_n, cp.cobs + cobs_off, cp.prog_rec + 2 * (pb + k + i + 1));
+            // (behind the chunk's last block: its tail copy of the constant sums, then the next chunk's block; behind the
+            // last program record: one record of padding)
+            yn = sload_here<typename Req::V>(cp.cobs + cobs_off);
+            wn = sload_here<typename Req::V>(cp.cobs + cobs_off + G);
+            w_n = sload_here<uint64_t>(recs + 2 * (k + i + 1));
+            __builtin_amdgcn_sched_barrier(0);
+#else
+            // this step's observation block goes out at the top of the step and is first touched behind the state update;
+            // the next step's record a step ahead (half the scalar registers of the form that keeps two blocks)
+            uint64_t w = w_n;
+            asm volatile("" : "+s"(w));
+            const typename Req::V yc = sload_here<typename Req::V>(cp.cobs + cobs_off);
+            const typename Req::V wc = sload_here<typename Req::V>(cp.cobs + cobs_off + G);
+            w_n = sload_here<uint64_t>(recs + 2 * (k + i + 1));
+            __builtin_amdgcn_sched_barrier(0);
+            cobs_off += 2 * G;
+#endif
             double ov_y[G], ov_w[G];
 #pragma unroll
             for (int j = 0; j < G; ++j) {
@@ -1245,11 +1292,9 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? PMX_LL_WAVES : 
 #pragma unroll
             for (int j = 0; j < G; ++j) {
               const double d = fma(-inv_vol0, x[j][ST], ov_y[j]);
-              ll_acc[j] = fma(-(d * ov_w[j]), d, ll_acc[j]);
+              ll_acc[j] = fma(-(d * ov_w[j]), d, ll_acc[j]);  // (weight 0 = a missing observation: the term vanishes)
             }
           }
-          asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(yn), "+s"(wn), "+s"(w_n)::"memory");
-          recp += 2 * run;
         };
         if (out_state0 == 0) fast_run(std::integral_constant<int, 0>{});
         if constexpr (NS > 1) {
@@ -1264,11 +1309,20 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? PMX_LL_WAVES : 
         kobs += run;
         voff += static_cast<int64_t>(run) * G;
         k += run;
+#ifndef PMX_LL_OV_SAME_STEP
+        if (k == n_steps) {  // the chunk's last step: what the run requested last is the tail copy of the constant sums
+#pragma unroll
+          for (int j = 0; j < G; ++j)
+            ll_acc[j] += __longlong_as_double(static_cast<int64_t>((static_cast<uint64_t>(yn[2 * j + 1]) << 32) | yn[2 * j]));
+          csum_in = true;
+        }
+#endif
+        PMX_STAMP(2, t_ph)
         continue;
       }
       // ---- any other step: the general form
-      const uint64_t w = recp[0], dtb = recp[1];
-      recp += 2;
+      const auto rp = as_const(reinterpret_cast<const uint64_t*>(recs)) + 2 * k;
+      const uint64_t w = rp[0], dtb = rp[1];
       const uint32_t meta = static_cast<uint32_t>(w);
       const uint32_t kind = meta & 0xffu;
       const int io = static_cast<int>((meta >> 8) & 0xffffu);
@@ -1356,32 +1410,66 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? PMX_LL_WAVES : 
       }
       voff += G;
       ++k;
+      PMX_STAMP(1, t_ph)
     }
+    // ---- epilogue.  The next chunk's header goes out first: the stores below cover its fetch.
+#ifndef PMX_LL_HDR_EARLY
+    {
+      const int64_t c_next = (c + n_cblocks < c_end) ? (c + n_cblocks) : c;
+      h_n = sload_here<u32x16>(hdr_base + c_next * 64);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
+    if (!csum_in) {  // (the chunk ended in a general step: fetch the tail copy now)
+      const auto cs = cobs + cobs_off;
+#pragma unroll
+      for (int j = 0; j < G; ++j) ll_acc[j] += cs[j];
+    }
+    double nanacc = 0.0;
 #pragma unroll
     for (int j = 0; j < G; ++j) {
-      if (j < n_live) {
-        const int64_t sid = chunk_subj[c * G + j];
-        const double llj = ll_acc[j] + cobs[cbase + j];  // + the member's constants
-        if (!isfinite(llj)) bad |= (1u << j);  // NonFiniteLikelihood (prediction.rs:119-124)
-#if !defined(PMX_ABL_NOSTORE)
-        if (lane_ok) ops.ll_out[sid * ops.ll_ld + p] = llj;  // (NaN already for a lane with complex roots)
+      if (j < n_live) {  // wave-uniform
+        const double llj = ll_acc[j];
+        nanacc = fma(llj, 0.0, nanacc);  // 0 * v is NaN iff v is not finite: resolved to members only in the rare wave that saw one
+        const uint32_t sidj = static_cast<uint32_t>(__builtin_amdgcn_readlane(sid_park, j));
+        double* const dst = reinterpret_cast<double*>(ll_lane + static_cast<uint64_t>(sidj) * ll_pitch);  // one v_mad_u64_u32
+#if defined(PMX_LL_STORE_PLAIN)
+        if (lane_ok) *dst = llj;
+#elif !defined(PMX_ABL_NOSTORE)
+        // streaming store: the matrix is written once and read by nobody on this device (plain stores, which allocate in L2:
+        // 0.600 ms on C3; nt: 0.530 - the wave sat in front of its eight stores for half its time, tools/ll_stamps.py)
+        if (lane_ok) __builtin_nontemporal_store(llj, dst);  // (NaN already for a lane with complex roots)
 #else
-        if (lane_ok && llj == 1.2345e300) ops.ll_out[sid * ops.ll_ld + p] = llj;
+        if (lane_ok && llj == 1.2345e300) *dst = llj;
 #endif
       }
     }
-    if (status != nullptr && (cp.zero_status == 2 || __any(((bad != 0u || !lane_good) && lane_ok) ? 1 : 0))) {
-      if (cp.zero_status == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clearing store above lands first
+    if (status != nullptr) {
+      if (__any((nanacc != nanacc) ? 1 : 0)) {  // NonFiniteLikelihood (prediction.rs:119-124)
 #pragma unroll
-      for (int j = 0; j < G; ++j) {
-        if (j < n_live) {
-          const int64_t sid = chunk_subj[c * G + j];
-          const uint8_t st = !lane_good ? PMX_PAIR_COMPLEX_ROOTS : (((bad >> j) & 1u) ? PMX_PAIR_NONFINITE : PMX_PAIR_OK);
-          if (lane_ok && (st != PMX_PAIR_OK || cp.zero_status == 2)) status[sid * P + p] = st;
+        for (int j = 0; j < G; ++j)
+          if (j < n_live && !isfinite(ll_acc[j])) bad |= (1u << j);
+      }
+      if (cp.zero_status == 2 || __any(((bad != 0u || !lane_good) && lane_ok) ? 1 : 0)) {
+        if (cp.zero_status == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clearing store above lands first
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+          if (j < n_live) {
+            const uint8_t st = !lane_good ? PMX_PAIR_COMPLEX_ROOTS : (((bad >> j) & 1u) ? PMX_PAIR_NONFINITE : PMX_PAIR_OK);
+            if (lane_ok && (st != PMX_PAIR_OK || cp.zero_status == 2))
+              status[static_cast<int64_t>(__builtin_amdgcn_readlane(sid_park, j)) * P + p] = st;
+          }
         }
       }
     }
+    PMX_STAMP(3, t_ph)
   }
+#ifdef PMX_LL_STAMPS
+  tp[4] = __builtin_amdgcn_s_memtime() - t_wave0;
+  if ((threadIdx.x & 63u) == 0u)
+    for (int i = 0; i < 5; ++i) atomicAdd(reinterpret_cast<unsigned long long*>(&g_ll_stamps[i]), static_cast<unsigned long long>(tp[i]));
+#endif
+#undef PMX_STAMP
 }
 
 // ------------------------------------------------------------------------------------
@@ -1649,7 +1737,8 @@ hipError_t launch_analytical(const LaunchArgs& a, const char** name) {
           else if (ll) *name = "pmx_analytical_classed<ll>";
           bool done = false;
           if constexpr (!LAG && !DYN) {
-            if (ll && a.cls.prog_rec != nullptr && a.tune_ll_old == 0) {  // exact classes of a plain model: the pipelined kernel
+            if (ll && a.cls.prog_rec != nullptr && a.cls.chunk_hdr != nullptr && a.tune_ll_old == 0 &&
+                a.ops.ll_ld < (int64_t{1} << 28)) {  // exact classes of a plain model: the pipelined kernel
               int64_t cpb = 1;
               const int64_t cblocks = blocks_for(n_exact, false, &cpb);
               if (cens)
@@ -1891,6 +1980,7 @@ __global__ __launch_bounds__(256) void pmx_ll_prepare_chunks(LLPrepareArgs a) {
       }
     }
     a.cobs[base + j] = csum;
+    a.cobs[base + (2 + 2 * static_cast<int64_t>(nobs)) * a.G + j] = csum;  // the tail copy, behind the last observation block
   }
 }
 }  // namespace
@@ -1932,6 +2022,18 @@ hipError_t launch_status_any(const uint8_t* d_status, int64_t n, int32_t* d_flag
   hipLaunchKernelGGL(pmx_status_any, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream), d_status, n, d_flag);
   return hipGetLastError();
 }
+
+#ifdef PMX_LL_STAMPS
+}  // namespace pmx
+extern "C" int32_t pmx_debug_ll_stamps(uint64_t* out5, int32_t reset) {  // diagnostic build only
+  uint64_t z[5] = {0, 0, 0, 0, 0};
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  if (out5 && hipMemcpyFromSymbol(out5, HIP_SYMBOL(pmx::g_ll_stamps), sizeof(z)) != hipSuccess) return 2;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(pmx::g_ll_stamps), z, sizeof(z)) != hipSuccess) return 3;
+  return 0;
+}
+namespace pmx {
+#endif
 
 hipError_t launch_predict(const LaunchArgs& a, const char** name) {
   if (a.S <= 0 || (a.P <= 0 && !a.batch)) return hipSuccess;

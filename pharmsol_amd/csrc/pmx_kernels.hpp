@@ -27,6 +27,9 @@ struct DevClassPlan {
                                     //   {meta (u64 bits), dt} - ONE scalar fetch per step, requested a step ahead
   const uint64_t* chunk_rate_mask;  // [n_chunks] ClassPlan::chunk_rate_mask
   const uint64_t* cls_fast_mask;    // [n_classes] ClassPlan::cls_fast_mask
+  const uint32_t* chunk_hdr;        // [n_chunks + 1][16]: everything pmx_analytical_classed_ll needs of a chunk in ONE 64-byte
+                                    //   record {n_live | n_steps << 16, program offset, val offset, cobs offset, rate mask (2),
+                                    //   class fast mask (2), subject ids (8)} (the last record is padding; null: plan too large)
   const double* dtv;                // loose chunks: each member's own PROP lengths, laid out like val
   const double* facp;               // covariate models: [..][G][n_fac] covariate factors of each member's PROP ...
   const double* faco;               // ... and of the observation fused into the step
