@@ -945,9 +945,7 @@ int32_t get_stream(pmx_population* pop, const pmx::CompileKey& key, DeviceStream
         int64_t at = 0;
         for (int64_t c = 0; c < cp.n_chunks; ++c) {
           off[static_cast<size_t>(c)] = at;
-          // {[G] constant sums, [G] flags, [observation][value | weight][G], [G] constant sums again (tail copy: the
-          // log-likelihood kernel's request a step ahead of a chunk's last step brings them in for its epilogue)}
-          at += (static_cast<int64_t>(ds->h_chunk_nobs[static_cast<size_t>(c)]) * 2 + 3) * cp.G;
+          at += (static_cast<int64_t>(ds->h_chunk_nobs[static_cast<size_t>(c)]) * 2 + 2) * cp.G;
         }
         off[static_cast<size_t>(cp.n_chunks)] = at;  // sentinel
         ds->cobs_size = at;

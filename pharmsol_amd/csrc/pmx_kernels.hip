@@ -1066,10 +1066,10 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? 4 : 2) void pmx
 // blocks at the top of every step.  Here
 //   * everything a chunk needs is ONE 128-byte record (DevClassPlan::chunk_hdr: program, offsets, masks, the G subject
 //     ids), requested a chunk ahead - at the start of the previous chunk's epilogue;
-//   * a step's {meta, dt} is one 16-byte record and its observation block (G observed values + G weights) one pair of
-//     wide fetches, both requested a whole step ahead, by hand (the compiler sinks such requests to their use);
-//   * the members' constant sums sit BEHIND the chunk's last observation block (cobs tail copy): the request a step
-//     ahead of the last step brings them in for the epilogue;
+//   * a step's {meta, dt} is one 16-byte record, requested a step ahead; its observation block (G observed values + G
+//     weights) one pair of wide fetches requested at the top of the step and first touched behind the state update
+//     (volatile fetches pinned by scheduling barriers: the compiler sinks plain ones to their use);
+//   * the members' constant sums are requested in front of the run that closes the chunk and added behind it;
 //   * runs of steps that are on the exponential ladder, carry a row of output 0 and see no infusion in this chunk are
 //     straight-line code (one basic block per step, every value updated in place); a missing observation's weight 0
 //     makes its term vanish, so without censored rows (CENS = false) every row qualifies;
@@ -1235,39 +1235,26 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? PMX_LL_WAVES : 
         // every value in place; the record of the NEXT step and its observation block are requested at the step's top.
         int32_t run = __builtin_ctzll(~run_bits);
         if (run > n_steps - k) run = n_steps - k;
-        typename Req::V yn, wn;
-        uint64_t w_n;
+        const bool closes = (k + run == n_steps);  // this run holds the chunk's last step
         auto fast_run = [&](auto st_c) {
           constexpr int ST = decltype(st_c)::value;
-#ifndef PMX_LL_OV_SAME_STEP
-          yn = sload_here<typename Req::V>(cp.cobs + cobs_off);
-          wn = sload_here<typename Req::V>(cp.cobs + cobs_off + G);
-#endif
-          w_n = sload_here<uint64_t>(recs + 2 * k);
+          // the members' constant sums (head of the chunk's block) ride along when this run closes the chunk: requested
+          // here, added behind the loop
+          typename Req::V cs_v;
+          if (closes) cs_v = sload_here<typename Req::V>(cp.cobs + cbase);
+          uint64_t w_n = sload_here<uint64_t>(recs + 2 * k);
 #pragma unroll 1
           for (int32_t i = 0; i < run; ++i) {
-#ifndef PMX_LL_OV_SAME_STEP
-            typename Req::V yc = yn, wc = wn;
-            uint64_t w = w_n;
-            asm volatile("" : "+s"(yc), "+s"(wc), "+s"(w));  // (this step's block and record are in; the next ones go out behind here)
-            cobs_off += 2 * G;
-            // (behind the chunk's last block: its tail copy of the constant sums, then the next chunk's block; behind the
-            // last program record: one record of padding)
-            yn = sload_here<typename Req::V>(cp.cobs + cobs_off);
-            wn = sload_here<typename Req::V>(cp.cobs + cobs_off + G);
-            w_n = sload_here<uint64_t>(recs + 2 * (k + i + 1));
-            __builtin_amdgcn_sched_barrier(0);
-#else
-            // this step's observation block goes out at the top of the step and is first touched behind the state update;
-            // the next step's record a step ahead (half the scalar registers of the form that keeps two blocks)
+            // this step's observation block goes out at the top of the step and is first touched behind the state update
+            // (keeping TWO blocks in flight - a whole step ahead - cost 32 more scalar registers and the spills that came
+            // with them: 0.53 ms against 0.48 on C3); the next step's record goes out a step ahead
             uint64_t w = w_n;
             asm volatile("" : "+s"(w));
             const typename Req::V yc = sload_here<typename Req::V>(cp.cobs + cobs_off);
             const typename Req::V wc = sload_here<typename Req::V>(cp.cobs + cobs_off + G);
-            w_n = sload_here<uint64_t>(recs + 2 * (k + i + 1));
+            w_n = sload_here<uint64_t>(recs + 2 * (k + i + 1));  // (behind the last program record: one record of padding)
             __builtin_amdgcn_sched_barrier(0);
             cobs_off += 2 * G;
-#endif
             double ov_y[G], ov_w[G];
 #pragma unroll
             for (int j = 0; j < G; ++j) {
@@ -1295,6 +1282,11 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? PMX_LL_WAVES : 
               ll_acc[j] = fma(-(d * ov_w[j]), d, ll_acc[j]);  // (weight 0 = a missing observation: the term vanishes)
             }
           }
+          if (closes) {
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+              ll_acc[j] += __longlong_as_double(static_cast<int64_t>((static_cast<uint64_t>(cs_v[2 * j + 1]) << 32) | cs_v[2 * j]));
+          }
         };
         if (out_state0 == 0) fast_run(std::integral_constant<int, 0>{});
         if constexpr (NS > 1) {
@@ -1309,14 +1301,7 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? PMX_LL_WAVES : 
         kobs += run;
         voff += static_cast<int64_t>(run) * G;
         k += run;
-#ifndef PMX_LL_OV_SAME_STEP
-        if (k == n_steps) {  // the chunk's last step: what the run requested last is the tail copy of the constant sums
-#pragma unroll
-          for (int j = 0; j < G; ++j)
-            ll_acc[j] += __longlong_as_double(static_cast<int64_t>((static_cast<uint64_t>(yn[2 * j + 1]) << 32) | yn[2 * j]));
-          csum_in = true;
-        }
-#endif
+        csum_in = closes;
         PMX_STAMP(2, t_ph)
         continue;
       }
@@ -1420,8 +1405,8 @@ __global__ __launch_bounds__(kBlock, (LaneModel<KID>::NS <= 2) ? PMX_LL_WAVES : 
       __builtin_amdgcn_sched_barrier(0);
     }
 #endif
-    if (!csum_in) {  // (the chunk ended in a general step: fetch the tail copy now)
-      const auto cs = cobs + cobs_off;
+    if (!csum_in) {  // (the chunk ended in a general step: fetch the constant sums now)
+      const auto cs = cobs + cbase;
 #pragma unroll
       for (int j = 0; j < G; ++j) ll_acc[j] += cs[j];
     }
@@ -1747,6 +1732,7 @@ hipError_t launch_analytical(const LaunchArgs& a, const char** name) {
               else
                 hipLaunchKernelGGL((pmx_analytical_classed_ll<KID, false>), dim3(static_cast<uint32_t>(cblocks * a.n_ptiles)),
                                    dim3(grid_threads(a.P)), 0, st, a.m, a.ops, a.cls, a.theta, a.P, a.n_ptiles, a.status);
+              *name = "pmx_analytical_classed_ll";
               done = true;
             }
           }
@@ -1980,7 +1966,6 @@ __global__ __launch_bounds__(256) void pmx_ll_prepare_chunks(LLPrepareArgs a) {
       }
     }
     a.cobs[base + j] = csum;
-    a.cobs[base + (2 + 2 * static_cast<int64_t>(nobs)) * a.G + j] = csum;  // the tail copy, behind the last observation block
   }
 }
 }  // namespace

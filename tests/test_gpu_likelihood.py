@@ -58,7 +58,7 @@ def test_c3_shared_design_classed_kernel(em):
     rng = np.random.default_rng(1)
     m, flat, theta = synth.config_c3(333, 1000)  # 333: the last chunk of 8 is partial
     flat = with_observed_values(m, flat, theta[:1], rng)
-    assert_ll_parity(m, flat, em, theta, expect_kernel="pmx_analytical_classed<ll>")
+    assert_ll_parity(m, flat, em, theta, expect_kernel="pmx_analytical_classed_ll")
 
 
 @pytest.mark.parametrize("missing_frac", [0.0, 0.02])
@@ -78,7 +78,7 @@ def test_classed_fold_without_per_member_tests(missing_frac):
     flat = m.flatten(Data(subs))
     theta = synth.theta_c3(130)
     flat = with_observed_values(m, flat, theta[:1], rng, missing_frac=missing_frac)
-    assert_ll_parity(m, flat, EM_PROP, theta, expect_kernel="pmx_analytical_classed<ll>")
+    assert_ll_parity(m, flat, EM_PROP, theta, expect_kernel="pmx_analytical_classed_ll")
 
 
 def test_ragged_population_generic_and_pair_kernels():
@@ -191,11 +191,11 @@ def test_censored_observations_and_per_observation_error_polynomials(n_support):
     theta = theta[:n_support]
     flat = _censor_some(with_observed_values(m, flat, theta[:1], rng), rng)
     assert_ll_parity(m, flat, EM_ADD, theta,
-                     expect_kernel="pmx_analytical_classed<ll>" if n_support >= 32 else "pmx_analytical_pair")
+                     expect_kernel="pmx_analytical_classed_ll" if n_support >= 32 else "pmx_analytical_pair")
     # error polynomials alone keep the classed kernel
     flat.ev_censor = None
     assert_ll_parity(m, flat, EM_PROP, theta,
-                     expect_kernel="pmx_analytical_classed<ll>" if n_support >= 32 else "pmx_analytical_pair")
+                     expect_kernel="pmx_analytical_classed_ll" if n_support >= 32 else "pmx_analytical_pair")
 
 
 def test_censored_tail_far_from_the_prediction():
