@@ -230,6 +230,7 @@ def main():
     elapsed = 0.0
     pred = None
     em = None
+    attainable_gbs = None
     if dry:
         barrier()
         t0 = time.perf_counter()
@@ -390,6 +391,21 @@ def main():
         else:
             pass_ms = [evs[0].elapsed_time(evs[1]) / args.steps]
         kernel_name = runtime.last_kernel_name()
+        # the device's write ceiling as measured on THIS box in THIS process (a linear streaming fill of the output buffer,
+        # outside the timed region): what "attainable" means beside the 8 TB/s datasheet peak
+        if pred is not None and pred.numel() >= (1 << 22):
+            import ctypes as C
+
+            from pharmsol_amd import _ffi
+            gbs = C.c_double()
+            flat_out = pred if pred.is_contiguous() else None
+            if flat_out is not None:
+                # (the fill overwrites the buffer: one more kernel pass below restores what the parity sample reads)
+                _ffi.check(_ffi.lib().pmx_measure_write_ceiling(flat_out.data_ptr(), int(flat_out.numel()), 5,
+                                                                torch.cuda.current_stream(dev).cuda_stream, C.byref(gbs)))
+                attainable_gbs = gbs.value
+                one_pass()
+                torch.cuda.synchronize()
 
     kms = float(np.mean(pass_ms)) if pass_ms else 0.0
     t_el = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -521,6 +537,10 @@ def main():
         if bound == "hbm":
             achieved = b_alg / t_k / 1e9
             roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}
+            valu = counters.get("valu_wave_insts_per_launch")
+            if valu:  # the secondary ceiling: share of the FP64 vector issue slots at the 2.4 GHz peak clock
+                roofline["valu_frac"] = valu / t_k / 1e9 / FP64_VALU_PEAK_GINST
+                roofline["valu_insts"] = valu
             if first_alloc_ms:
                 roofline["frac_first_allocation"] = b_alg / (first_alloc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
                 roofline["kernel_ms_first_allocation"] = first_alloc_ms
@@ -533,6 +553,9 @@ def main():
                         "hbm_frac": b_alg / t_k / 1e9 / HBM_PEAK_GBS,
                         "note": "compute-bound: FP64-rate vector instructions issue once per 4 cycles per SIMD; "
                                 "frac = share of the chip's issue slots at the 2.4 GHz peak clock"}
+        roofline["attainable"] = attainable_gbs if not dry else None  # measured write ceiling of this device (GB/s): linear fill
+        if attainable_gbs and roofline.get("bound") == "hbm":
+            roofline["frac_of_attainable"] = roofline["achieved"] / attainable_gbs
         roofline.update({"traffic": counters.get("hbm_bytes_per_launch"),
                          "traffic_source": counters_src if counters.get("hbm_bytes_per_launch") else None,
                          "kernel": kernel_name, "kernel_ms": kernel_ms_mean, "algorithmic_bytes": b_alg})

@@ -49,7 +49,8 @@ typedef enum pmx_status {
   PMX_ERR_INVALID_ARGUMENT = 1,
   PMX_ERR_INPUT_OUT_OF_RANGE = 2,  /* PharmsolError::InputOutOfRange  (error/mod.rs:43; equation/mod.rs:322-327) */
   PMX_ERR_OUTEQ_OUT_OF_RANGE = 3,  /* PharmsolError::OuteqOutOfRange  (error/mod.rs:45) */
-  PMX_ERR_UNSUPPORTED = 4,         /* feature not available on the device path yet */
+  PMX_ERR_UNSUPPORTED = 4,         /* reserved: since ABI 3 no entry point returns it - every model shape the reference
+                                      accepts runs on the device (tests/test_formerly_refused_shapes.py) */
   PMX_ERR_NO_DEVICE = 5,           /* no HIP device / kernel image: the library never falls back to a CPU path */
   PMX_ERR_HIP = 6,                 /* a HIP runtime call failed (message has the hipError string) */
   PMX_ERR_OUT_OF_MEMORY = 7,
@@ -519,6 +520,12 @@ int32_t pmx_loglik_batch(const pmx_model* model, const pmx_population* pop, cons
                          const double* theta, double* ll, uint8_t* status);
 int32_t pmx_loglik_batch_device(const pmx_model* model, const pmx_population* pop, const pmx_error_model* em,
                                 const double* d_theta, double* d_ll, uint8_t* d_status, void* stream);
+
+/* The device's write ceiling as measured, for roofline reports: average rate (GB/s, HIP events on `stream`) of `reps`
+ * linear streaming fills of d_buf[0 .. n_doubles), after one untimed fill - the best of three store shapes (16 bytes per
+ * lane non-temporal / plain, and the prediction kernels' own 512 contiguous bytes per wave).  The buffer's contents are
+ * overwritten with zeros.  bench.py prints it as roofline.attainable beside the 8 TB/s datasheet peak. */
+int32_t pmx_measure_write_ceiling(double* d_buf, int64_t n_doubles, int32_t reps, void* stream, double* gb_per_s);
 
 /* Page-locked host memory for the outputs of the HOST-pointer entry points (pmx_predict, pmx_loglik, ...).  Those entry
  * points keep their device buffers, streams and staging areas on the population handle between calls; an output array

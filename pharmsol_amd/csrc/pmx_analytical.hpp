@@ -29,7 +29,8 @@ namespace {
 // Policy M:
 //   NS, NP, NIN (ndrugs), NOUT, NCOV, NDER       sizes
 //   KID            built-in structure (PMX_K_*), or -1: the user's own propagator `eq`
-//   RATE_INPUT     the input whose infusion rate a built-in structure reads (rateiv[0])
+//   RATE_INPUT     the input whose infusion rate a built-in structure reads (rateiv[0]; rateiv[1] under pm_* indexing)
+//   PM             1 = Pmetrics indexing: model state / input 0 is the wrapper's dead pad slot (analytical/mod.rs:62-90)
 //   COV_ABS        eq's derive sees covariates at the absolute segment end instead of at dt
 //   HAS_LAG, HAS_FA, HAS_SEQ, HAS_DERIVE, STATIC_COEF (built-in structure whose rate constants never change in a lane)
 //   derive(t, p, cov, der) / lag(t, p, cov, der, lag[NIN]) / fa(.., fa[NIN]) / init(p, cov, der, x) /
@@ -73,7 +74,7 @@ __device__ __forceinline__ void user_piece(const DevOps& ops, int64_t occ, const
     using S = Structure<ST>;
     double xk[S::NS];
 #pragma unroll
-    for (int i = 0; i < S::NS; ++i) xk[i] = s.x[i];
+    for (int i = 0; i < S::NS; ++i) xk[i] = s.x[i + M::PM];  // (PM = 1: the pm_* wrapper drops slot 0, analytical/mod.rs:62-90)
     if constexpr (M::STATIC_COEF) {
       advance<ST>(coef, xk, dt, rate[M::RATE_INPUT]);
     } else {
@@ -86,7 +87,8 @@ __device__ __forceinline__ void user_piece(const DevOps& ops, int64_t occ, const
       S::apply(pr, xk, rate[M::RATE_INPUT]);
     }
 #pragma unroll
-    for (int i = 0; i < S::NS; ++i) s.x[i] = xk[i];
+    for (int i = 0; i < S::NS; ++i) s.x[i + M::PM] = xk[i];
+    if constexpr (M::PM != 0) s.x[0] = 0.0;  // ... and re-pads it with 0 after every kernel call
   } else {
     user_cov_der<M>(ops, occ, t_cov, s.pw, cov, der);
     double xn[M::NS];
@@ -133,7 +135,7 @@ __device__ __forceinline__ void user_lag_apply(const DevOps& ops, int64_t occ, c
 template <class M, bool UNIFORM, bool LL>
 __device__ __forceinline__ void user_walk_subject(const DevOps& ops, const double* __restrict__ th, int64_t subj,
                                                   bool walk, bool store_ok, double* __restrict__ pred, int64_t ld,
-                                                  int64_t p, double* ll_slot, uint8_t* status_slot) {
+                                                  int64_t p, double* ll_slot, uint8_t* status_slot, int state_override = -1) {
   constexpr int NS = M::NS;
   using Coef = typename Structure<kernel_structure(M::KID < 0 ? 0 : M::KID)>::Coef;
   const double nanv = __longlong_as_double(0x7ff8000000000000LL);
@@ -229,6 +231,7 @@ __device__ __forceinline__ void user_walk_subject(const DevOps& ops, const doubl
       double y = yv[0];
 #pragma unroll
       for (int q = 1; q < M::NOUT; ++q) y = (q == io) ? yv[q] : y;
+      if (state_override >= 0) y = select_state<NS>(s.x, state_override);  // Prediction::state read-out (wave-uniform)
       if (s.cplx || bad_lag) y = nanv;
       if (s.cplx && st == PMX_PAIR_OK) st = PMX_PAIR_COMPLEX_ROOTS;
       if constexpr (LL) {
@@ -306,7 +309,7 @@ __device__ __forceinline__ void user_grid_body(const DevModel& m, const DevOps& 
 #pragma unroll 1
   for (int64_t s = s_begin; s < s_end; ++s)
     user_walk_subject<M, true, LL>(ops, th, s, true, lane_ok, pred, ld, pc, LL ? (ops.ll_out + s * ops.ll_ld + pc) : nullptr,
-                                   status ? (status + s * P + pc) : nullptr);
+                                   status ? (status + s * P + pc) : nullptr, m.state_override);
 }
 
 // PAIR: lane = one (subject, support point) pair; batch: subject s with theta row s
@@ -322,7 +325,7 @@ __device__ __forceinline__ void user_pair_body(const DevModel& m, const DevOps& 
   const int64_t p = batch ? 0 : (ic % P);
   const double* __restrict__ th = theta + (batch ? s : p) * m.nparams;
   user_walk_subject<M, false, LL>(ops, th, s, lane_ok, lane_ok, pred, ld, p, LL ? (ops.ll_out + (batch ? s : (s * ops.ll_ld + p))) : nullptr,
-                                  status ? (status + (batch ? s : (s * P + p))) : nullptr);
+                                  status ? (status + (batch ? s : (s * P + p))) : nullptr, m.state_override);
 }
 
 }  // namespace

@@ -30,6 +30,7 @@ int32_t fail(int32_t code, const std::string& msg) {
   g_err = msg;
   return code;
 }
+int32_t create_user_ode(const pmx_model_desc* d, const char* source, uint32_t fns, pmx_model** out);  // (after check_user_ode)
 
 // Developer switches (INTEGRATION.md "environment switches").  Read ONCE, at the first call that needs them: a
 // std::getenv per launch is measurable on the 11 us C2 pass.  pmx_debug_reload_env() re-reads them (tuning scripts
@@ -141,6 +142,7 @@ struct DeviceStream {
   int64_t n_ops = 0, n_prop = 0;
   int64_t max_lagb_per_list = 0;
   int32_t prop_cache_used = 0;        // LDS slots the stream's propagator-cache codes use
+  bool no_rates = false;              // no PROP of the stream has an active infusion
   double prop_reuse_fraction = 0.0;   // share of PROP ops that take a kept propagator
   ~DeviceStream() {
     for (void* p : allocs) (void)hipFree(p);
@@ -399,6 +401,7 @@ int32_t pmx_model_create(const pmx_model_desc* d, pmx_model** out) {
   auto m = std::make_unique<pmx_model>();
   m->d = *d;
   const int pm = d->pmetrics_indexing ? 1 : 0;
+  bool to_user_walker = false, ode_many_lags = false;
   if (d->eq_kind == PMX_EQ_ANALYTICAL) {
     if (d->kernel < 0 || d->kernel >= PMX_K_ANALYTICAL_COUNT) return fail(PMX_ERR_INVALID_ARGUMENT, "unknown analytical kernel");
     static const int kNS[12] = {1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4};  // AnalyticalKernel::state_count analysis.rs:259-270
@@ -422,11 +425,10 @@ int32_t pmx_model_create(const pmx_model_desc* d, pmx_model** out) {
         return fail(PMX_ERR_INVALID_ARGUMENT, "lag_param / fa_param out of range");
       if (d->lag_param[i] >= 0) ++n_lag;
     }
-    if (n_lag > pmx::kMaxLagSlots)
-      return fail(PMX_ERR_UNSUPPORTED, "more than 4 lagged inputs are not supported on the device path");
-    if (n_lag > 0 && (m->dyn || pm))
-      return fail(PMX_ERR_UNSUPPORTED,
-                  "lag time together with covariate-derived rate constants or pm_* indexing is not on the device path yet");
+    // Descriptor forms the library's own kernels do not take - lag time together with covariate-derived rate constants
+    // or pm_* indexing, more than four lagged inputs - run on the user-closure walker instead (pmx_analytical.hpp): the
+    // derived values are written out as source, every other closure is generated from the descriptor as for any user model.
+    to_user_walker = n_lag > pmx::kMaxLagSlots || (n_lag > 0 && (m->dyn || pm));
   } else if (d->eq_kind == PMX_EQ_ODE) {
     if (ode_nstates(d->kernel) < 0) return fail(PMX_ERR_INVALID_ARGUMENT, "unknown ODE model");
     if (d->nstates < ode_nstates(d->kernel)) return fail(PMX_ERR_INVALID_ARGUMENT, "model has fewer states than its diffeq");
@@ -436,7 +438,7 @@ int32_t pmx_model_create(const pmx_model_desc* d, pmx_model** out) {
       return fail(PMX_ERR_INVALID_ARGUMENT, "unknown ode_solver");
     if (d->ode_solver == PMX_SOLVER_DOPRI5 && !(d->ode_rtol > 0.0 && d->ode_atol > 0.0))
       return fail(PMX_ERR_INVALID_ARGUMENT, "the adaptive solver needs ode_rtol > 0 and ode_atol > 0");
-    if (pm) return fail(PMX_ERR_UNSUPPORTED, "pm indexing is not supported for ODE models");
+    if (pm) return fail(PMX_ERR_INVALID_ARGUMENT, "pm_* indexing is a wrapper of the analytical structures (analytical/mod.rs:62-90): it does not apply to ODE models");
     if (d->n_bind != 0 && d->n_bind != ode_nparams(d->kernel))
       return fail(PMX_ERR_INVALID_ARGUMENT, "n_bind must equal the diffeq's parameter count");
     for (int j = 0; j < d->n_bind; ++j) {
@@ -448,7 +450,7 @@ int32_t pmx_model_create(const pmx_model_desc* d, pmx_model** out) {
     {
       int n_lag = 0;
       for (int i = 0; i < PMX_MAX_INPUTS; ++i) n_lag += d->lag_param[i] >= 0;
-      if (n_lag > pmx::kMaxLagSlots) return fail(PMX_ERR_UNSUPPORTED, "more than 4 lagged inputs are not supported on the device path");
+      ode_many_lags = n_lag > pmx::kMaxLagSlots;  // (the state-machine kernels keep four lag cursors: the general ODE walker takes over)
     }
     for (int i = 0; i < PMX_MAX_INPUTS; ++i) {
       if (d->lag_param[i] >= d->nparams || d->fa_param[i] >= d->nparams)
@@ -469,6 +471,29 @@ int32_t pmx_model_create(const pmx_model_desc* d, pmx_model** out) {
   for (int i = 0; i < PMX_MAX_STATES; ++i) {
     if (d->init_param[i] >= d->nparams) return fail(PMX_ERR_INVALID_ARGUMENT, "init_param out of range");
     if (d->init_param[i] >= 0 && i < d->nstates) m->has_init = true;
+  }
+  if (to_user_walker) {
+    pmx::JitSpec sp;
+    sp.analytical = true;
+    sp.fns = d->n_derived > 0 ? static_cast<uint32_t>(PMX_FN_DERIVE) : 0u;
+    sp.desc = *d;
+    sp.source = d->n_derived > 0 ? pmx::analytical_descriptor_source(*d) : std::string();
+    std::string log;
+    if (!pmx::jit_compile(sp, &m->jit_code, &log))
+      return fail(PMX_ERR_HIP, "hiprtc could not compile the generated closures:\n" + log);
+    m->custom = true;
+    m->dyn = false;
+    m->user_fns = sp.fns;
+    m->user_lag = true;
+    m->has_init = true;  // (RESET ops always carry the occasion-index flag; the policy's init may be empty)
+  }
+  if (ode_many_lags) {  // built-in diffeq body, more than four lagged inputs: body written out as source, the general ODE walker
+    pmx_model_desc dd = *d;
+    dd.kernel = PMX_ODE_CUSTOM;
+    dd.n_derived = 0;
+    dd.n_bind = 0;
+    const std::string src = pmx::ode_descriptor_source(*d);
+    return create_user_ode(&dd, src.c_str(), PMX_FN_DYNAMICS | PMX_FN_OUTPUTS | PMX_FN_INIT, out);
   }
   if (d->eq_kind == PMX_EQ_ODE && (d->n_derived > 0 || d->n_bind > 0)) {
     // covariate-derived parameters of a built-in diffeq body (expand/ode.rs:126-185): the body is written out as source
@@ -514,7 +539,7 @@ int32_t check_custom_desc(const pmx_model_desc* d, const char* source) {
   if (d->n_covariates < 0 || d->n_covariates > PMX_MAX_COVARIATES)
     return fail(PMX_ERR_INVALID_ARGUMENT, "n_covariates out of range");
   if (d->n_derived != 0 || d->n_bind != 0 || d->pmetrics_indexing)
-    return fail(PMX_ERR_UNSUPPORTED, "derived-parameter descriptors / pm indexing do not apply to custom ODE bodies (compute them in the body)");
+    return fail(PMX_ERR_INVALID_ARGUMENT, "derived-parameter descriptors / pm indexing do not apply to custom ODE bodies (compute them in the body)");
   int n_lag = 0;
   for (int i = 0; i < PMX_MAX_INPUTS; ++i) {
     if (d->lag_param[i] >= d->nparams || d->fa_param[i] >= d->nparams)
@@ -522,7 +547,7 @@ int32_t check_custom_desc(const pmx_model_desc* d, const char* source) {
     if (d->bolus_dest[i] >= d->nstates) return fail(PMX_ERR_INVALID_ARGUMENT, "route destination out of range");
     n_lag += d->lag_param[i] >= 0;
   }
-  if (n_lag > pmx::kMaxLagSlots) return fail(PMX_ERR_UNSUPPORTED, "more than 4 lagged inputs are not supported on the device path");
+  (void)n_lag;  // (more than four lagged inputs: pmx_model_create_custom hands the model to the general ODE walker)
   return PMX_OK;
 }
 pmx::JitSpec spec_of(const pmx_model_desc* d, const char* source, int32_t has_init) {
@@ -546,6 +571,12 @@ int32_t pmx_model_create_custom(const pmx_model_desc* d, const char* source, int
   *out = nullptr;
   const int32_t rc = check_custom_desc(d, source);
   if (rc != PMX_OK) return rc;
+  {
+    int n_lag = 0;
+    for (int i = 0; i < PMX_MAX_INPUTS; ++i) n_lag += d->lag_param[i] >= 0;
+    if (n_lag > pmx::kMaxLagSlots)  // the state-machine kernels keep four lag cursors: the general ODE walker sorts any number
+      return create_user_ode(d, source, PMX_FN_DYNAMICS | PMX_FN_OUTPUTS | (has_init ? PMX_FN_INIT : 0u), out);
+  }
   auto m = std::make_unique<pmx_model>();
   m->d = *d;
   m->custom = true;
@@ -586,7 +617,8 @@ int32_t check_user_analytical(const pmx_model_desc* d, const char* source, uint3
   if (d->n_covariates < 0 || d->n_covariates > PMX_MAX_COVARIATES) return fail(PMX_ERR_INVALID_ARGUMENT, "n_covariates out of range");
   if (d->n_derived < 0 || d->n_derived > PMX_MAX_USER_DERIVED) return fail(PMX_ERR_INVALID_ARGUMENT, "n_derived out of range");
   if (d->n_derived > 0 && !(fns & PMX_FN_DERIVE)) return fail(PMX_ERR_INVALID_ARGUMENT, "n_derived > 0 needs PMX_FN_DERIVE (desc.derived[] is not read for user models)");
-  if (d->pmetrics_indexing) return fail(PMX_ERR_UNSUPPORTED, "pm_* indexing together with user closures is not supported");
+  if (d->pmetrics_indexing && d->kernel == PMX_K_CUSTOM)
+    return fail(PMX_ERR_INVALID_ARGUMENT, "pm_* indexing wraps a built-in structure: it does not apply to a user propagator (pmx_eq)");
   if (fns & PMX_FN_DYNAMICS) return fail(PMX_ERR_INVALID_ARGUMENT, "PMX_FN_DYNAMICS belongs to ODE models");
   if (d->kernel == PMX_K_CUSTOM) {
     if (!(fns & PMX_FN_EQ)) return fail(PMX_ERR_INVALID_ARGUMENT, "kernel = PMX_K_CUSTOM needs PMX_FN_EQ");
@@ -594,7 +626,7 @@ int32_t check_user_analytical(const pmx_model_desc* d, const char* source, uint3
     if (fns & PMX_FN_EQ) return fail(PMX_ERR_INVALID_ARGUMENT, "PMX_FN_EQ needs kernel = PMX_K_CUSTOM");
     if (d->kernel < 0 || d->kernel >= PMX_K_ANALYTICAL_COUNT) return fail(PMX_ERR_INVALID_ARGUMENT, "unknown analytical kernel");
     static const int kNS[12] = {1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4};
-    if (d->nstates < kNS[d->kernel]) return fail(PMX_ERR_INVALID_ARGUMENT, "model has fewer states than its structure");
+    if (d->nstates < kNS[d->kernel] + (d->pmetrics_indexing ? 1 : 0)) return fail(PMX_ERR_INVALID_ARGUMENT, "model has fewer states than its structure");
     const int np = pmx::kernel_nparams(d->kernel);
     if (d->n_bind == 0 && d->nparams < np) return fail(PMX_ERR_INVALID_ARGUMENT, "too few parameters for the structure");
     if (d->n_bind != 0 && d->n_bind != np) return fail(PMX_ERR_INVALID_ARGUMENT, "n_bind must equal the structure's parameter count");
@@ -659,6 +691,23 @@ pmx::JitSpec user_spec_of(const pmx_model_desc* d, const char* source, uint32_t 
   sp.source = source;
   return sp;
 }
+int32_t create_user_ode(const pmx_model_desc* d, const char* source, uint32_t fns, pmx_model** out) {
+  const int32_t rc = check_user_ode(d, source, fns);
+  if (rc != PMX_OK) return rc;
+  auto m = std::make_unique<pmx_model>();
+  m->d = *d;
+  m->custom = true;
+  m->user_ode = true;
+  m->user_fns = fns;
+  m->user_lag = (fns & PMX_FN_ROUTE_LAG) != 0;
+  for (int i = 0; i < PMX_MAX_INPUTS; ++i) m->user_lag |= d->lag_param[i] >= 0;
+  m->has_init = true;  // (RESET ops always carry the occasion-index flag; the policy's init may be empty)
+  std::string log;
+  if (!pmx::jit_compile(user_spec_of(d, source, fns), &m->jit_code, &log))
+    return fail(PMX_ERR_INVALID_ARGUMENT, "hiprtc could not compile the model source:\n" + log);
+  *out = m.release();
+  return PMX_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -671,21 +720,7 @@ int32_t pmx_model_create_user(const pmx_model_desc* d, const char* source, uint3
   if (d->eq_kind == PMX_EQ_ODE) {
     if ((functions & ~static_cast<uint32_t>(PMX_FN_INIT)) == (PMX_FN_DYNAMICS | PMX_FN_OUTPUTS) && d->n_derived == 0)
       return pmx_model_create_custom(d, source, (functions & PMX_FN_INIT) ? 1 : 0, out);  // theta-indexed lag / fa: the state-machine kernels
-    const int32_t rc = check_user_ode(d, source, functions);
-    if (rc != PMX_OK) return rc;
-    auto m = std::make_unique<pmx_model>();
-    m->d = *d;
-    m->custom = true;
-    m->user_ode = true;
-    m->user_fns = functions;
-    m->user_lag = (functions & PMX_FN_ROUTE_LAG) != 0;
-    for (int i = 0; i < PMX_MAX_INPUTS; ++i) m->user_lag |= d->lag_param[i] >= 0;
-    m->has_init = true;  // (RESET ops always carry the occasion-index flag; the policy's init may be empty)
-    std::string log;
-    if (!pmx::jit_compile(user_spec_of(d, source, functions), &m->jit_code, &log))
-      return fail(PMX_ERR_INVALID_ARGUMENT, "hiprtc could not compile the model source:\n" + log);
-    *out = m.release();
-    return PMX_OK;
+    return create_user_ode(d, source, functions, out);
   }
   if (d->eq_kind != PMX_EQ_ANALYTICAL) return fail(PMX_ERR_INVALID_ARGUMENT, "unknown eq_kind");
   const int32_t rc = check_user_analytical(d, source, functions);
@@ -738,7 +773,7 @@ pmx::CompileKey key_for(const pmx_model* m) {
     // model has any lag closure - ALL boluses leave the stream into one list per occasion that each lane sorts itself
     k.cov_time_mode = PMX_COV_TIME_SEGMENT_DT;  // (unused: no host-side covariate evaluation)
     k.rk4_h_max = 0.0;
-    k.rate_input = 0;
+    k.rate_input = (m->d.pmetrics_indexing && !m->user_eq) ? 1 : 0;  // (pm_* wrappers read rateiv[1]: analytical/mod.rs:86-88)
     k.full_rates = m->user_eq;
     k.n_rate = m->user_eq ? (m->d.ndrugs > 0 ? m->d.ndrugs : 1) : 1;
     k.want_times = true;
@@ -875,6 +910,9 @@ int32_t get_stream(pmx_population* pop, const pmx::CompileKey& key, DeviceStream
   if (key.lag_merge && (rc = upload(os.lagb_input, &ds->dev.lagb_input, &ds->allocs)) != PMX_OK) return rc;
   ds->max_lagb_per_list = os.max_lagb_per_list;
   ds->prop_cache_used = os.prop_cache_used;
+  ds->no_rates = true;  // (analytical streams: a PROP's op_b is its rate)
+  for (size_t o = 0; o < os.op_meta.size() && ds->no_rates; ++o)
+    if ((os.op_meta[o] & 0xffu) == pmx::OP_PROP && os.op_b[o] != 0.0) ds->no_rates = false;
   ds->prop_reuse_fraction = os.n_prop > 0 ? static_cast<double>(os.n_prop_reused) / static_cast<double>(os.n_prop) : 0.0;
   ds->dev.n_rate = key.n_rate;
   ds->dev.n_cov = 0;
@@ -1146,6 +1184,7 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
   std::memcpy(a.m.derived, d.derived, sizeof(d.derived));
   std::memcpy(a.m.bind, d.bind, sizeof(d.bind));
   std::memcpy(a.m.out, d.out, sizeof(d.out));
+  a.m.state_override = state_override;  // (the run-time-compiled walkers read it)
   if (state_override >= 0)  // Prediction::state: every output equation reads the raw amount of one state
     for (int o = 0; o < PMX_MAX_OUT; ++o) a.m.out[o] = pmx_out{state_override, PMX_SRC_NONE, 0};
   for (int o = 0; o < PMX_MAX_OUT; ++o) {
@@ -1195,6 +1234,7 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
   }
   // the stream's codes were written for key.prop_cache_slots slots; the kernel decodes them with the same number
   a.prop_slots = ds->prop_cache_used > 0 ? ds->key.prop_cache_slots : 0;
+  a.no_rates = (ds->no_rates && d.eq_kind == PMX_EQ_ANALYTICAL && std::getenv("PMX_DISABLE_DYN3") == nullptr) ? 1 : 0;
   a.dyn_tile = tunables().dyn_tile;  // (0 = the default tile; 64 and 256 measured the same with one slot)
   DeviceStream::LLCache* slot = nullptr;
   struct SlotGuard {  // the slot is released (event recorded on the stream) however this function leaves
@@ -1568,7 +1608,6 @@ int32_t pmx_predict_state_device(const pmx_model* model, const pmx_population* c
   if (!model || !cpop || !d_theta || !d_out) return fail(PMX_ERR_INVALID_ARGUMENT, "null argument");
   if (n_support <= 0 || ld_out < n_support) return fail(PMX_ERR_INVALID_ARGUMENT, "n_support must be > 0 and ld_out >= n_support");
   if (state < 0 || state >= model->d.nstates) return fail(PMX_ERR_INVALID_ARGUMENT, "state out of range");
-  if (model->custom) return fail(PMX_ERR_UNSUPPORTED, "state read-out of a custom model: add an output equation for the state");
   pmx_population* pop = const_cast<pmx_population*>(cpop);
   DeviceGuard g;
   PMX_HIP(g.enter(pop->device));
@@ -1708,6 +1747,33 @@ int32_t pmx_loglik_batch_device(const pmx_model* model, const pmx_population* cp
   PMX_HIP(g.enter(pop->device));
   LLRequest req{em, d_ll, 1};
   return enqueue(model, pop, d_theta, 1, 1, d_ll, 1, d_status, stream, &req);
+}
+
+int32_t pmx_measure_write_ceiling(double* d_buf, int64_t n_doubles, int32_t reps, void* stream, double* gb_per_s) {
+  g_err.clear();
+  if (!d_buf || !gb_per_s || n_doubles < 2 || reps < 1) return fail(PMX_ERR_INVALID_ARGUMENT, "bad argument");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  PMX_HIP(hipEventCreate(&e0));
+  PMX_HIP(hipEventCreate(&e1));
+  hipError_t e = hipSuccess;
+  float best_ms = 0.0f;
+  for (int shape = 0; shape < 3 && e == hipSuccess; ++shape) {  // the best of three store shapes (pmx_kernels.hip)
+    e = pmx::launch_fill_linear(d_buf, n_doubles, 0.0, stream, shape);  // untimed
+    if (e == hipSuccess) e = hipEventRecord(e0, st);
+    for (int32_t i = 0; i < reps && e == hipSuccess; ++i) e = pmx::launch_fill_linear(d_buf, n_doubles, 0.0, stream, shape);
+    float ms = 0.0f;
+    if (e == hipSuccess) e = hipEventRecord(e1, st);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e == hipSuccess && (shape == 0 || ms < best_ms)) best_ms = ms;
+  }
+  const float ms = best_ms;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (e != hipSuccess) return fail(PMX_ERR_HIP, hipGetErrorString(e));
+  *gb_per_s = static_cast<double>(n_doubles / 2 * 16) * reps / (static_cast<double>(ms) * 1.0e-3) / 1.0e9;
+  return PMX_OK;
 }
 
 int32_t pmx_host_alloc(int64_t bytes, void** out) {

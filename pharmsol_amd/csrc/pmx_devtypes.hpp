@@ -19,7 +19,8 @@ struct DevModel {
   int32_t eq_kind, kernel;
   int32_t nparams, n_cov, n_derived, n_bind, nout, pm;
   int32_t has_init;
-  int32_t pad_;
+  int32_t state_override;  // >= 0: every output reads the raw amount of this state (Prediction::state, pmx_predict_state_device);
+                           // read by the run-time-compiled walkers - the library's own kernels get their out[] rewritten
   pmx_derived derived[PMX_MAX_DERIVED];
   pmx_bind bind[PMX_MAX_KPARAMS];
   pmx_out out[PMX_MAX_OUT];

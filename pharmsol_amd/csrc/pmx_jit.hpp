@@ -32,6 +32,12 @@ inline JitKind jit_kind(const JitSpec& s) { return s.analytical ? JIT_ANALYTICAL
 // user lag / fa closures - GRID/PAIR x log-likelihood x solver).
 std::string jit_translation_unit(const JitSpec& spec);
 
+// Source text (pmx_derive) of an ANALYTICAL descriptor's derived values (desc.derived[]: theta * covariate factors), for
+// descriptor models the library's own kernels do not take (lag time together with covariate-derived rate constants or
+// pm_* indexing, more than four lagged inputs): such a model runs on the user-closure walker, every other closure
+// generated from the descriptor as usual.
+std::string analytical_descriptor_source(const pmx_model_desc& d);
+
 // Source text (pmx_dynamics / pmx_outputs / pmx_init) of a BUILT-IN diffeq body whose parameters / volumes are derived
 // from covariates through the descriptor (desc.derived[], desc.bind[]): the covariates are bound at the stage time.
 std::string ode_descriptor_source(const pmx_model_desc& d);

@@ -386,6 +386,120 @@ __global__ __launch_bounds__(kBlock, (!LAG && LaneModel<KID>::NS <= 2) ? 4 : ((!
 }
 
 // ------------------------------------------------------------------------------------
+// Three-compartment structures with covariate-derived rate constants on a population WITHOUT infusions (oral / bolus
+// dosing: C5).  Every segment rebuilds its propagator and applies it once, so no transition matrix is formed: the
+// matrix-free step of pmx_structures.hpp (ThreeNewton) - eigenvalues, the divided differences of exp(-l dt) on them and
+// three sparse matrix-vector products.  Same lane mapping, op stream, kept-propagator codes and status rules as
+// pmx_analytical_grid<KID, dyn>; a kept segment holds 6-7 numbers per lane in LDS instead of 12-16.  The host picks it
+// when the compiled stream holds no PROP with a rate (LaunchArgs::no_rates) and the model has no pm_ pad slot.
+// ------------------------------------------------------------------------------------
+#ifndef PMX_DYN3_WAVES
+#define PMX_DYN3_WAVES 3
+#endif
+template <int KID, bool LL>
+__global__ __launch_bounds__(kBlock, PMX_DYN3_WAVES) void pmx_analytical_dyn3(DevModel m, DevOps ops, const double* __restrict__ theta,
+                                                                             int64_t P, int64_t S, int32_t s_chunk, int32_t n_ptiles,
+                                                                             double* __restrict__ pred, int64_t ld,
+                                                                             uint8_t* __restrict__ status,
+                                                                             const int32_t* __restrict__ subj_list, int32_t zero_status,
+                                                                             int32_t prop_slots) {
+  using LM = LaneModel<KID>;
+  constexpr int NS = LM::NS;
+  constexpr int ND0 = LM::S::ND0;
+  const int64_t b = blockIdx.x;
+  const int32_t ptile = static_cast<int32_t>(b % n_ptiles);
+  const int64_t chunk = b / n_ptiles;
+  const uint32_t tile = blockDim.x;
+  const int64_t p = static_cast<int64_t>(ptile) * tile + threadIdx.x;
+  const bool lane_ok = p < P;
+  const int64_t pc = lane_ok ? p : (P - 1);
+  const double* __restrict__ th = theta + pc * m.nparams;
+  extern __shared__ double prop_cache[];  // [slot][ND0][lane]
+  (void)prop_cache;
+
+  LM L;
+  lane_setup<KID, true>(m, th, L);
+  const double nanv = __longlong_as_double(0x7ff8000000000000LL);
+  const auto c_subj_op_off = as_const(ops.subj_op_off);
+  const auto c_subj_obs_off = as_const(ops.subj_obs_off);
+  const auto c_op_meta = as_const(ops.op_meta);
+  const auto c_op_a = as_const(ops.op_a);
+
+  const int64_t s_begin = chunk * s_chunk;
+  const int64_t s_end = (s_begin + s_chunk < S) ? (s_begin + s_chunk) : S;
+  for (int64_t si = s_begin; si < s_end; ++si) {
+    const int64_t s = subj_list ? static_cast<int64_t>(as_const(subj_list)[si]) : si;
+    const int64_t o0 = c_subj_op_off[s];
+    const int64_t o1 = c_subj_op_off[s + 1];
+    int64_t row = c_subj_obs_off[s];
+    double x[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) x[i] = 0.0;
+    double ll_acc = 0.0;
+    uint8_t st = PMX_PAIR_OK;
+    uint8_t st_sticky = PMX_PAIR_OK;  // first failure of an EARLIER occasion (the reference errors out for the whole subject)
+    if (zero_status == 1 && status != nullptr) {  // (status protocol: pmx_analytical_grid)
+      const uint32_t zl = threadIdx.x & 63u;
+      const int64_t zp = static_cast<int64_t>(ptile) * tile + (threadIdx.x & ~63u) + 8 * zl;
+      if (zl < 8u && zp < P) *reinterpret_cast<uint64_t*>(status + s * P + zp) = 0ull;
+    }
+    for (int64_t o = o0; o < o1; ++o) {
+      const uint32_t meta = c_op_meta[o];
+      const uint32_t kind = meta & 0xffu;
+      const int io = static_cast<int>((meta >> 8) & 0xffffu);
+      const double a = c_op_a[o];
+      const double* cov = ops.op_fac + o * (m.n_derived * PMX_MAX_FACTORS);
+      if (kind == OP_PROP) {
+        // bits 24-26: 0 = build; 1 + k = build and keep in slot k; 1 + S + k = take slot k (pmx_compile.cpp)
+        const uint32_t rc = (meta >> 24) & 7u;
+        const uint32_t n_slots = static_cast<uint32_t>(prop_slots);
+        double q[LM::NKP], keep[ND0];
+        lane_params_dyn<KID>(m, L, cov, q);
+        if (rc > n_slots) {
+#pragma unroll
+          for (int k = 0; k < ND0; ++k) keep[k] = prop_cache[((rc - 1u - n_slots) * ND0 + k) * tile + threadIdx.x];
+        } else {
+          if (!LM::S::direct0_make(q, a, keep)) st = PMX_PAIR_COMPLEX_ROOTS;
+          if (rc != 0u) {
+#pragma unroll
+            for (int k = 0; k < ND0; ++k) prop_cache[((rc - 1u) * ND0 + k) * tile + threadIdx.x] = keep[k];
+          }
+        }
+        LM::S::direct0_apply(q, keep, x);
+      } else if (kind == OP_OBS) {
+        double y = lane_out<KID>(m, L, x, 0.0, io, cov);
+        if (st == PMX_PAIR_COMPLEX_ROOTS) y = nanv;
+        if constexpr (LL) {
+          ll_accumulate(as_const(ops.ll_obs) + row * 4, y, ll_acc);
+        } else {
+          if (st == PMX_PAIR_OK && !isfinite(y)) st = PMX_PAIR_NONFINITE;
+          if (lane_ok) pred[row * ld + p] = y;
+        }
+        ++row;
+      } else if (kind == OP_BOLUS) {
+        const double amt = a * fa_of(m, th, io);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) x[i] += (i == io) ? amt : 0.0;
+      } else {  // OP_RESET
+#pragma unroll
+        for (int i = 0; i < NS; ++i) x[i] = io ? L.xinit[i] : 0.0;
+        if (st_sticky == PMX_PAIR_OK) st_sticky = st;
+        st = PMX_PAIR_OK;
+      }
+    }
+    if (st_sticky != PMX_PAIR_OK) st = st_sticky;
+    if constexpr (LL) {
+      if (st == PMX_PAIR_OK && !isfinite(ll_acc)) st = PMX_PAIR_NONFINITE;
+      if (lane_ok) ops.ll_out[s * ops.ll_ld + p] = (st == PMX_PAIR_OK || st == PMX_PAIR_NONFINITE) ? ll_acc : nanv;
+    }
+    if (status != nullptr && lane_ok && (st != PMX_PAIR_OK || zero_status == 2)) {
+      if (zero_status == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      status[s * P + p] = st;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // LEAN GRID walker (analytical, plain models): the subjects no class holds - populations without a shared program shape -
 // walked from FUSED step records (DevSteps).  Same lane mapping and arithmetic as pmx_analytical_grid<KID, false, false>;
 // what goes is everything that kernel carries for the cases it also serves (covariate factors, lag cursors, pm_ pads,
@@ -1786,6 +1900,19 @@ hipError_t launch_analytical(const LaunchArgs& a, const char** name) {
         return hipGetLastError();
       }
     }
+    if constexpr (DYN && !LAG && kHasDirect0<kernel_structure(KID)>) {
+      if (a.no_rates && a.m.pm == 0) {  // three-compartment covariate model, no infusion anywhere: the matrix-free walker
+        *name = (list != nullptr) ? *name : "pmx_analytical_dyn3";
+        const size_t lds3 = (a.prop_slots > 0) ? static_cast<size_t>(a.prop_slots) * LaneModel<KID>::S::ND0 * sizeof(double) * threads : 0;
+        if (a.ops.ll_obs != nullptr)
+          hipLaunchKernelGGL((pmx_analytical_dyn3<KID, true>), dim3(static_cast<uint32_t>(blocks)), dim3(threads), lds3, st, a.m, a.ops,
+                             a.theta, a.P, n_walk, s_chunk, n_ptiles, a.pred, a.ld, a.status, list, a.cls.zero_status, a.prop_slots);
+        else
+          hipLaunchKernelGGL((pmx_analytical_dyn3<KID, false>), dim3(static_cast<uint32_t>(blocks)), dim3(threads), lds3, st, a.m, a.ops,
+                             a.theta, a.P, n_walk, s_chunk, n_ptiles, a.pred, a.ld, a.status, list, a.cls.zero_status, a.prop_slots);
+        return hipGetLastError();
+      }
+    }
     if (a.ops.ll_obs != nullptr)
       hipLaunchKernelGGL((pmx_analytical_grid<KID, DYN, LAG, true>), dim3(static_cast<uint32_t>(blocks)), dim3(threads), lds, st,
                          a.m, a.ops, a.theta, a.P, n_walk, s_chunk, n_ptiles, a.pred, a.ld, a.status, list, a.cls.zero_status,
@@ -1999,6 +2126,52 @@ __global__ __launch_bounds__(256) void pmx_status_any(const uint8_t* __restrict_
   if (__any(acc != 0u ? 1 : 0) && (threadIdx.x & 63u) == 0u) atomicOr(flag, 1);
 }
 }  // namespace
+
+namespace {
+// Streaming fills: what the device's write path takes when nothing else is asked of it (the measured ceiling bench.py
+// prints beside the 8 TB/s datasheet peak: roofline.attainable).  Three shapes, the entry point reports the best:
+//   0  grid-stride, 16 bytes per lane, streaming (nt) stores
+//   1  the same with plain stores
+//   2  the prediction kernels' own shape: one wave = 512 contiguous bytes per store (8 bytes per lane, nt), each
+//      workgroup walking its own contiguous 64 KiB piece
+template <int SHAPE>
+__global__ __launch_bounds__(256) void pmx_fill_linear(double* __restrict__ dst, int64_t n_pairs, double v) {
+  typedef double dbl2 __attribute__((ext_vector_type(2)));
+  if constexpr (SHAPE == 2) {
+    constexpr int64_t kPiece = 8192;  // doubles per workgroup piece
+    const int64_t n = n_pairs * 2;
+    for (int64_t base = static_cast<int64_t>(blockIdx.x) * kPiece; base < n; base += static_cast<int64_t>(gridDim.x) * kPiece) {
+#pragma unroll 4
+      for (int64_t i = threadIdx.x; i < kPiece; i += 256)
+        if (base + i < n) __builtin_nontemporal_store(v, dst + base + i);
+    }
+  } else {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
+    dbl2 vv;
+    vv.x = v;
+    vv.y = v;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n_pairs; i += stride) {
+      if constexpr (SHAPE == 0)
+        __builtin_nontemporal_store(vv, reinterpret_cast<dbl2*>(dst) + i);
+      else
+        reinterpret_cast<dbl2*>(dst)[i] = vv;
+    }
+  }
+}
+}  // namespace
+
+hipError_t launch_fill_linear(double* d_dst, int64_t n_doubles, double v, void* stream, int shape) {
+  const int64_t n_pairs = n_doubles / 2;
+  if (n_pairs <= 0) return hipSuccess;
+  int64_t blocks = shape == 2 ? (n_doubles + 8191) / 8192 : (n_pairs + 255) / 256;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  const dim3 g(static_cast<uint32_t>(blocks)), b(256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (shape == 0) hipLaunchKernelGGL(pmx_fill_linear<0>, g, b, 0, st, d_dst, n_pairs, v);
+  if (shape == 1) hipLaunchKernelGGL(pmx_fill_linear<1>, g, b, 0, st, d_dst, n_pairs, v);
+  if (shape == 2) hipLaunchKernelGGL(pmx_fill_linear<2>, g, b, 0, st, d_dst, n_pairs, v);
+  return hipGetLastError();
+}
 
 hipError_t launch_status_any(const uint8_t* d_status, int64_t n, int32_t* d_flag, void* stream) {
   if (n <= 0) return hipSuccess;

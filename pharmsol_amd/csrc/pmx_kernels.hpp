@@ -77,6 +77,7 @@ struct LaunchArgs {
   int32_t use_classes;  // GRID analytical: run the classed kernel on cls.n_chunks, the generic one on the rest
   int32_t prop_slots;   // DYN GRID: LDS slots for kept propagators (OpStream::prop_cache_used; 0 = none)
   int32_t dyn_tile;     // DYN GRID with kept propagators: support points per block (0 = the default tile)
+  int32_t no_rates;     // the compiled stream holds no PROP with an active infusion (three-compartment DYN: matrix-free walker)
   int32_t tune_cpb;     // > 0: chunks per block of the classed kernel forced by PMX_TUNE_CPB (tuning experiments)
   int32_t tune_ll_old;  // != 0: PMX_TUNE_LL_OLD - the round-2 log-likelihood kernel for exact classes (A/B)
   DevClassPlan cls;
@@ -118,6 +119,9 @@ hipError_t launch_ll_prepare(const LLPrepareArgs& a);
 
 // *d_flag |= 1 iff any of the n status bytes is non-zero (the host forms' "did any pair fail", without copying the array)
 hipError_t launch_status_any(const uint8_t* d_status, int64_t n, int32_t* d_flag, void* stream);
+
+// a linear streaming fill of n_doubles (pmx_measure_write_ceiling)
+hipError_t launch_fill_linear(double* d_dst, int64_t n_doubles, double v, void* stream, int shape = 0);  // shape 0..2 (pmx_kernels.hip)
 
 // Enqueue the prediction kernel; *name receives a static string naming the kernel family.
 hipError_t launch_predict(const LaunchArgs& a, const char** name);

@@ -201,6 +201,7 @@ template <class M>
 __device__ __forceinline__ double ode_out(const DevModel& m, const OdeLane<M>& L,
                                           const double (&x)[M::NS], int outeq, double t) {
   if constexpr (M::CUSTOM) {
+    if (m.state_override >= 0) return select_state<M::NS>(x, m.state_override);  // (wave-uniform)
     double y[M::NOUT];
 #pragma unroll
     for (int o = 0; o < M::NOUT; ++o) y[o] = 0.0;

@@ -676,6 +676,105 @@ __device__ __forceinline__ bool three_direct(double k10, double k12, double k13,
   return ok;
 }
 
+// ---------------------------------------------------------------- rate-free segment of a covariate model, matrix-free
+// A covariate model rebuilds its propagator for (almost) every segment and applies it ONCE, so the nine matrix entries
+// (and the absorption vector) of three_direct are never needed as such.  With x' = -B x,
+//     B = [ ka    0     0     0  ]      (ABS: gut first; without absorption the lower-right 3 x 3 block)
+//         [-ka    K   -k21  -k31 ]      K = k10 + k12 + k13
+//         [ 0   -k12   k21    0  ]
+//         [ 0   -k13    0    k31 ]
+// exp(-B dt) x = p(B) x for the polynomial p that interpolates f(l) = exp(-l dt) on B's eigenvalues {l0, l1, l2 (, ka)}
+// (Lagrange-Sylvester; the same spectral sum as three_compartment_models.rs:47-77 / :218-236, regrouped).  In Newton form
+//     p(B) x = c0 x + c1 (B - l0) x + c2 (B - l1)(B - l0) x + c3 (B - l2)(B - l1)(B - l0) x,
+// c_k = f[l0..lk] the divided differences: three sparse matrix-vector products (13 instructions each) and six
+// differences whose reciprocals come from ONE Newton reciprocal of their product - about 100 vector instructions where
+// the table-free matrix form takes about 165, and 7 numbers to keep for a segment that repeats (l0..l2, c0..c3).
+// Conditioning is that of the partial-fraction form: both divide by the same eigenvalue gaps.
+template <bool ABS>
+struct ThreeNewton {
+  static constexpr int NC = ABS ? 4 : 3;
+  static constexpr int NKEEP = 3 + NC;
+  // keep = {l0, l1, l2, c0..}
+  __device__ __forceinline__ static bool make(double k10, double k12, double k13, double k21, double k31, double ka, double dt,
+                                              double (&keep)[NKEEP]) {
+    double le[3];
+    const bool ok = ThreeCore::eigen(k10, k12, k13, k21, k31, le);
+    // nodes in ASCENDING order (eigen returns l0 >= l1 >= l2): the slowest mode first.  In f64 against an 80-bit evaluation
+    // of the spectral sum, 3000 draws of the C5 parameter ranges: this order 1.8e-13 worst relative error (the partial-
+    // fraction form 2.4e-13), descending order 4.3e-12.
+    const double l[3] = {le[2], le[1], le[0]};
+    const double dts = dt * kNegLog2e;  // exp(-l dt) = 2^(l dts)
+    const double d01 = l[1] - l[0], d12 = l[2] - l[1], d02 = l[2] - l[0];
+    keep[0] = l[0];
+    keep[1] = l[1];
+    keep[2] = l[2];
+    if constexpr (ABS) {
+      const double t4[4] = {l[0] * dts, l[1] * dts, l[2] * dts, ka * dts};
+      double e[4];
+      pmx_exp2_n<4>(t4, e);
+      const double d23 = ka - l[2], d13 = ka - l[1], d03 = ka - l[0];
+      // six reciprocals from one: pair products, the reciprocal of all six, then peel
+      const double p1 = d01 * d12, p2 = d23 * d02, p3 = d13 * d03;
+      const double p23 = p2 * p3, p13 = p1 * p3, p12 = p1 * p2;
+      const double R = pmx_rcp(p1 * p23);
+      const double i1 = R * p23, i2 = R * p13, i3 = R * p12;  // 1/p1, 1/p2, 1/p3
+      const double r01 = i1 * d12, r12 = i1 * d01, r23 = i2 * d02, r02 = i2 * d23, r13 = i3 * d03, r03 = i3 * d13;
+      const double f01 = (e[1] - e[0]) * r01, f12 = (e[2] - e[1]) * r12, f23 = (e[3] - e[2]) * r23;
+      const double f012 = (f12 - f01) * r02, f123 = (f23 - f12) * r13;
+      keep[3] = e[0];
+      keep[4] = f01;
+      keep[5] = f012;
+      keep[6] = (f123 - f012) * r03;
+    } else {
+      const double t3[3] = {l[0] * dts, l[1] * dts, l[2] * dts};
+      double e[3];
+      pmx_exp2_n<3>(t3, e);
+      const double q12 = d12 * d02, q02 = d01 * d02, q01 = d01 * d12;
+      const double R = pmx_rcp(d01 * q12);
+      const double r01 = R * q12, r12 = R * q02, r02 = R * q01;
+      const double f01 = (e[1] - e[0]) * r01, f12 = (e[2] - e[1]) * r12;
+      keep[3] = e[0];
+      keep[4] = f01;
+      keep[5] = (f12 - f01) * r02;
+    }
+    return ok;
+  }
+  // w <- (B - n) w on the three-compartment block (c, p2, p3) + (ABS) the gut in front
+  __device__ __forceinline__ static void shift_mul(double k12, double k13, double k21, double k31, double K, double ka, double n,
+                                                   double& g, double& c, double& p2, double& p3) {
+    double nc = fma(K - n, c, -(k21 * p2));
+    nc = fma(-k31, p3, nc);
+    if constexpr (ABS) nc = fma(-ka, g, nc);
+    const double n2 = fma(k21 - n, p2, -(k12 * c));
+    const double n3 = fma(k31 - n, p3, -(k13 * c));
+    if constexpr (ABS) g = (ka - n) * g;
+    c = nc;
+    p2 = n2;
+    p3 = n3;
+  }
+  // x <- p(B) x
+  __device__ __forceinline__ static void apply(double k10, double k12, double k13, double k21, double k31, double ka,
+                                               const double (&keep)[NKEEP], double& g, double& c, double& p2, double& p3) {
+    const double K = k10 + k12 + k13;
+    double wg = g, wc = c, w2 = p2, w3 = p3;
+    double yg = 0.0, yc = keep[3] * wc, y2 = keep[3] * w2, y3 = keep[3] * w3;
+    if constexpr (ABS) yg = keep[3] * wg;
+#pragma unroll
+    for (int k = 1; k < NC; ++k) {
+      shift_mul(k12, k13, k21, k31, K, ka, keep[k - 1], wg, wc, w2, w3);
+      const double ck = keep[3 + k];
+      if constexpr (ABS) yg = fma(ck, wg, yg);
+      yc = fma(ck, wc, yc);
+      y2 = fma(ck, w2, y2);
+      y3 = fma(ck, w3, y3);
+    }
+    g = yg;
+    c = yc;
+    p2 = y2;
+    p3 = y3;
+  }
+};
+
 template <>
 struct Structure<S_THREE> {
   static constexpr int NS = 3;
@@ -701,6 +800,15 @@ struct Structure<S_THREE> {
   __device__ __forceinline__ static bool make_prop_dyn(const double* kp, double dt, Prop& p) {
     double ea_unused, g_unused[3];
     return three_direct<false, WITH_J>(kp[0], kp[1], kp[2], kp[3], kp[4], 0.0, dt, p.p, ea_unused, g_unused);
+  }
+  // rate-free segment, matrix-free (ThreeNewton): what to keep for a repeat, and the step itself
+  static constexpr int ND0 = ThreeNewton<false>::NKEEP;
+  __device__ __forceinline__ static bool direct0_make(const double* kp, double dt, double (&keep)[ND0]) {
+    return ThreeNewton<false>::make(kp[0], kp[1], kp[2], kp[3], kp[4], 0.0, dt, keep);
+  }
+  __device__ __forceinline__ static void direct0_apply(const double* kp, const double (&keep)[ND0], double (&x)[NS]) {
+    double g_unused = 0.0;
+    ThreeNewton<false>::apply(kp[0], kp[1], kp[2], kp[3], kp[4], 0.0, keep, g_unused, x[0], x[1], x[2]);
   }
   __device__ __forceinline__ static void apply(const Prop& q, double (&x)[NS], double r) {
     const ThreeProp& p = q.p;
@@ -776,6 +884,13 @@ struct Structure<S_THREE_ABS> {
   __device__ __forceinline__ static bool make_prop_dyn(const double* kp, double dt, Prop& p) {
     return three_direct<true, WITH_J>(kp[1], kp[2], kp[3], kp[4], kp[5], kp[0], dt, p.p, p.ea, p.g);
   }
+  static constexpr int ND0 = ThreeNewton<true>::NKEEP;
+  __device__ __forceinline__ static bool direct0_make(const double* kp, double dt, double (&keep)[ND0]) {
+    return ThreeNewton<true>::make(kp[1], kp[2], kp[3], kp[4], kp[5], kp[0], dt, keep);
+  }
+  __device__ __forceinline__ static void direct0_apply(const double* kp, const double (&keep)[ND0], double (&x)[NS]) {
+    ThreeNewton<true>::apply(kp[1], kp[2], kp[3], kp[4], kp[5], kp[0], keep, x[0], x[1], x[2], x[3]);
+  }
   __device__ __forceinline__ static void apply(const Prop& q, double (&x)[NS], double r) {
     const ThreeProp& p = q.p;
     const double g = x[0];
@@ -825,6 +940,15 @@ __device__ __forceinline__ void ladder_pow(double (&e)[NE], uint32_t n) {
     e[i] = (n == 2u) ? sq : ((n == 3u) ? sq * b : sq * sq);
   }
 }
+
+// structures with the matrix-free rate-free step (direct0_make / direct0_apply)
+template <int ST>
+inline constexpr bool kHasDirect0 =
+#ifdef PMX_NO_DIRECT0
+    false;
+#else
+    (ST == S_THREE || ST == S_THREE_ABS);
+#endif
 
 // covariate-derived rate constants: prepare + make for ONE segment.  Structures with a fused form provide
 // make_prop_dyn; the others go through their Coef.

@@ -406,6 +406,9 @@ class Analytical(Equation):
         j <- ``("p", k)`` theta[k] or ``("d", k)`` derived[k] (default: the leading parameters).  Closures the source
         leaves out fall back to the index forms (``out`` / ``init`` / ``lag`` / ``fa``) of ``Analytical.new``."""
         m = Analytical()
+        if eq is not None and eq.startswith("pm_"):  # Pmetrics 1-indexed wrapper around the structure (analytical/mod.rs:62-90)
+            m.pmetrics = True
+            eq = eq[3:]
         m.kernel_name = eq or "custom"
         if eq is not None and eq not in _abi.ANALYTICAL_KERNELS:
             raise KeyError(f"unknown analytical structure '{eq}'")

@@ -81,7 +81,7 @@ def test_descriptor_rules_for_custom_models():
     h = C.c_void_p()
     assert _ffi.lib().pmx_model_create(C.byref(d), C.byref(h)) == _abi.PMX_ERR_INVALID_ARGUMENT  # needs the source
     d.pmetrics_indexing = 1
-    assert _ffi.lib().pmx_model_create_custom(C.byref(d), ONE_CMT.encode(), 0, C.byref(h)) == _abi.PMX_ERR_UNSUPPORTED
+    assert _ffi.lib().pmx_model_create_custom(C.byref(d), ONE_CMT.encode(), 0, C.byref(h)) == _abi.PMX_ERR_INVALID_ARGUMENT
     d = m.desc()
     d.rk4_h_max = 0.0
     assert _ffi.lib().pmx_model_create_custom(C.byref(d), ONE_CMT.encode(), 0, C.byref(h)) == _abi.PMX_ERR_INVALID_ARGUMENT

@@ -197,9 +197,9 @@ def test_model_validation_errors():
     assert create(d) == _abi.PMX_OK  # lag time: merged per lane on the device
     d.lag_param[1] = 9
     assert create(d) == _abi.PMX_ERR_INVALID_ARGUMENT
-    d = models.readme_analytical().desc()  # covariate-derived rate constant + lag: not on the device path yet
+    d = models.readme_analytical().desc()  # covariate-derived rate constant + lag: the closure walker, derive written out
     d.lag_param[0] = 0
-    assert create(d) == _abi.PMX_ERR_UNSUPPORTED
+    assert create(d) == _abi.PMX_OK
     d = models.handwritten_ode("one_cmt_iv", 0, 2).desc()
     d.lag_param[0] = 1
     assert create(d) == _abi.PMX_OK  # ODE lag: RK4 pieces split per lane on the device

@@ -98,3 +98,65 @@ def test_every_declared_function_is_bound_and_exported():
     assert consts["PMX_ABI_VERSION"] == _abi.PMX_ABI_VERSION == _ffi.lib().pmx_abi_version()
     for k in ("PMX_ERR_PAIR_FAILED", "PMX_PAIR_BAD_LAG", "PMX_K_CUSTOM", "PMX_FN_EQ", "PMX_CENSOR_ALOQ", "PMX_MAX_PARAMS"):
         assert consts[k] == getattr(_abi, k), k
+
+
+# --------------------------------------------------------------------------- the safe layer (bindings/rust/hip.rs)
+HIP_RS = os.path.join(ROOT, "bindings", "rust", "hip.rs")
+
+
+def _split_args(s):
+    """Top-level comma split of a call's argument text."""
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur)
+    return out
+
+
+def _call_args(text, start):
+    """Argument text of the call whose '(' is at `start`."""
+    depth = 0
+    for i in range(start, len(text)):
+        depth += text[i] == "("
+        depth -= text[i] == ")"
+        if depth == 0:
+            return text[start + 1:i]
+    raise AssertionError("unbalanced call")
+
+
+def test_safe_layer_calls_match_the_raw_binding():
+    """hip.rs cannot be compiled here (no rustc): every pmx_* call names a bound function with the declared number of
+    arguments, every PMX_* constant exists, and the pmx_population_desc literal names each field once, in order."""
+    rs = open(RS).read()
+    arity = {}
+    for m in re.finditer(r"pub fn (pmx_\w+)\((.*?)\)(?: -> [^;]+)?;", rs):
+        arity[m.group(1)] = len(_split_args(m.group(2)))
+    structs, funcs, consts = parse_rs()
+    code = "\n".join(ln.split("//")[0] for ln in open(HIP_RS).read().splitlines())  # comments dropped
+    n_calls = 0
+    for m in re.finditer(r"\b(pmx_[a-z_0-9]+)\(", code):
+        name = m.group(1)
+        assert name in arity, f"hip.rs calls {name}, which pmx_sys.rs does not declare"
+        got = len(_split_args(_call_args(code, m.end() - 1)))
+        assert got == arity[name], f"{name}: hip.rs passes {got} arguments, the binding declares {arity[name]}"
+        n_calls += 1
+    assert n_calls >= 20
+    for name in set(re.findall(r"\b(PMX_[A-Z_0-9]+)\b", code)):
+        assert name in consts, f"hip.rs uses {name}, which pmx_sys.rs does not define"
+    lit = re.search(r"pmx_population_desc \{\n(.*?)\n        \}", code, flags=re.S)
+    fields = re.findall(r"^\s+(\w+):", lit.group(1), flags=re.M)
+    assert fields == [f for f, _ in structs["pmx_population_desc"]]
+    for m in re.finditer(r"pmx_error_model \{([^}]*)\}", code):
+        assert [f.split(":")[0].strip() for f in _split_args(m.group(1))] == [f for f, _ in structs["pmx_error_model"]]
+    # every struct type the layer names is a struct (or opaque handle) of the raw binding
+    for t in set(re.findall(r"\b(pmx_[a-z_]+)\b(?!\()", code)) - set(arity) - {"pmx_sys", "pmx_hip"}:
+        assert re.search(r"pub struct %s\b" % t, rs), t
