@@ -815,6 +815,11 @@ pmx::CompileKey key_for(const pmx_model* m) {
       k.class_g = (st == pmx::S_ONE || st == pmx::S_ONE_ABS || st == pmx::S_TWO) ? 8 : 4;  // == ClassBatch<KID>::G
     }
     // covariate models that take the generic walker: equal (length, factors) PROPs of an occasion share a propagator
+    if (m->dyn && k.lag_mask == 0 && k.class_g == 0 && (st == pmx::S_THREE || st == pmx::S_THREE_ABS) && !m->d.pmetrics_indexing) {
+      k.kfac_n = pmx::kernel_nparams(m->d.kernel);  // (the matrix-free walker, pmx_analytical_dyn3)
+      for (int j = 0; j < k.kfac_n && j < 8; ++j)
+        k.kfac_map[j] = (m->d.n_bind > 0 && m->d.bind[j].src == PMX_SRC_DERIVED) ? static_cast<int8_t>(m->d.bind[j].index) : int8_t(-1);
+    }
     if (m->dyn && k.lag_mask == 0 && k.class_g == 0) {
       k.prop_cache_slots = tun.prop_slots >= 0 ? (tun.prop_slots > 3 ? 3 : tun.prop_slots) : 1;
       // the kept propagators live in LDS, [slot][component][256 lanes]: stay inside the 64 KB a block may take without an
@@ -902,6 +907,22 @@ int32_t get_stream(pmx_population* pop, const pmx::CompileKey& key, DeviceStream
     if ((rc = upload(rec, &ds->dev.op_rec, &ds->allocs)) != PMX_OK) return rc;
   }
   if ((rc = upload(os.op_fac, &ds->dev.op_fac, &ds->allocs)) != PMX_OK) return rc;
+  if (key.kfac_n > 0 && !os.op_fac.empty()) {  // one 64-byte record per op for the matrix-free walker (DevOps::op_kfac)
+    const size_t n_ops = os.op_meta.size();
+    const size_t fw = static_cast<size_t>(key.n_derived) * PMX_MAX_FACTORS;
+    std::vector<double> kf(n_ops * 8, 1.0);
+    for (size_t o = 0; o < n_ops; ++o) {
+      for (int j = 0; j < key.kfac_n && j < 7; ++j) {
+        const int dd = key.kfac_map[j];
+        if (dd < 0 || dd >= key.n_derived) continue;
+        double f = 1.0;  // the parameter's factors multiplied out: theta * (f0 * f1) for the descriptor's (theta * f0) * f1
+        for (int q = 0; q < key.derived[dd].n_factors && q < PMX_MAX_FACTORS; ++q) f *= os.op_fac[o * fw + static_cast<size_t>(dd) * PMX_MAX_FACTORS + q];
+        kf[o * 8 + j] = f;
+      }
+      kf[o * 8 + 7] = os.op_a[o];
+    }
+    if ((rc = upload(kf, &ds->dev.op_kfac, &ds->allocs)) != PMX_OK) return rc;
+  }
   if ((rc = upload(os.op_t0, &ds->dev.op_t0, &ds->allocs)) != PMX_OK) return rc;
   if ((rc = upload(os.op_t1, &ds->dev.op_t1, &ds->allocs)) != PMX_OK) return rc;
   if ((rc = upload(os.lagb_off, &ds->dev.lagb_off, &ds->allocs)) != PMX_OK) return rc;
@@ -1234,7 +1255,7 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
   }
   // the stream's codes were written for key.prop_cache_slots slots; the kernel decodes them with the same number
   a.prop_slots = ds->prop_cache_used > 0 ? ds->key.prop_cache_slots : 0;
-  a.no_rates = (ds->no_rates && d.eq_kind == PMX_EQ_ANALYTICAL && std::getenv("PMX_DISABLE_DYN3") == nullptr) ? 1 : 0;
+  a.no_rates = (ds->no_rates && d.eq_kind == PMX_EQ_ANALYTICAL && ds->dev.op_kfac != nullptr && std::getenv("PMX_DISABLE_DYN3") == nullptr) ? 1 : 0;
   a.dyn_tile = tunables().dyn_tile;  // (0 = the default tile; 64 and 256 measured the same with one slot)
   DeviceStream::LLCache* slot = nullptr;
   struct SlotGuard {  // the slot is released (event recorded on the stream) however this function leaves

@@ -83,6 +83,9 @@ struct CompileKey {
   int32_t prop_cache_slots = 0;  // covariate-derived rate constants: PROP ops of one occasion with the same (length,
                                  // covariate factors) have the same propagator; bits 24-26 of such ops say
                                  // "compute and keep in slot k" / "take slot k" (prop_cache_codes, pmx_compile.cpp)
+  // three-compartment covariate models: op_kfac rows (DevOps) are built for this kernel-parameter -> derived-value map
+  int32_t kfac_n = 0;                 // kernel parameters (0 = no op_kfac)
+  int8_t kfac_map[8] = {-1, -1, -1, -1, -1, -1, -1, -1};  // derived index behind kernel parameter j, -1 = a primary parameter
   bool ladder = false;     // analytical, theta-only coefficients, no lag: PROP ops carry the exponential-ladder code
                            // (bits 27-29 of op_meta, pmx_structures.hpp ladder_pow)
   bool operator==(const CompileKey& o) const {
@@ -90,7 +93,7 @@ struct CompileKey {
            n_rate == o.n_rate && rate_input == o.rate_input && class_g == o.class_g && lag_mask == o.lag_mask &&
            ladder == o.ladder && want_times == o.want_times && lag_merge == o.lag_merge && solve_marks == o.solve_marks &&
            full_rates == o.full_rates && user_cov == o.user_cov && prop_cache_slots == o.prop_cache_slots &&
-           n_derived == o.n_derived &&
+           n_derived == o.n_derived && kfac_n == o.kfac_n && std::memcmp(kfac_map, o.kfac_map, sizeof(kfac_map)) == 0 &&
            std::memcmp(derived, o.derived, sizeof(derived)) == 0;
   }
 };

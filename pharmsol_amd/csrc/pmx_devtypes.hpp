@@ -54,6 +54,10 @@ struct DevOps {
                                 //   instead of up to five scattered array reads.  ODE: [n_ops][6] = {meta | n << 32
                                 //   (bits), a, b, rate[0], t0, t1}; analytical: [n_ops][4] = {meta (bits), a, b, t0}
   const double* op_fac;         // [n_ops*n_derived*PMX_MAX_FACTORS] covariate factors of the derived values (host-evaluated)
+  const double* op_kfac;        // three-compartment covariate models (pmx_analytical_dyn3): one 64-byte record per op,
+                                //   [n_ops][8] = {covariate factor of kernel parameter 0..6 (1.0 = none; a parameter's
+                                //   factors multiplied out), op_a} - ONE wide scalar fetch per op, requested an op ahead
+                                //   (nullptr = none)
   const double* op_t0;          // lag models: absolute start of each PROP / first event time of a RESET's occasion
   const double* op_t1;          // lag models: absolute end of each PROP
   const int64_t* lagb_off;      // [(n_occasions*n_lag_slots)+1]

@@ -53,6 +53,16 @@ __device__ __forceinline__ double apply_factors(const DevModel& m, int d, double
   return v;
 }
 
+// wide wave-uniform fetches through the scalar unit, placed where they are written (volatile: the compiler neither
+// moves nor merges them, and tracks their completion itself)
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+template <class V>
+__device__ __forceinline__ V sload_here(const void* p_) {
+  const void* p = reinterpret_cast<const void*>(uniform64(reinterpret_cast<int64_t>(p_)));  // (wave-uniform: a scalar address)
+  return *(const volatile __attribute__((address_space(4))) V*)(p);
+}
+
 // Everything a lane needs besides its state; filled once per lane.
 template <int KID>
 struct LaneModel {
@@ -423,15 +433,25 @@ __global__ __launch_bounds__(kBlock, PMX_DYN3_WAVES) void pmx_analytical_dyn3(De
   const auto c_subj_op_off = as_const(ops.subj_op_off);
   const auto c_subj_obs_off = as_const(ops.subj_obs_off);
   const auto c_op_meta = as_const(ops.op_meta);
-  const auto c_op_a = as_const(ops.op_a);
 
   const int64_t s_begin = chunk * s_chunk;
   const int64_t s_end = (s_begin + s_chunk < S) ? (s_begin + s_chunk) : S;
+  // An op = its 4-byte meta word + its 64-byte record {factor of kernel parameter 0..6, op_a} (DevOps::op_kfac), both
+  // requested ONE OP AHEAD: a scalar fetch of a line nobody touched before costs about a microsecond, and with one in
+  // front of every rebuild the walker waited on the scalar cache more than it computed.  Without a subject list the
+  // stream is walked in order, so the look-ahead runs across subjects (a subject's last op requests the next one's first).
+  const bool chained = subj_list == nullptr;
+  uint32_t meta_n = 0u;
+  u32x16 rec_n = {};
   for (int64_t si = s_begin; si < s_end; ++si) {
     const int64_t s = subj_list ? static_cast<int64_t>(as_const(subj_list)[si]) : si;
     const int64_t o0 = c_subj_op_off[s];
     const int64_t o1 = c_subj_op_off[s + 1];
     int64_t row = c_subj_obs_off[s];
+    if ((!chained || si == s_begin) && o0 < o1) {
+      meta_n = sload_here<uint32_t>(ops.op_meta + o0);
+      rec_n = sload_here<u32x16>(ops.op_kfac + o0 * 8);
+    }
     double x[NS];
 #pragma unroll
     for (int i = 0; i < NS; ++i) x[i] = 0.0;
@@ -444,17 +464,34 @@ __global__ __launch_bounds__(kBlock, PMX_DYN3_WAVES) void pmx_analytical_dyn3(De
       if (zl < 8u && zp < P) *reinterpret_cast<uint64_t*>(status + s * P + zp) = 0ull;
     }
     for (int64_t o = o0; o < o1; ++o) {
-      const uint32_t meta = c_op_meta[o];
+      uint32_t meta = meta_n;
+      u32x16 rec = rec_n;
+      asm volatile("" : "+s"(meta), "+s"(rec));  // (this op's words are in scalar registers from here on)
+      {
+        int64_t on = o + 1;
+        if (on >= o1 && (!chained || si + 1 >= s_end)) on = o;  // nothing follows: request this op again
+        meta_n = sload_here<uint32_t>(ops.op_meta + on);
+        rec_n = sload_here<u32x16>(ops.op_kfac + on * 8);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       const uint32_t kind = meta & 0xffu;
       const int io = static_cast<int>((meta >> 8) & 0xffffu);
-      const double a = c_op_a[o];
-      const double* cov = ops.op_fac + o * (m.n_derived * PMX_MAX_FACTORS);
+      auto rec_f64 = [&rec](int k) {
+        return __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(rec[2 * k + 1]) << 32) | rec[2 * k]));
+      };
+      const double a = rec_f64(7);
+      const double* cov = ops.op_fac + o * (m.n_derived * PMX_MAX_FACTORS);  // (derived volumes: lane_out)
       if (kind == OP_PROP) {
         // bits 24-26: 0 = build; 1 + k = build and keep in slot k; 1 + S + k = take slot k (pmx_compile.cpp)
         const uint32_t rc = (meta >> 24) & 7u;
         const uint32_t n_slots = static_cast<uint32_t>(prop_slots);
         double q[LM::NKP], keep[ND0];
-        lane_params_dyn<KID>(m, L, cov, q);
+        {
+          double kp[LM::NKP];
+#pragma unroll
+          for (int j = 0; j < LM::NKP; ++j) kp[j] = L.kp_base[j] * rec_f64(j);
+          to_native_params<KID>(kp, q);
+        }
         if (rc > n_slots) {
 #pragma unroll
           for (int k = 0; k < ND0; ++k) keep[k] = prop_cache[((rc - 1u - n_slots) * ND0 + k) * tile + threadIdx.x];
@@ -1199,13 +1236,6 @@ __device__ uint64_t g_ll_stamps[5];  // diagnostic build only (tools/ll_stamps.p
 // optimiser, and a scheduling barrier behind it keeps the instruction scheduler from moving it either.  (The waits are the
 // compiler's own: it knows these registers are pending.  An earlier form issued the fetches from inline assembly - faster
 // to write, but the register allocator may spill or copy an output it believes is already there.)
-typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
-typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
-template <class V>
-__device__ __forceinline__ V sload_here(const void* p_) {
-  const void* p = reinterpret_cast<const void*>(uniform64(reinterpret_cast<int64_t>(p_)));  // (wave-uniform: a scalar address)
-  return *(const volatile __attribute__((address_space(4))) V*)(p);
-}
 template <int G>
 struct ObsRequest;
 template <>

@@ -455,8 +455,8 @@ struct ThreeCore {
     const double n = (2.0 * (a * a * a) - 9.0 * a * b + 27.0 * cc) * (1.0 / 27.0);
     const double q = (n * n) * 0.25 + (m * m * m) * (1.0 / 27.0);
     const bool ok = !(q > 0.0);  // reference panics on q > 0 (:32-34)
-    const double alpha = sqrt(-q);
-    const double beta = -0.5 * n;
+    auto beta_of = [](double nn) { return -0.5 * nn; };
+    (void)beta_of;
     // The reference takes gamma = |beta + i alpha|, theta = atan2(alpha, beta), gamma^(1/3) and cos/sin(theta/3)
     // (:36-45), i.e. the principal cube root z = cr (cs + i sn) of w = beta + i alpha.  Three f64 transcendentals
     // per segment dominate a covariate model's cost, so z is seeded in single precision and polished with two
@@ -465,7 +465,57 @@ struct ThreeCore {
     // min/max (Abramowitz & Stegun 4.4.49, 2e-8) plus two reflections; theta/3 <= pi/3 goes straight to the hardware
     // sine/cosine.  Outside the float range the f64 functions are used directly.
     const double p3 = -m * (1.0 / 3.0);  // gamma^(2/3)
+#ifndef PMX_EIGEN_ZDOMAIN
+    // Real-root form (the default): with x = -lambda the reference's cubic is x^3 + a x^2 + b x + c, depressed by
+    // x = t - a/3 to t^3 + m t + n = 0, whose roots are t_k = 2 sqrt(p3) cos((theta - 2 pi k) / 3) - the same angle theta.
+    // The trigonometric seed is taken in single precision (alpha = sqrt(-q) included: no f64 square root at all) and two
+    // of the roots are polished by Newton steps on the depressed cubic itself, t <- t - f(t) / f'(t) with the quotient's
+    // reciprocal in single precision (the correction only needs its leading digits); the third follows from
+    // t0 + t1 + t2 = 0.  Polished: the middle root (it can be near zero) and the largest (the SMALLEST eigenvalue, the one
+    // whose relative accuracy the long segments feel); derived: the most negative one, the largest in magnitude.  Against an
+    // 80-bit evaluation over the C5 parameter ranges two steps reach 1e-15 / 5e-14 / 3e-12 relative (largest / middle /
+    // smallest eigenvalue; the last is the cancellation in a/3 - t every formula shares), a third changes nothing.
+    if (p3 > 1.0e-20 && p3 < 1.0e20) {
+      const float af = __builtin_amdgcn_sqrtf(static_cast<float>(-q)), bf = static_cast<float>(beta_of(n));
+      const float ax = fabsf(bf);
+      const float mx = fmaxf(ax, af), mn = fminf(ax, af);
+      const float t = mn * __builtin_amdgcn_rcpf(mx);
+      const float s2 = t * t;
+      float pl = 0.0028662257f;
+      pl = fmaf(pl, s2, -0.0161657367f);
+      pl = fmaf(pl, s2, 0.0429096138f);
+      pl = fmaf(pl, s2, -0.0752896400f);
+      pl = fmaf(pl, s2, 0.1065626393f);
+      pl = fmaf(pl, s2, -0.1420889944f);
+      pl = fmaf(pl, s2, 0.1999355085f);
+      pl = fmaf(pl, s2, -0.3333314528f);
+      float thf = fmaf(pl * s2, t, t);
+      thf = (af > ax) ? (1.57079632679f - thf) : thf;
+      thf = (bf < 0.0f) ? (3.14159265359f - thf) : thf;
+      const float ph = thf * (1.0f / 3.0f);
+      const float crf = __builtin_amdgcn_sqrtf(static_cast<float>(p3));
+      const float zrf = crf * __cosf(ph), zif = crf * __sinf(ph);
+      double t2 = static_cast<double>(2.0f * zrf);                      // in [cr, 2 cr]
+      double t1 = static_cast<double>(fmaf(1.7320508f, zif, -zrf));    // in [-cr, cr]
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const double g1 = fma(t1, t1, m), g2 = fma(t2, t2, m);
+        const double f1 = fma(g1, t1, n), f2 = fma(g2, t2, n);
+        const double d1 = fma(2.0 * t1, t1, g1), d2 = fma(2.0 * t2, t2, g2);  // 3 t^2 + m
+        t1 = fma(-f1, static_cast<double>(__builtin_amdgcn_rcpf(static_cast<float>(d1))), t1);
+        t2 = fma(-f2, static_cast<double>(__builtin_amdgcn_rcpf(static_cast<float>(d2))), t2);
+      }
+      const double a3 = a * (1.0 / 3.0);
+      l[0] = a3 + (t1 + t2);  // a/3 - t0,  t0 = -(t1 + t2)
+      l[1] = a3 - t1;
+      l[2] = a3 - t2;
+      return ok;
+    }
+#endif
+    const double alpha = sqrt(-q);
+    const double beta = -0.5 * n;
     double zr, zi;
+#ifdef PMX_EIGEN_ZDOMAIN
     if (p3 > 1.0e-20 && p3 < 1.0e20) {
       const float af = static_cast<float>(alpha), bf = static_cast<float>(beta);
       const float ax = fabsf(bf);
@@ -500,7 +550,9 @@ struct ThreeCore {
         zr = (2.0 * zr + qr) * (1.0 / 3.0);
         zi = (2.0 * zi + qi) * (1.0 / 3.0);
       }
-    } else {
+    } else
+#endif
+    {
       const double gamma = sqrt(beta * beta + alpha * alpha);
       const double theta = atan2(alpha, beta);
       const double cr = cbrt(gamma);  // reference: gamma.powf(1.0/3.0)

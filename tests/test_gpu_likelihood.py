@@ -97,7 +97,7 @@ def test_covariate_model_c5():
     rng = np.random.default_rng(3)
     m, flat, theta = synth.config_c5(120, 64)
     flat = with_observed_values(m, flat, theta[:1], rng)
-    assert_ll_parity(m, flat, EM_ADD, theta, expect_kernel="pmx_analytical_grid<dyn>")
+    assert_ll_parity(m, flat, EM_ADD, theta, expect_kernel="pmx_analytical_dyn3")
 
 
 def test_ode_model():

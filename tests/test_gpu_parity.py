@@ -95,14 +95,14 @@ def test_c4_at_its_full_size_every_prediction():
 @pytest.mark.parametrize("cov_time", ["segment_dt", "segment_end_abs"])
 def test_c5_three_compartment_absorption_time_varying_wt(cov_time):
     m, flat, theta = synth.config_c5(300, 512, cov_time)
-    assert_parity(m, flat, theta, TOL_ANALYTICAL, expect_kernel="pmx_analytical_grid<dyn>")
+    assert_parity(m, flat, theta, TOL_ANALYTICAL, expect_kernel="pmx_analytical_dyn3")
 
 
 def test_c5_subject_constant_covariate():
     # one wt value per subject (the usual allometric-scaling case) and a mix of constant and interpolated subjects
     m = synth.model_three_cpt_abs_wt()
     flat = synth.population_c5(300, constant_wt=True)
-    assert_parity(m, flat, synth.theta_c5(512), TOL_ANALYTICAL, expect_kernel="pmx_analytical_grid<dyn>")
+    assert_parity(m, flat, synth.theta_c5(512), TOL_ANALYTICAL, expect_kernel="pmx_analytical_dyn3")
 
 
 @pytest.mark.parametrize("structure,params,states,central", [
@@ -601,7 +601,7 @@ def test_c5_full_size_properties():
     pop = runtime.DevicePopulation(flat, 0)
     pred, status = runtime.predict(m, pop, theta)
     torch.cuda.synchronize()
-    assert runtime.last_kernel_name() == "pmx_analytical_grid<dyn>"
+    assert runtime.last_kernel_name() == "pmx_analytical_dyn3"
     assert int(status.max().item()) == 0 and bool(torch.isfinite(pred).all().item())
     pr = pred.view(200_000, 10, 512)
     idx = np.sort(np.random.default_rng(1).choice(200_000, size=48, replace=False))
