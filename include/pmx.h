@@ -522,8 +522,9 @@ int32_t pmx_loglik_batch_device(const pmx_model* model, const pmx_population* po
                                 const double* d_theta, double* d_ll, uint8_t* d_status, void* stream);
 
 /* The device's write ceiling as measured, for roofline reports: average rate (GB/s, HIP events on `stream`) of `reps`
- * linear streaming fills of d_buf[0 .. n_doubles), after one untimed fill - the best of three store shapes (16 bytes per
- * lane non-temporal / plain, and the prediction kernels' own 512 contiguous bytes per wave).  The buffer's contents are
+ * linear streaming fills of d_buf[0 .. n_doubles), after one untimed fill - the best of four store shapes (16 bytes per
+ * lane non-temporal / plain in a grid-stride loop, the prediction kernels' own 512 contiguous bytes per wave, and one
+ * 16-byte store per lane with no loop - the fastest on the boxes measured, tools/fill_probe.hip).  The buffer's contents are
  * overwritten with zeros.  bench.py prints it as roofline.attainable beside the 8 TB/s datasheet peak. */
 int32_t pmx_measure_write_ceiling(double* d_buf, int64_t n_doubles, int32_t reps, void* stream, double* gb_per_s);
 

@@ -857,8 +857,16 @@ pmx::CompileKey key_for(const pmx_model* m) {
 }
 
 // Find or build (compile + upload) the device op stream for this model flavour.
-int32_t get_stream(pmx_population* pop, const pmx::CompileKey& key, DeviceStream** out) {
+int32_t get_stream(pmx_population* pop, const pmx::CompileKey& key_in, DeviceStream** out) {
   std::lock_guard<std::mutex> lock(pop->mu);
+  pmx::CompileKey key = key_in;
+  if (key.kfac_n > 0 && key.prop_cache_slots == 1 && tunables().prop_slots < 0 && std::getenv("PMX_DISABLE_DYN3") == nullptr) {
+    // a population without infusions takes the matrix-free walker, whose kept segment is 6-7 numbers per lane: two slots
+    // fit where the matrix form held one (C5: 8 rebuilds per subject instead of 9)
+    bool infusions = false;
+    for (uint8_t kd : pop->hp.ev_kind) infusions |= (kd == PMX_EV_INFUSION);
+    if (!infusions) key.prop_cache_slots = 2;
+  }
   for (auto& s : pop->streams)
     if (s->key == key) {
       *out = s.get();
@@ -1779,7 +1787,7 @@ int32_t pmx_measure_write_ceiling(double* d_buf, int64_t n_doubles, int32_t reps
   PMX_HIP(hipEventCreate(&e1));
   hipError_t e = hipSuccess;
   float best_ms = 0.0f;
-  for (int shape = 0; shape < 3 && e == hipSuccess; ++shape) {  // the best of three store shapes (pmx_kernels.hip)
+  for (int shape = 0; shape < 4 && e == hipSuccess; ++shape) {  // the best of four store shapes (pmx_kernels.hip)
     e = pmx::launch_fill_linear(d_buf, n_doubles, 0.0, stream, shape);  // untimed
     if (e == hipSuccess) e = hipEventRecord(e0, st);
     for (int32_t i = 0; i < reps && e == hipSuccess; ++i) e = pmx::launch_fill_linear(d_buf, n_doubles, 0.0, stream, shape);

@@ -169,6 +169,25 @@ __device__ __forceinline__ double lane_out(const DevModel& m, const LaneModel<KI
   return xs * inv;
 }
 
+// The same for a compile-time output O behind a wave-uniform branch on the op's output index (the lane-valued volume
+// terms need no select chain then); no pm_ pad slot.
+template <int KID, int O>
+__device__ __forceinline__ double lane_out_at(const DevModel& m, const LaneModel<KID>& L, const double (&x)[LaneModel<KID>::NS],
+                                              const double* cov) {
+  using LM = LaneModel<KID>;
+  const double xs = select_state<LM::NS>(x, m.out[O].state);
+  if (m.out[O].vol_src == PMX_SRC_DERIVED) return xs * pmx_rcp(apply_factors(m, m.out[O].vol_index, L.vol_base[O], cov));
+  return xs * L.inv_vol[O];
+}
+template <int KID>
+__device__ __forceinline__ double lane_out_uniform(const DevModel& m, const LaneModel<KID>& L,
+                                                   const double (&x)[LaneModel<KID>::NS], int outeq, const double* cov) {
+  static_assert(PMX_MAX_OUT == 4, "one branch per output");
+  if (outeq == 0) return lane_out_at<KID, 0>(m, L, x, cov);
+  if (outeq == 1) return lane_out_at<KID, 1>(m, L, x, cov);
+  if (outeq == 2) return lane_out_at<KID, 2>(m, L, x, cov);
+  return lane_out_at<KID, 3>(m, L, x, cov);
+}
 
 // (lag / bioavailability helpers shared with the ODE back-end: pmx_device.hpp)
 
@@ -443,14 +462,37 @@ __global__ __launch_bounds__(kBlock, PMX_DYN3_WAVES) void pmx_analytical_dyn3(De
   const bool chained = subj_list == nullptr;
   uint32_t meta_n = 0u;
   u32x16 rec_n = {};
+  // ... and so does the subject's header {first op, end op, first row}: the next subject's end op and first row are
+  // requested while this one is walked (its first op is this one's end op)
+  int64_t o0_n = 0, o1_n = 0, row_n = 0;
+  bool primed = false;
+  if (chained && s_begin < s_end) {
+    o0_n = sload_here<int64_t>(ops.subj_op_off + s_begin);
+    o1_n = sload_here<int64_t>(ops.subj_op_off + s_begin + 1);
+    row_n = sload_here<int64_t>(ops.subj_obs_off + s_begin);
+  }
   for (int64_t si = s_begin; si < s_end; ++si) {
     const int64_t s = subj_list ? static_cast<int64_t>(as_const(subj_list)[si]) : si;
-    const int64_t o0 = c_subj_op_off[s];
-    const int64_t o1 = c_subj_op_off[s + 1];
-    int64_t row = c_subj_obs_off[s];
-    if ((!chained || si == s_begin) && o0 < o1) {
+    int64_t o0, o1, row;
+    if (chained) {
+      o0 = o0_n;
+      o1 = o1_n;
+      row = row_n;
+      asm volatile("" : "+s"(o0), "+s"(o1), "+s"(row));
+      const int64_t sn = (si + 1 < s_end) ? s + 1 : s;  // (the last subject of the block requests itself again)
+      o0_n = o1;
+      o1_n = sload_here<int64_t>(ops.subj_op_off + sn + 1);
+      row_n = sload_here<int64_t>(ops.subj_obs_off + sn);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      o0 = c_subj_op_off[s];
+      o1 = c_subj_op_off[s + 1];
+      row = c_subj_obs_off[s];
+    }
+    if ((!chained || !primed) && o0 < o1) {  // (chained: once, at the block's first subject that has any op)
       meta_n = sload_here<uint32_t>(ops.op_meta + o0);
       rec_n = sload_here<u32x16>(ops.op_kfac + o0 * 8);
+      primed = true;
     }
     double x[NS];
 #pragma unroll
@@ -504,7 +546,7 @@ __global__ __launch_bounds__(kBlock, PMX_DYN3_WAVES) void pmx_analytical_dyn3(De
         }
         LM::S::direct0_apply(q, keep, x);
       } else if (kind == OP_OBS) {
-        double y = lane_out<KID>(m, L, x, 0.0, io, cov);
+        double y = lane_out_uniform<KID>(m, L, x, io, cov);
         if (st == PMX_PAIR_COMPLEX_ROOTS) y = nanv;
         if constexpr (LL) {
           ll_accumulate(as_const(ops.ll_obs) + row * 4, y, ll_acc);
@@ -2159,11 +2201,12 @@ __global__ __launch_bounds__(256) void pmx_status_any(const uint8_t* __restrict_
 
 namespace {
 // Streaming fills: what the device's write path takes when nothing else is asked of it (the measured ceiling bench.py
-// prints beside the 8 TB/s datasheet peak: roofline.attainable).  Three shapes, the entry point reports the best:
+// prints beside the 8 TB/s datasheet peak: roofline.attainable).  Four shapes, the entry point reports the best:
 //   0  grid-stride, 16 bytes per lane, streaming (nt) stores
 //   1  the same with plain stores
 //   2  the prediction kernels' own shape: one wave = 512 contiguous bytes per store (8 bytes per lane, nt), each
 //      workgroup walking its own contiguous 64 KiB piece
+//   3  shape 0 without the loop: one store per lane, as many workgroups as that takes
 template <int SHAPE>
 __global__ __launch_bounds__(256) void pmx_fill_linear(double* __restrict__ dst, int64_t n_pairs, double v) {
   typedef double dbl2 __attribute__((ext_vector_type(2)));
@@ -2194,7 +2237,12 @@ hipError_t launch_fill_linear(double* d_dst, int64_t n_doubles, double v, void* 
   const int64_t n_pairs = n_doubles / 2;
   if (n_pairs <= 0) return hipSuccess;
   int64_t blocks = shape == 2 ? (n_doubles + 8191) / 8192 : (n_pairs + 255) / 256;
-  if (blocks > 256 * 64) blocks = 256 * 64;
+  if (shape == 3) {  // one 16-byte streaming store per lane, no loop: the fastest of the shapes tried (tools/fill_probe.hip:
+    shape = 0;       // 6.7 TB/s where the grid-stride forms reach 5.6-6.2 and hipMemsetAsync 6.4)
+    if (blocks > 0x7fffffff) blocks = 0x7fffffff;
+  } else if (blocks > 256 * 64) {
+    blocks = 256 * 64;
+  }
   const dim3 g(static_cast<uint32_t>(blocks)), b(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (shape == 0) hipLaunchKernelGGL(pmx_fill_linear<0>, g, b, 0, st, d_dst, n_pairs, v);

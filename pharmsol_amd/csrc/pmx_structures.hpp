@@ -497,13 +497,24 @@ struct ThreeCore {
       const float zrf = crf * __cosf(ph), zif = crf * __sinf(ph);
       double t2 = static_cast<double>(2.0f * zrf);                      // in [cr, 2 cr]
       double t1 = static_cast<double>(fmaf(1.7320508f, zif, -zrf));    // in [-cr, cr]
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
+      // (one Newton step, then two chord steps on the same slope: the seed is good to ~1e-6, so f' moved by that much and
+      // each chord step gains another ~5 digits - 80-bit check as above: 1e-15 / 5e-14 / 3e-12, where a single chord step
+      // leaves 9e-11 on the smallest eigenvalue.  Two quarter-rate reciprocals less than a second Newton step.)
+      double i1, i2;
+      {
         const double g1 = fma(t1, t1, m), g2 = fma(t2, t2, m);
         const double f1 = fma(g1, t1, n), f2 = fma(g2, t2, n);
         const double d1 = fma(2.0 * t1, t1, g1), d2 = fma(2.0 * t2, t2, g2);  // 3 t^2 + m
-        t1 = fma(-f1, static_cast<double>(__builtin_amdgcn_rcpf(static_cast<float>(d1))), t1);
-        t2 = fma(-f2, static_cast<double>(__builtin_amdgcn_rcpf(static_cast<float>(d2))), t2);
+        i1 = static_cast<double>(__builtin_amdgcn_rcpf(static_cast<float>(d1)));
+        i2 = static_cast<double>(__builtin_amdgcn_rcpf(static_cast<float>(d2)));
+        t1 = fma(-f1, i1, t1);
+        t2 = fma(-f2, i2, t2);
+      }
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const double f1 = fma(fma(t1, t1, m), t1, n), f2 = fma(fma(t2, t2, m), t2, n);
+        t1 = fma(-f1, i1, t1);
+        t2 = fma(-f2, i2, t2);
       }
       const double a3 = a * (1.0 / 3.0);
       l[0] = a3 + (t1 + t2);  // a/3 - t0,  t0 = -(t1 + t2)
@@ -745,8 +756,8 @@ __device__ __forceinline__ bool three_direct(double k10, double k12, double k13,
 template <bool ABS>
 struct ThreeNewton {
   static constexpr int NC = ABS ? 4 : 3;
-  static constexpr int NKEEP = 3 + NC;
-  // keep = {l0, l1, l2, c0..}
+  static constexpr int NKEEP = 3 + NC + (ABS ? 1 : 0);
+  // keep = {l0, l1, l2, c0.. (, exp(-ka dt): the gut decouples, its own step is that one product)}
   __device__ __forceinline__ static bool make(double k10, double k12, double k13, double k21, double k31, double ka, double dt,
                                               double (&keep)[NKEEP]) {
     double le[3];
@@ -777,6 +788,7 @@ struct ThreeNewton {
       keep[4] = f01;
       keep[5] = f012;
       keep[6] = (f123 - f012) * r03;
+      keep[7] = e[3];
     } else {
       const double t3[3] = {l[0] * dts, l[1] * dts, l[2] * dts};
       double e[3];
@@ -799,7 +811,7 @@ struct ThreeNewton {
     if constexpr (ABS) nc = fma(-ka, g, nc);
     const double n2 = fma(k21 - n, p2, -(k12 * c));
     const double n3 = fma(k31 - n, p3, -(k13 * c));
-    if constexpr (ABS) g = (ka - n) * g;
+    if constexpr (ABS) g = (ka - n) * g;  // (feeds nc of the NEXT product: the gut's own result is taken from exp(-ka dt))
     c = nc;
     p2 = n2;
     p3 = n3;
@@ -810,12 +822,11 @@ struct ThreeNewton {
     const double K = k10 + k12 + k13;
     double wg = g, wc = c, w2 = p2, w3 = p3;
     double yg = 0.0, yc = keep[3] * wc, y2 = keep[3] * w2, y3 = keep[3] * w3;
-    if constexpr (ABS) yg = keep[3] * wg;
+    if constexpr (ABS) yg = keep[NKEEP - 1] * wg;  // p(B) x restricted to the gut = p(ka) g = exp(-ka dt) g
 #pragma unroll
     for (int k = 1; k < NC; ++k) {
       shift_mul(k12, k13, k21, k31, K, ka, keep[k - 1], wg, wc, w2, w3);
       const double ck = keep[3 + k];
-      if constexpr (ABS) yg = fma(ck, wg, yg);
       yc = fma(ck, wc, yc);
       y2 = fma(ck, w2, y2);
       y3 = fma(ck, w3, y3);

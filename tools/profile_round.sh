@@ -24,7 +24,7 @@ for mode in placed first; do
   st=$(find $OUT/trace_$mode -name "*kernel_stats.csv" | head -1); cp "$st" $OUT/kernel_stats_$mode.csv
 done
 unset PMX_TUNE_PLACE_WINDOW
-for w in "c3:" "c5:--workload c5" "c3_ragged:--ragged" "c4:--workload c4" "user:--workload user"; do
+for w in "c3:" "c5:--workload c5" "c3_ragged:--ragged" "c3_generic:--no-class" "c3_loglik:--loglik" "c3_ragged_loglik:--ragged --loglik" "c4:--workload c4" "user:--workload user"; do
   key=${w%%:*}; args=${w#*:}
   tools/pmc_run.sh $OUT/pmc_$key $args > $OUT/pmc_$key.log 2>&1; echo "pmc $key rc=$?"
   python3 tools/pmc_summary.py $OUT/pmc_$key $OUT/pmc_$key.json > $OUT/pmc_$key.txt
