@@ -84,7 +84,9 @@ def parse_args(argv=None):
                     help="C3 with per-subject jittered sampling times (no shared design, no related step lengths)")
     ap.add_argument("--constant-cov", action="store_true",
                     help="c5: one wt value per subject instead of 2-4 interpolation knots")
-    ap.add_argument("--ld", type=int, default=0, help="leading dimension of the prediction rows (>= support points; 0 = dense)")
+    ap.add_argument("--ld", type=int, default=0,
+                    help="row pitch of the prediction matrix in doubles (>= support points).  0 = the library's recommendation "
+                         "(pmx_recommended_ld: rows start on 128-byte boundaries; 1000 -> 1008), -1 = dense rows + the arena search")
     ap.add_argument("--no-class", action="store_true",
                     help="A/B: disable the classed kernel (shared-design propagator reuse); every subject walks the generic kernel")
     ap.add_argument("--dry-run", action="store_true",
@@ -226,6 +228,7 @@ def main():
     steps_per_pass_local = flat.n_events * (1 if batch else P)
 
     kernel_name, placed = "", "first allocation"
+    row_pitch = None
     pass_ms, first_alloc_ms = [], None
     elapsed = 0.0
     pred = None
@@ -260,7 +263,11 @@ def main():
         d_theta = torch.as_tensor(np.ascontiguousarray(theta), device=dev)
         n_obs = pop.n_observations
         out_shape = (n_obs,) if batch else ((pop.n_subjects, P) if args.loglik else (n_obs, P))
-        ld = max(args.ld, P) if (args.ld and not batch and not args.loglik) else None
+        ld = None
+        if not batch and not args.loglik and args.ld >= 0:
+            ld = max(args.ld, P) if args.ld else runtime.recommended_ld(P)
+            if ld == P:
+                ld = None  # (already a multiple of 16: the dense path)
         # (N > 1: no placement search - eight ranks each timing 100 GiB of arena windows would say more about the search
         # than about the path; every rank writes into a plain allocation, what a caller's own buffer gets)
         want_placement = (world == 1 and not batch and not args.loglik and args.place_gib > 0 and ld is None and
@@ -309,8 +316,33 @@ def main():
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) / reps
 
-        if ld is not None:  # rows padded to a leading dimension (ld_pred of pmx_predict_device); same bytes written
+        row_pitch = (ld if (ld is not None and not want_gather) else P) if not (batch or args.loglik) else None
+        if ld is not None and not want_gather:
+            # rows padded to a pitch (ld_pred of pmx_predict_device; the same bytes are written, the padding never is).
+            # N = 1: the first plain allocation of the process is what a caller's own buffer gets (`frac_first_allocation`);
+            # --alloc-tries - 1 more are timed with the real kernel during set-up, all alive at once so that each sits on
+            # different memory, and the fastest is kept (where the matrix lands in HBM moves the row-strided stream by up to
+            # 25 %)
             pred = torch.empty((n_obs, ld), dtype=torch.float64, device=dev)[:, :P]
+            placed = "one plain allocation, rows padded to %d doubles" % ld
+            if world == 1 and n_obs * P * 8 > (1 << 28) and args.alloc_tries > 1 and args.place_gib > 0:
+                spin_up(pred)
+                first_alloc_ms = best_ms = ms_into(pred)
+                held, n_plain = [pred], 1
+                for _ in range(args.alloc_tries - 1):
+                    try:
+                        cand = torch.empty((n_obs, ld), dtype=torch.float64, device=dev)[:, :P]
+                    except RuntimeError:
+                        break
+                    held.append(cand)
+                    n_plain += 1
+                    ms_c = ms_into(cand, reps=6)
+                    if ms_c < best_ms:
+                        pred, best_ms = cand, ms_c
+                del held
+                cand = None
+                torch.cuda.empty_cache()
+                placed = "best of %d plain allocations, rows padded to %d doubles (pmx_recommended_ld)" % (n_plain, ld)
         elif want_placement:
             # Where the matrix lands in HBM changes the write rate of the row-strided stream by up to 25 %, and which memory
             # is the fast kind differs from box to box.  Candidates, all timed with the real kernel
@@ -399,6 +431,8 @@ def main():
             from pharmsol_amd import _ffi
             gbs = C.c_double()
             flat_out = pred if pred.is_contiguous() else None
+            if flat_out is None and getattr(pred, "_base", None) is not None and pred._base.is_contiguous():
+                flat_out = pred._base  # (rows padded to a pitch: the whole allocation, padding included)
             if flat_out is not None:
                 # (the fill overwrites the buffer: one more kernel pass below restores what the parity sample reads)
                 _ffi.check(_ffi.lib().pmx_measure_write_ceiling(flat_out.data_ptr(), int(flat_out.numel()), 5,
@@ -571,7 +605,7 @@ def main():
             "config": {"workload": label, "subjects_per_gpu": flat.n_subjects if strong else S_arg, "support_points": P,
                        "steps_per_pass": steps_per_pass, "kernel": kernel_name,
                        "status_bytes_written": not args.no_status,
-                       "prediction_buffer": placed, "sharding": f"subjects x{world}, no data-path collective",
+                       "prediction_buffer": placed, "row_pitch_doubles": row_pitch, "sharding": f"subjects x{world}, no data-path collective",
                        "backend": backend if world > 1 else None,
                        "rccl_ranks": (dist.get_world_size() if (world > 1 and backend == "nccl") else None)},
             "max_rel_err_vs_cpu_ref": max_rel_err, "rel_err_tolerance": dtype_tol, "parity_ok": parity_ok,

@@ -67,6 +67,7 @@ SYMBOLS = [
     ("pmx_loglik_batch", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("pmx_loglik_batch_device", C.c_int32,
      [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("pmx_recommended_ld", C.c_int64, [C.c_int64]),
     ("pmx_measure_write_ceiling", C.c_int32, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.POINTER(C.c_double)]),
     ("pmx_host_alloc", C.c_int32, [C.c_int64, C.POINTER(C.c_void_p)]),
     ("pmx_host_free", None, [C.c_void_p]),

@@ -1778,6 +1778,8 @@ int32_t pmx_loglik_batch_device(const pmx_model* model, const pmx_population* cp
   return enqueue(model, pop, d_theta, 1, 1, d_ll, 1, d_status, stream, &req);
 }
 
+int64_t pmx_recommended_ld(int64_t n_support) { return n_support <= 0 ? 0 : (n_support + 15) / 16 * 16; }
+
 int32_t pmx_measure_write_ceiling(double* d_buf, int64_t n_doubles, int32_t reps, void* stream, double* gb_per_s) {
   g_err.clear();
   if (!d_buf || !gb_per_s || n_doubles < 2 || reps < 1) return fail(PMX_ERR_INVALID_ARGUMENT, "bad argument");

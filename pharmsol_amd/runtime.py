@@ -159,6 +159,11 @@ def place_predictions(model, pop: DevicePopulation, theta, search_gib: float = 4
     return t
 
 
+def recommended_ld(n_support: int) -> int:
+    """Row pitch (doubles) at which the prediction kernels write fastest (``pmx_recommended_ld``: 128-byte row starts)."""
+    return int(_ffi.lib().pmx_recommended_ld(int(n_support)))
+
+
 def predict_states(model, pop: DevicePopulation, theta, states=None):
     """``Prediction::state`` (likelihood/prediction.rs:18-27) for every observation: a CUDA tensor
     ``[n_observations, len(states), n_support]`` (default: all model states), one ``pmx_predict_state_device`` call
