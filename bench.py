@@ -298,7 +298,7 @@ def main():
 
         def spin_up(out=None):
             # untimed back-to-back passes: after the set-up phase (allocations, frees, host work) the device sits idle for
-            # a while and comes back with reduced clocks (profiles/r01_dispatch_ramp.txt)
+            # a while and comes back with reduced clocks (profiles/r01/dispatch_ramp.txt)
             t_spin = time.perf_counter()
             while time.perf_counter() - t_spin < args.spin_up_ms * 1e-3:
                 for _ in range(8):

@@ -522,7 +522,7 @@ int32_t pmx_loglik_batch_device(const pmx_model* model, const pmx_population* po
                                 const double* d_theta, double* d_ll, uint8_t* d_status, void* stream);
 
 /* Row pitch (ld_pred, in doubles) at which the prediction kernels write fastest: n_support rounded up to a multiple of 16,
- * so every row starts on a 128-byte boundary.  Measured on C3 (profiles/r03_ld_by_allocation.txt): 1000 -> 1008 doubles
+ * so every row starts on a 128-byte boundary.  Measured on C3 (profiles/r03/ld_by_allocation.txt): 1000 -> 1008 doubles
  * gives 6.45 -> 6.8 TB/s in fast allocations and 5.3 -> 5.5 in slow ones; a pitch that is a multiple of 8 but not 16
  * doubles is slower than the dense one.  The padding doubles are never written. */
 int64_t pmx_recommended_ld(int64_t n_support);
@@ -530,7 +530,7 @@ int64_t pmx_recommended_ld(int64_t n_support);
 /* The device's write ceiling as measured, for roofline reports: average rate (GB/s, HIP events on `stream`) of `reps`
  * linear streaming fills of d_buf[0 .. n_doubles), after one untimed fill - the best of four store shapes (16 bytes per
  * lane non-temporal / plain in a grid-stride loop, the prediction kernels' own 512 contiguous bytes per wave, and one
- * 16-byte store per lane with no loop - the fastest on the boxes measured, tools/fill_probe.hip).  The buffer's contents are
+ * 16-byte store per lane with no loop - the fastest on the boxes measured, tools/experiments/fill_probe.hip).  The buffer's contents are
  * overwritten with zeros.  bench.py prints it as roofline.attainable beside the 8 TB/s datasheet peak. */
 int32_t pmx_measure_write_ceiling(double* d_buf, int64_t n_doubles, int32_t reps, void* stream, double* gb_per_s);
 

@@ -1,7 +1,7 @@
 // pmx_alloc.cpp — placing the prediction matrix where the row-strided write stream runs fastest.
 //
 // On MI355X the rate of the prediction stream depends on WHERE in device memory the matrix sits (the same kernel:
-// 0.81-0.90 ms in some 5.6 GB windows, 1.04-1.12 ms in most; linear fills do not care; tools/store_pattern_probe.hip
+// 0.81-0.90 ms in some 5.6 GB windows, 1.04-1.12 ms in most; linear fills do not care; tools/experiments/store_pattern_probe.hip
 // `arena`).  Nothing in the HIP API says which memory is the fast kind, so this helper measures: it maps
 // an arena out of separately allocated physical chunks (HIP virtual-memory API) window by window, times the real kernel
 // into each, stops inside the first plateau of the fast kind (or at the arena's size limit, with the best window seen),

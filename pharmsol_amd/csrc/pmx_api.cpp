@@ -182,7 +182,7 @@ int32_t set_error(int32_t code, const std::string& msg) { return fail(code, msg)
 // What the HOST-pointer entry points (pmx_predict, pmx_predict_batch, pmx_loglik, pmx_loglik_batch) keep between
 // calls, per population: device buffers for theta / output / status (grown, never shrunk), a private stream pair and
 // two pinned bounce buffers.  An NPAG loop calls these entry points thousands of times; allocating, page-locking and
-// freeing per call cost ~700x the kernel (profiles/r01_pcie_inclusive.txt).  Calls on one population take turns.
+// freeing per call cost ~700x the kernel (profiles/r01/pcie_inclusive.txt).  Calls on one population take turns.
 struct HostWorkspace {
   std::mutex mu;
   hipStream_t compute = nullptr, copy = nullptr;
@@ -967,7 +967,7 @@ int32_t get_stream(pmx_population* pop, const pmx::CompileKey& key_in, DeviceStr
     pmx::ClassPlan cp;
     const Tunables tun = tunables();  // (tuning experiments)
     const int32_t min_class = tun.min_class > 0 ? tun.min_class : key.class_g / 2;
-    const bool spread = tun.spread < 0 ? true : tun.spread != 0;  // (0.94-0.97 vs 1.05-1.11 ms on C3 in most allocations, never slower: tools/alloc_tune.py)
+    const bool spread = tun.spread < 0 ? true : tun.spread != 0;  // (0.94-0.97 vs 1.05-1.11 ms on C3 in most allocations, never slower: tools/experiments/alloc_tune.py)
     const bool loose = tun.loose < 0 ? true : tun.loose != 0;  // subjects without a shared design still share a program shape: batched with per-member step lengths
     pmx::build_class_plan(pop->hp, os, key.class_g, min_class, &cp, key.ladder, spread, loose);
     if (cp.n_chunks > 0) {
@@ -1237,7 +1237,7 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
   }
   a.ops = ds->dev;
   {
-    // ODE PAIR kernel, steps per trip of the lane state machine (pmx_ode.hpp ode_pair_body): tools/steps_per_trip_sweep.sh
+    // ODE PAIR kernel, steps per trip of the lane state machine (pmx_ode.hpp ode_pair_body): tools/experiments/steps_per_trip_sweep.sh
     const int64_t n_pairs = batch ? pop->hp.n_subjects : pop->hp.n_subjects * P;
     const int32_t spt_tuned = tunables().steps_per_trip;
     a.ops.steps_per_trip = spt_tuned > 0 ? spt_tuned : (n_pairs <= 131072 ? 48 : 32);
@@ -1288,7 +1288,7 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
       if (llreq->em[q].kind >= PMX_EM_RES_CONSTANT) a.ll_censored = 1;  // residual models fold from the full records too
   }
   // GRID (lane = support point, wave-uniform op stream) vs PAIR (lane = pair, divergent streams): measured crossovers
-  // (tools/pairgrid_sweep.sh) are 8 support points when the classed kernel serves most subjects, ~48 when every
+  // (tools/experiments/pairgrid_sweep.sh) are 8 support points when the classed kernel serves most subjects, ~48 when every
   // subject goes through the generic walker (a GRID wave with few live lanes still pays the whole walk); ODE: 32.
   int64_t grid_min_p = 32;
   if (d.eq_kind == PMX_EQ_ANALYTICAL)

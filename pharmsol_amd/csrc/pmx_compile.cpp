@@ -775,7 +775,7 @@ void build_class_plan(const HostPopulation& hp, const OpStream& os, int32_t G, i
     // Which members share a chunk is free (any G subjects of the class may share a propagator).  `spread`: member j of
     // chunk c is the (c + j * n_chunks)-th subject of the class, so the G rows a block writes at one step are far
     // apart while neighbouring blocks write neighbouring subjects: G slowly advancing write fronts instead of every
-    // block covering its own 8-subject region (tools/store_pattern_probe.hip, rows B vs H).
+    // block covering its own 8-subject region (tools/experiments/store_pattern_probe.hip, rows B vs H).
     const size_t n_chunks_cls = (mem.size() + static_cast<size_t>(G) - 1) / static_cast<size_t>(G);
     std::vector<int32_t> pick(static_cast<size_t>(G));
     for (size_t c = 0; c < n_chunks_cls; ++c) {

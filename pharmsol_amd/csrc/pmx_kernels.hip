@@ -754,7 +754,7 @@ __device__ __forceinline__ void classed_emit(const double (&x)[G][NS], double in
         dbl2 vv;
         vv.x = v.x;
         vv.y = v.y;
-        // streaming store, cache policy `sc1 nt` (tools/store_pattern_probe.hip: plain 1.23 ms, nt 1.12, sc1 nt 1.07
+        // streaming store, cache policy `sc1 nt` (tools/experiments/store_pattern_probe.hip: plain 1.23 ms, nt 1.12, sc1 nt 1.07
         // for this address map); no builtin carries sc1, hence the asm
         asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(dst), "v"(vv) : "memory");
       }
@@ -1878,12 +1878,12 @@ hipError_t launch_analytical(const LaunchArgs& a, const char** name) {
       if (a.use_classes && a.cls.n_chunks > 0) {
         *name = "pmx_analytical_classed";
         // enough blocks to fill the chip several times over, few enough that lane_setup stays amortised
-        // (chunks are taken in grid-stride order; one chunk per block up to 32k blocks measured best: tools/cpb_on_one_allocation.py)
+        // (chunks are taken in grid-stride order; one chunk per block up to 32k blocks measured best: tools/experiments/cpb_on_one_allocation.py)
         // (the log-likelihood variant writes almost nothing: it prefers fewer, longer blocks that amortise the lane setup)
         const bool ll = a.ops.ll_obs != nullptr;
         const int64_t n_exact = a.cls.n_chunks_exact, n_loose = a.cls.n_chunks - a.cls.n_chunks_exact;
         // (the loose launch is FP64-bound too and behaves the same: 4 chunks per block 1.83 ms, one 1.88 ms, eight 1.84 ms
-        // on jittered C3, profiles/r02_loose_chunks_per_block.txt)
+        // on jittered C3, profiles/r02/loose_chunks_per_block.txt)
         auto blocks_for = [&](int64_t n, bool loose, int64_t* cpb_out) {
           int64_t cpb = (n * a.n_ptiles) / ((ll || loose) ? 8192 : 32768);
           if (cpb < 1) cpb = 1;
@@ -2237,7 +2237,7 @@ hipError_t launch_fill_linear(double* d_dst, int64_t n_doubles, double v, void* 
   const int64_t n_pairs = n_doubles / 2;
   if (n_pairs <= 0) return hipSuccess;
   int64_t blocks = shape == 2 ? (n_doubles + 8191) / 8192 : (n_pairs + 255) / 256;
-  if (shape == 3) {  // one 16-byte streaming store per lane, no loop: the fastest of the shapes tried (tools/fill_probe.hip:
+  if (shape == 3) {  // one 16-byte streaming store per lane, no loop: the fastest of the shapes tried (tools/experiments/fill_probe.hip:
     shape = 0;       // 6.7 TB/s where the grid-stride forms reach 5.6-6.2 and hipMemsetAsync 6.4)
     if (blocks > 0x7fffffff) blocks = 0x7fffffff;
   } else if (blocks > 256 * 64) {

@@ -717,7 +717,7 @@ __device__ __forceinline__ void ode_pair_body(const DevModel& m, const DevOps& o
     // Stepping phase
     if (ADAPT ? stepping : rem > 0) {
       // up to ops.steps_per_trip steps of the open piece: a trip through this state machine costs ~7 bare RK4 steps
-      // of dx/dt = -ke x + r (tools/rk4_latency_probe.hip: 46 ns/step for a lone wave, 333 ns/trip here), and a
+      // of dx/dt = -ke x + r (tools/experiments/rk4_latency_probe.hip: 46 ns/step for a lone wave, 333 ns/trip here), and a
       // batch of a few 10k pairs is one wave per SIMD, i.e. latency-bound.  Bounded, so a lane that needs its next
       // op waits for at most that many steps of its neighbours, not for the longest piece in the wave; the host
       // picks the bound from the batch size (pmx_api.cpp).

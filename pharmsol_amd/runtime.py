@@ -83,7 +83,7 @@ def alloc_predictions(model, pop: DevicePopulation, theta, tries: int = 4, reps:
     """A prediction matrix ``[n_observations, n_support]`` placed where the kernel writes fastest.
 
     The prediction stream is a row-strided scatter; on MI355X its rate depends on WHICH allocation it lands in
-    (tools/store_pattern_probe.hip ``alloc``, tools/alloc_tune.py: the same kernel takes 0.94-0.97 ms in most 5.6 GB
+    (tools/experiments/store_pattern_probe.hip ``alloc``, tools/experiments/alloc_tune.py: the same kernel takes 0.94-0.97 ms in most 5.6 GB
     allocations and 1.10-1.12 ms in others, stable for the life of the allocation).  This helper allocates up to
     ``tries`` candidates (all alive at once, so that each sits on different memory), times ``reps`` passes of the real
     kernel into each, keeps the fastest and frees the rest.  A caller reuses the returned buffer across passes."""

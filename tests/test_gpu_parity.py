@@ -679,7 +679,7 @@ def test_pmetrics_csv_population_end_to_end():
 
 def test_small_support_grids_pick_the_measured_lane_mapping():
     """Shared designs go through the classed GRID kernel from 8 support points (64-thread blocks), ragged ones switch
-    from PAIR to GRID at 48 (tools/pairgrid_sweep.sh); every mapping gives the same numbers."""
+    from PAIR to GRID at 48 (tools/experiments/pairgrid_sweep.sh); every mapping gives the same numbers."""
     rng = np.random.default_rng(101)
     m, flat, theta = synth.config_c3(120, 64)
     for n, kernel in ((4, "pmx_analytical_pair"), (8, "pmx_analytical_classed"), (33, "pmx_analytical_classed"),

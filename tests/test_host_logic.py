@@ -304,3 +304,10 @@ def test_prediction_stores_of_the_write_bound_kernels_stay_fire_and_forget():
     spec.loader.exec_module(g)
     n, bad = g.check(g.assembly())
     assert n == 24 and not bad, bad
+
+
+def test_recommended_row_pitch():
+    # include/pmx.h pmx_recommended_ld: rows start on 128-byte boundaries
+    from pharmsol_amd import runtime
+
+    assert [runtime.recommended_ld(n) for n in (0, 1, 16, 17, 512, 1000, 1008)] == [0, 16, 16, 32, 512, 1008, 1008]

@@ -1,5 +1,5 @@
 // Which store shape fills HBM fastest on this box?  (feeds pmx_measure_write_ceiling's choice of shapes)
-//   hipcc --offload-arch=gfx950 -O3 tools/fill_probe.hip -o /tmp/fill_probe && /tmp/fill_probe
+//   hipcc --offload-arch=gfx950 -O3 tools/experiments/fill_probe.hip -o /tmp/fill_probe && /tmp/fill_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>

@@ -3,7 +3,7 @@
 // 50k pairs.  Variants: 0 = x += (h/6)(...) with the division in the step (what the compiler sees when h is a
 // loop-carried per-lane value), 1 = h/6 hoisted, 2 = hoisted + 4 steps per trip, 3 = as 0 but behind the
 // state-machine shaped branch (rem > 0) with per-lane trip counts.
-// build: hipcc -O3 --offload-arch=gfx950 tools/rk4_latency_probe.hip -o tools/bin/rk4_latency_probe
+// build: hipcc -O3 --offload-arch=gfx950 tools/experiments/rk4_latency_probe.hip -o tools/bin/rk4_latency_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

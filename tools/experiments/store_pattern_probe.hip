@@ -1,7 +1,7 @@
 // store_pattern_probe.hip — which geometry of the prediction write stream does MI355X like?
 // Stand-alone micro-benchmark (not part of the library): writes the C3 prediction matrix
 // (700 000 rows x 1000 doubles = 5.6 GB) with different wave->address maps and prints TB/s for each.
-//   build: hipcc --offload-arch=gfx950 -O3 -o gpurun_out/store_probe tools/store_pattern_probe.hip
+//   build: hipcc --offload-arch=gfx950 -O3 -o gpurun_out/store_probe tools/experiments/store_pattern_probe.hip
 #include <hip/hip_runtime.h>
 
 #include <cstdint>

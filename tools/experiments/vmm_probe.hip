@@ -1,6 +1,6 @@
 // vmm_probe.hip — build device buffers with a chosen virtual alignment / physical chunk size / mapping order through the
-// HIP virtual-memory API, for the placement experiments of tools/vmm_probe.py (which times the real kernel into them).
-// hipcc -shared -fPIC --offload-arch=gfx950 -o tools/bin/libvmmprobe.so tools/vmm_probe.hip
+// HIP virtual-memory API, for the placement experiments of tools/experiments/vmm_probe.py (which times the real kernel into them).
+// hipcc -shared -fPIC --offload-arch=gfx950 -o tools/bin/libvmmprobe.so tools/experiments/vmm_probe.hip
 #include <hip/hip_runtime.h>
 
 #include <cstdint>

@@ -1,5 +1,5 @@
 """Placement experiments (DESIGN.md "Where the matrix lives"): C3 pass time of the real kernel into buffers built
-with a chosen virtual alignment / physical chunk size / mapping order (tools/vmm_probe.hip), next to plain hipMalloc.
+with a chosen virtual alignment / physical chunk size / mapping order (tools/experiments/vmm_probe.hip), next to plain hipMalloc.
 Question: is the two-speed behaviour of the row-strided write stream a matter of page-table fragments (TLB reach:
 amdgpu marks 2^k physically contiguous, equally aligned pages as one translation)?"""
 import ctypes as C, os, sys

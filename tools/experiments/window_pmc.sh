@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC counters of the headline kernel writing into a FAST and into a SLOW window of one placement arena (same box, same
 # process layout: the landscape of an arena is reproducible from process to process on one box).
-# usage: tools/window_pmc.sh <outdir> <arena GiB>
+# usage: tools/experiments/window_pmc.sh <outdir> <arena GiB>
 set -u
 export TMPDIR=/tmp
 OUT=$1; GIB=$2
