@@ -451,7 +451,6 @@ __global__ __launch_bounds__(kBlock, PMX_DYN3_WAVES) void pmx_analytical_dyn3(De
   const double nanv = __longlong_as_double(0x7ff8000000000000LL);
   const auto c_subj_op_off = as_const(ops.subj_op_off);
   const auto c_subj_obs_off = as_const(ops.subj_obs_off);
-  const auto c_op_meta = as_const(ops.op_meta);
 
   const int64_t s_begin = chunk * s_chunk;
   const int64_t s_end = (s_begin + s_chunk < S) ? (s_begin + s_chunk) : S;
