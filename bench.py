@@ -343,6 +343,21 @@ def main():
                 cand = None
                 torch.cuda.empty_cache()
                 placed = "best of %d plain allocations, rows padded to %d doubles (pmx_recommended_ld)" % (n_plain, ld)
+                # ... and the best window of an arena the library maps chunk by chunk and times window by window
+                # (pmx_prediction_buffer_create_pitched, exhaustive form): boxes exist where none of the plain allocations
+                # is of the fast kind (profiles/r03/bench_c3_box_without_a_fast_plain_allocation.json)
+                free_b, _tot = torch.cuda.mem_get_info(dev)
+                gib = min(args.place_gib, 0.75 * free_b / (1 << 30))
+                try:
+                    cand = runtime.place_predictions(model, pop, d_theta, search_gib=gib, exhaustive=True, ld=ld)
+                    if ms_into(cand) < best_ms:
+                        pred = cand
+                        placed = "best window of a %.0f GiB arena, rows padded to %d doubles (%.3f ms during the search)" % (
+                            gib, ld, cand._pmx_owner.ms_per_pass)
+                except Exception as e:  # no virtual-memory API / not enough memory
+                    placed += " (arena search failed: %s)" % type(e).__name__
+                cand = None
+                torch.cuda.empty_cache()
         elif want_placement:
             # Where the matrix lands in HBM changes the write rate of the row-strided stream by up to 25 %, and which memory
             # is the fast kind differs from box to box.  Candidates, all timed with the real kernel

@@ -222,13 +222,16 @@ typedef struct pmx_model_desc {
   double rk4_h_max;     /* ODE: fixed-step RK4, h = dt/ceil(dt/h_max) per constant-rate piece; adaptive: largest step */
   /* ODE solver (`ODE::with_solver` / `with_tolerances`, ode/mod.rs:134-166; the reference's diffsol solvers are
    * replaced: SURVEY.md §8 a23).  PMX_SOLVER_RK4 = the fixed-step default.  PMX_SOLVER_DOPRI5 = embedded
-   * Dormand-Prince 5(4) with step-size control per lane: err = rms(e_i / (atol + rtol max(|x_i|, |x'_i|))) <= 1. */
+   * Dormand-Prince 5(4) with step-size control per lane: err = rms(e_i / (atol + rtol max(|x_i|, |x'_i|))) <= 1.
+   * PMX_SOLVER_ROS2 = the stiff option (the role of the reference's default OdeSolver::Bdf / Sdirk, ode/mod.rs:60-77):
+   * ROS2, a second-order L-stable Rosenbrock method with the same per-lane step control (error estimate from its embedded
+   * first-order solution), Jacobian by forward differences, NS x NS elimination in registers (csrc/pmx_ode.hpp ros2_try). */
   int32_t ode_solver;
   int32_t reserved_;
   double ode_rtol, ode_atol;
 } pmx_model_desc;
 
-enum { PMX_SOLVER_RK4 = 0, PMX_SOLVER_DOPRI5 = 1 };
+enum { PMX_SOLVER_RK4 = 0, PMX_SOLVER_DOPRI5 = 1, PMX_SOLVER_ROS2 = 2 /* stiff: L-stable Rosenbrock, adaptive */ };
 
 typedef struct pmx_population pmx_population; /* opaque */
 typedef struct pmx_model pmx_model;           /* opaque */
@@ -346,6 +349,10 @@ int32_t pmx_time_predict_device(const pmx_model* model, const pmx_population* po
  * is restored on return).  Free with pmx_prediction_buffer_destroy. */
 int32_t pmx_prediction_buffer_create(const pmx_model* model, const pmx_population* pop, const double* d_theta,
                                      int64_t n_support, int64_t search_bytes, void* stream, double** d_pred,
+                                     double* ms_per_pass);
+/* ... with rows `ld` doubles apart (ld >= n_support; pmx_recommended_ld): [n_observations x ld] doubles are placed. */
+int32_t pmx_prediction_buffer_create_pitched(const pmx_model* model, const pmx_population* pop, const double* d_theta,
+                                     int64_t n_support, int64_t ld, int64_t search_bytes, void* stream, double** d_pred,
                                      double* ms_per_pass);
 void pmx_prediction_buffer_destroy(double* d_pred);
 

@@ -874,6 +874,68 @@ static double dopri5_try(const ctx_t* c, const double* x, const double* p, const
   return sqrt(acc / (double)ns);
 }
 
+/* ---- PMX_SOLVER_ROS2: the stiff option (the role of the reference's OdeSolver::Bdf / Sdirk, ode/mod.rs:60-77); ROS2
+ * (Verwer et al. 1999), same rule set as pmx_ode.hpp ros2_try: forward-difference Jacobian and time derivative,
+ * elimination in the natural order, error estimate from the embedded first-order solution. ------------------------- */
+static double ros2_try(const ctx_t* c, const double* x, const double* p, const double* rate, double t, double h,
+                       double* xn) {
+  const pmx_model_desc* m = c->m;
+  const int ns = m->nstates;
+  const double kGamma = 1.7071067811865475, kSqrtEps = 1.4901161193847656e-08;
+  const double gh = kGamma * h;
+  double f0[PMX_MAX_STATES], f1[PMX_MAX_STATES], xt[PMX_MAX_STATES], W[PMX_MAX_STATES][PMX_MAX_STATES],
+      ft[PMX_MAX_STATES], k1[PMX_MAX_STATES], k2[PMX_MAX_STATES];
+  ode_f(c, t, x, p, rate, f0);
+  for (int j = 0; j < ns; j++) {
+    for (int i = 0; i < ns; i++) xt[i] = x[i];
+    double d = kSqrtEps * fmax(fabs(x[j]), 1.0);
+    xt[j] = x[j] + d;
+    ode_f(c, t, xt, p, rate, f1);
+    double s = -gh / d;
+    for (int i = 0; i < ns; i++) W[i][j] = (f1[i] - f0[i]) * s + ((i == j) ? 1.0 : 0.0);
+  }
+  {
+    double dt = kSqrtEps * fmax(fabs(t), 1.0);
+    ode_f(c, t + dt, x, p, rate, f1);
+    double s = gh / dt;
+    for (int i = 0; i < ns; i++) ft[i] = (f1[i] - f0[i]) * s;
+  }
+  for (int k = 0; k < ns; k++) {
+    double inv = 1.0 / W[k][k];
+    for (int i = k + 1; i < ns; i++) {
+      double l = W[i][k] * inv;
+      W[i][k] = l;
+      for (int j = k + 1; j < ns; j++) W[i][j] -= l * W[k][j];
+    }
+    W[k][k] = inv;
+  }
+#define PMX_ROS2_SOLVE(b)                                          \
+  do {                                                             \
+    for (int i = 1; i < ns; i++)                                   \
+      for (int j = 0; j < i; j++) (b)[i] -= W[i][j] * (b)[j];      \
+    for (int i = ns - 1; i >= 0; i--) {                            \
+      for (int j = i + 1; j < ns; j++) (b)[i] -= W[i][j] * (b)[j]; \
+      (b)[i] *= W[i][i];                                           \
+    }                                                              \
+  } while (0)
+  for (int i = 0; i < ns; i++) k1[i] = f0[i] + ft[i];
+  PMX_ROS2_SOLVE(k1);
+  for (int i = 0; i < ns; i++) xt[i] = x[i] + h * k1[i];
+  ode_f(c, t + h, xt, p, rate, f1);
+  for (int i = 0; i < ns; i++) k2[i] = f1[i] - ft[i] - 2.0 * k1[i];
+  PMX_ROS2_SOLVE(k2);
+#undef PMX_ROS2_SOLVE
+  double acc = 0.0;
+  for (int i = 0; i < ns; i++) {
+    xn[i] = x[i] + h * (1.5 * k1[i] + 0.5 * k2[i]);
+    double e = (0.5 * h) * (k1[i] + k2[i]);
+    double sc = m->ode_atol + m->ode_rtol * fmax(fabs(x[i]), fabs(xn[i]));
+    double q = e / sc;
+    acc += q * q;
+  }
+  return sqrt(acc / (double)ns);
+}
+
 typedef struct {
   double h;
   int failed;
@@ -890,9 +952,10 @@ static void dopri5_piece(const ctx_t* c, double* x, const double* p, const doubl
     int clipped = h >= left;
     if (clipped) h = left;
     double xn[PMX_MAX_STATES];
-    double err = dopri5_try(c, x, p, rate, t, h, xn);
+    int stiff = m->ode_solver == PMX_SOLVER_ROS2;
+    double err = stiff ? ros2_try(c, x, p, rate, t, h, xn) : dopri5_try(c, x, p, rate, t, h, xn);
     int ok = err <= 1.0;
-    double fac = (err > 0.0) ? 0.9 * pow(err, -0.2) : 5.0;
+    double fac = (err > 0.0) ? 0.9 * pow(err, stiff ? -0.5 : -0.2) : 5.0;
     if (!(fac >= 0.2)) fac = 0.2;
     if (fac > 5.0) fac = 5.0;
     if (!ok && fac > 1.0) fac = 1.0;
@@ -1125,7 +1188,7 @@ static int simulate_pair(const pmx_model_desc* m, const pmx_population_desc* pop
               double s = sc->inf[k].time, en = s + sc->inf[k].duration;
               if (s <= t && t < en) rate[sc->inf[k].input] += sc->inf[k].amount / sc->inf[k].duration;
             }
-            if (m->ode_solver == PMX_SOLVER_DOPRI5)
+            if (m->ode_solver != PMX_SOLVER_RK4)
               dopri5_piece(&ctx, x, theta, rate, t, stop, &adapt);
             else
               rk4_piece(&ctx, x, theta, rate, t, stop);

@@ -103,7 +103,7 @@ ODE_MODELS = {
     "one_cmt_mm": 6,
 }
 PMX_ODE_CUSTOM = 100
-PMX_SOLVER_RK4, PMX_SOLVER_DOPRI5 = 0, 1
+PMX_SOLVER_RK4, PMX_SOLVER_DOPRI5, PMX_SOLVER_ROS2 = 0, 1, 2
 PMX_PAIR_SOLVER_FAIL = 4
 ODE_STATE_COUNT = {"one_cmt_iv": 1, "one_cmt_oral": 2, "two_cmt_iv": 2, "two_cmt_oral": 3, "three_cmt_iv": 3,
                    "three_cmt_oral": 4, "one_cmt_mm": 1}

@@ -53,6 +53,8 @@ SYMBOLS = [
      [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     ("pmx_prediction_buffer_create", C.c_int32,
      [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_double)]),
+    ("pmx_prediction_buffer_create_pitched", C.c_int32,
+     [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_double)]),
     ("pmx_prediction_buffer_destroy", None, [C.c_void_p]),
     ("pmx_time_predict_device", C.c_int32,
      [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.POINTER(C.c_double)]),

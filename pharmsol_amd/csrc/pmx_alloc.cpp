@@ -45,12 +45,12 @@ void release(Arena& a) {
 
 extern "C" {
 
-int32_t pmx_prediction_buffer_create(const pmx_model* model, const pmx_population* pop, const double* d_theta,
-                                     int64_t n_support, int64_t search_bytes, void* stream, double** d_pred,
+int32_t pmx_prediction_buffer_create_pitched(const pmx_model* model, const pmx_population* pop, const double* d_theta,
+                                     int64_t n_support, int64_t ld, int64_t search_bytes, void* stream, double** d_pred,
                                      double* ms_per_pass) {
-  if (!model || !pop || !d_theta || !d_pred || n_support <= 0) return PMX_ERR_INVALID_ARGUMENT;
+  if (!model || !pop || !d_theta || !d_pred || n_support <= 0 || ld < n_support) return PMX_ERR_INVALID_ARGUMENT;
   *d_pred = nullptr;
-  const size_t need = static_cast<size_t>(pmx_population_n_observations(pop)) * static_cast<size_t>(n_support) * sizeof(double);
+  const size_t need = static_cast<size_t>(pmx_population_n_observations(pop)) * static_cast<size_t>(ld) * sizeof(double);
   if (need == 0) return PMX_ERR_INVALID_ARGUMENT;
   // the arena lives on the population's device, whatever the calling thread's current device is (restored on return)
   const int dev = pmx_population_device(pop);
@@ -115,13 +115,13 @@ int32_t pmx_prediction_buffer_create(const pmx_model* model, const pmx_populatio
   // ordinary allocation runs at the medium speed), then the kernel into window after window
   double ms = 0.0;
   double* w0 = static_cast<double*>(a.va);
-  int32_t rc = pmx_time_predict_device(model, pop, d_theta, n_support, w0, n_support, 30, stream, &ms);
+  int32_t rc = pmx_time_predict_device(model, pop, d_theta, n_support, w0, ld, 30, stream, &ms);
   void* plain = nullptr;
   double plain_ms = 1e300;
   // (only where placement matters at all: a pass that moves less than ~1.5 TB/s of predictions is not write-bound)
   const bool plain_matters = rc == PMX_OK && ms > 0.0 && static_cast<double>(need) / (ms * 1.0e-3) > 1.5e12;
   if (plain_matters && search_bytes > 0 && hipMalloc(&plain, need) == hipSuccess) {
-    if (pmx_time_predict_device(model, pop, d_theta, n_support, static_cast<double*>(plain), n_support, 6, stream, &plain_ms) != PMX_OK) {
+    if (pmx_time_predict_device(model, pop, d_theta, n_support, static_cast<double*>(plain), ld, 6, stream, &plain_ms) != PMX_OK) {
       (void)hipFree(plain);
       plain = nullptr;
       plain_ms = 1e300;
@@ -155,7 +155,7 @@ int32_t pmx_prediction_buffer_create(const pmx_model* model, const pmx_populatio
   if (forced >= 0 && rc == PMX_OK) {
     best = static_cast<size_t>(forced);
     double* w = reinterpret_cast<double*>(static_cast<char*>(a.va) + best * chunk);
-    rc = pmx_time_predict_device(model, pop, d_theta, n_support, w, n_support, 4, stream, &ms);
+    rc = pmx_time_predict_device(model, pop, d_theta, n_support, w, ld, 4, stream, &ms);
     t.assign(best + 1, ms);
   } else if (!write_bound) {
     if (rc == PMX_OK) t.push_back(ms);
@@ -164,7 +164,7 @@ int32_t pmx_prediction_buffer_create(const pmx_model* model, const pmx_populatio
     long stopped_at = -1;
     for (size_t i = 0; rc == PMX_OK && map_up_to(i + win_chunks); ++i) {
       double* w = reinterpret_cast<double*>(static_cast<char*>(a.va) + i * chunk);
-      rc = pmx_time_predict_device(model, pop, d_theta, n_support, w, n_support, 4, stream, &ms);
+      rc = pmx_time_predict_device(model, pop, d_theta, n_support, w, ld, 4, stream, &ms);
       if (debug) std::fprintf(stderr, "[pmx] window at chunk %zu (%.2f GiB): %.4f ms\n", i, i * chunk / 1073741824.0, ms);
       t.push_back(ms);
       if (ms > slowest) slowest = ms;
@@ -227,6 +227,12 @@ int32_t pmx_prediction_buffer_create(const pmx_model* model, const pmx_populatio
   }
   if (ms_per_pass) *ms_per_pass = best_ms;
   return PMX_OK;
+}
+
+int32_t pmx_prediction_buffer_create(const pmx_model* model, const pmx_population* pop, const double* d_theta,
+                                     int64_t n_support, int64_t search_bytes, void* stream, double** d_pred,
+                                     double* ms_per_pass) {
+  return pmx_prediction_buffer_create_pitched(model, pop, d_theta, n_support, n_support, search_bytes, stream, d_pred, ms_per_pass);
 }
 
 void pmx_prediction_buffer_destroy(double* d_pred) {

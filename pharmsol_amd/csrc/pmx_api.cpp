@@ -240,10 +240,15 @@ struct pmx_model {
   bool user_lag = false, user_eq = false;  // user model: any lag closure (user's or descriptor's) / own propagator
   bool user_ode = false;                   // ODE model on the general walker (pmx_ode_user.hpp): lag / fa / derive closures, bolus[]
   std::vector<char> jit_code;
+  pmx::JitSpec jit_spec;  // what jit_code was compiled from (the big-lists build below is made from it on demand)
+  mutable std::vector<char> jit_code_big;  // closure walkers: the PMX_USER_BIG_LISTS build, compiled at the first launch on a
+                                           // population with more than 64 lagged boluses in one occasion (pmx_userlag.hpp)
   mutable std::mutex jit_mu;
   mutable std::map<int, pmx::JitModule> jit_modules;
+  mutable std::map<int, pmx::JitModule> jit_modules_big;
   ~pmx_model() {
     for (auto& kv : jit_modules) pmx::jit_unload(&kv.second);
+    for (auto& kv : jit_modules_big) pmx::jit_unload(&kv.second);
   }
 };
 
@@ -434,9 +439,9 @@ int32_t pmx_model_create(const pmx_model_desc* d, pmx_model** out) {
     if (d->nstates < ode_nstates(d->kernel)) return fail(PMX_ERR_INVALID_ARGUMENT, "model has fewer states than its diffeq");
     if (d->nparams < ode_nparams(d->kernel)) return fail(PMX_ERR_INVALID_ARGUMENT, "too few parameters for the diffeq");
     if (!(d->rk4_h_max > 0.0)) return fail(PMX_ERR_INVALID_ARGUMENT, "rk4_h_max must be > 0");
-    if (d->ode_solver != PMX_SOLVER_RK4 && d->ode_solver != PMX_SOLVER_DOPRI5)
+    if (d->ode_solver != PMX_SOLVER_RK4 && d->ode_solver != PMX_SOLVER_DOPRI5 && d->ode_solver != PMX_SOLVER_ROS2)
       return fail(PMX_ERR_INVALID_ARGUMENT, "unknown ode_solver");
-    if (d->ode_solver == PMX_SOLVER_DOPRI5 && !(d->ode_rtol > 0.0 && d->ode_atol > 0.0))
+    if (d->ode_solver != PMX_SOLVER_RK4 && !(d->ode_rtol > 0.0 && d->ode_atol > 0.0))
       return fail(PMX_ERR_INVALID_ARGUMENT, "the adaptive solver needs ode_rtol > 0 and ode_atol > 0");
     if (pm) return fail(PMX_ERR_INVALID_ARGUMENT, "pm_* indexing is a wrapper of the analytical structures (analytical/mod.rs:62-90): it does not apply to ODE models");
     if (d->n_bind != 0 && d->n_bind != ode_nparams(d->kernel))
@@ -479,6 +484,7 @@ int32_t pmx_model_create(const pmx_model_desc* d, pmx_model** out) {
     sp.desc = *d;
     sp.source = d->n_derived > 0 ? pmx::analytical_descriptor_source(*d) : std::string();
     std::string log;
+    m->jit_spec = sp;
     if (!pmx::jit_compile(sp, &m->jit_code, &log))
       return fail(PMX_ERR_HIP, "hiprtc could not compile the generated closures:\n" + log);
     m->custom = true;
@@ -511,6 +517,7 @@ int32_t pmx_model_create(const pmx_model_desc* d, pmx_model** out) {
     sp.ncov = d->n_covariates;
     sp.source = pmx::ode_descriptor_source(*d);
     std::string log;
+    m->jit_spec = sp;
     if (!pmx::jit_compile(sp, &m->jit_code, &log))
       return fail(PMX_ERR_HIP, "hiprtc could not compile the generated diffeq body:\n" + log);
     m->d = dd;
@@ -532,9 +539,9 @@ int32_t check_custom_desc(const pmx_model_desc* d, const char* source) {
   if (d->nout < 1 || d->nout > PMX_MAX_OUT) return fail(PMX_ERR_INVALID_ARGUMENT, "nout out of range");
   if (d->nparams < 1 || d->nparams > PMX_MAX_PARAMS) return fail(PMX_ERR_INVALID_ARGUMENT, "nparams out of range");
   if (!(d->rk4_h_max > 0.0)) return fail(PMX_ERR_INVALID_ARGUMENT, "rk4_h_max must be > 0");
-  if (d->ode_solver != PMX_SOLVER_RK4 && d->ode_solver != PMX_SOLVER_DOPRI5)
+  if (d->ode_solver != PMX_SOLVER_RK4 && d->ode_solver != PMX_SOLVER_DOPRI5 && d->ode_solver != PMX_SOLVER_ROS2)
     return fail(PMX_ERR_INVALID_ARGUMENT, "unknown ode_solver");
-  if (d->ode_solver == PMX_SOLVER_DOPRI5 && !(d->ode_rtol > 0.0 && d->ode_atol > 0.0))
+  if (d->ode_solver != PMX_SOLVER_RK4 && !(d->ode_rtol > 0.0 && d->ode_atol > 0.0))
     return fail(PMX_ERR_INVALID_ARGUMENT, "the adaptive solver needs ode_rtol > 0 and ode_atol > 0");
   if (d->n_covariates < 0 || d->n_covariates > PMX_MAX_COVARIATES)
     return fail(PMX_ERR_INVALID_ARGUMENT, "n_covariates out of range");
@@ -582,7 +589,8 @@ int32_t pmx_model_create_custom(const pmx_model_desc* d, const char* source, int
   m->custom = true;
   m->has_init = has_init != 0;
   std::string log;
-  if (!pmx::jit_compile(spec_of(d, source, has_init), &m->jit_code, &log))
+  m->jit_spec = spec_of(d, source, has_init);
+  if (!pmx::jit_compile(m->jit_spec, &m->jit_code, &log))
     return fail(PMX_ERR_INVALID_ARGUMENT, "hiprtc could not compile the model source:\n" + log);
   *out = m.release();
   return PMX_OK;
@@ -670,8 +678,8 @@ int32_t check_user_ode(const pmx_model_desc* d, const char* source, uint32_t fns
   if (d->n_derived > 0 && !(fns & PMX_FN_DERIVE)) return fail(PMX_ERR_INVALID_ARGUMENT, "n_derived > 0 needs PMX_FN_DERIVE (desc.derived[] is not read for user models)");
   if (d->n_bind != 0 || d->pmetrics_indexing) return fail(PMX_ERR_INVALID_ARGUMENT, "bind[] / pm indexing do not apply to ODE models with user closures");
   if (!(d->rk4_h_max > 0.0)) return fail(PMX_ERR_INVALID_ARGUMENT, "rk4_h_max must be > 0");
-  if (d->ode_solver != PMX_SOLVER_RK4 && d->ode_solver != PMX_SOLVER_DOPRI5) return fail(PMX_ERR_INVALID_ARGUMENT, "unknown ode_solver");
-  if (d->ode_solver == PMX_SOLVER_DOPRI5 && !(d->ode_rtol > 0.0 && d->ode_atol > 0.0))
+  if (d->ode_solver != PMX_SOLVER_RK4 && d->ode_solver != PMX_SOLVER_DOPRI5 && d->ode_solver != PMX_SOLVER_ROS2) return fail(PMX_ERR_INVALID_ARGUMENT, "unknown ode_solver");
+  if (d->ode_solver != PMX_SOLVER_RK4 && !(d->ode_rtol > 0.0 && d->ode_atol > 0.0))
     return fail(PMX_ERR_INVALID_ARGUMENT, "the adaptive solver needs ode_rtol > 0 and ode_atol > 0");
   for (int i = 0; i < PMX_MAX_INPUTS; ++i) {
     if (d->lag_param[i] >= d->nparams || d->fa_param[i] >= d->nparams)
@@ -703,7 +711,8 @@ int32_t create_user_ode(const pmx_model_desc* d, const char* source, uint32_t fn
   for (int i = 0; i < PMX_MAX_INPUTS; ++i) m->user_lag |= d->lag_param[i] >= 0;
   m->has_init = true;  // (RESET ops always carry the occasion-index flag; the policy's init may be empty)
   std::string log;
-  if (!pmx::jit_compile(user_spec_of(d, source, fns), &m->jit_code, &log))
+  m->jit_spec = user_spec_of(d, source, fns);
+  if (!pmx::jit_compile(m->jit_spec, &m->jit_code, &log))
     return fail(PMX_ERR_INVALID_ARGUMENT, "hiprtc could not compile the model source:\n" + log);
   *out = m.release();
   return PMX_OK;
@@ -734,7 +743,8 @@ int32_t pmx_model_create_user(const pmx_model_desc* d, const char* source, uint3
   for (int i = 0; i < PMX_MAX_INPUTS; ++i) m->user_lag |= d->lag_param[i] >= 0;
   m->has_init = true;  // (RESET ops always carry the occasion-index flag; the policy's init may be empty)
   std::string log;
-  if (!pmx::jit_compile(user_spec_of(d, source, functions), &m->jit_code, &log))
+  m->jit_spec = user_spec_of(d, source, functions);
+  if (!pmx::jit_compile(m->jit_spec, &m->jit_code, &log))
     return fail(PMX_ERR_INVALID_ARGUMENT, "hiprtc could not compile the model source:\n" + log);
   *out = m.release();
   return PMX_OK;
@@ -851,7 +861,7 @@ pmx::CompileKey key_for(const pmx_model* m) {
     for (int i = 0; i < PMX_MAX_INPUTS; ++i)
       if (m->d.lag_param[i] >= 0) k.lag_mask |= (1u << i);
     // absolute piece times: a user body may be non-autonomous; the adaptive solver steps on [t0, t1] itself
-    k.want_times = m->custom || m->d.ode_solver == PMX_SOLVER_DOPRI5;
+    k.want_times = m->custom || m->d.ode_solver != PMX_SOLVER_RK4;
   }
   return k;
 }
@@ -1209,7 +1219,8 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
   a.m.rk4_h_max = d.rk4_h_max;
   a.m.ode_rtol = d.ode_rtol;
   a.m.ode_atol = d.ode_atol;
-  a.adaptive = (d.eq_kind == PMX_EQ_ODE && d.ode_solver == PMX_SOLVER_DOPRI5) ? 1 : 0;
+  a.adaptive = (d.eq_kind == PMX_EQ_ODE && d.ode_solver != PMX_SOLVER_RK4) ? 1 : 0;
+  a.m.ode_stiff = (d.eq_kind == PMX_EQ_ODE && d.ode_solver == PMX_SOLVER_ROS2) ? 1 : 0;
   std::memcpy(a.m.derived, d.derived, sizeof(d.derived));
   std::memcpy(a.m.bind, d.bind, sizeof(d.bind));
   std::memcpy(a.m.out, d.out, sizeof(d.out));
@@ -1327,13 +1338,24 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
     const pmx::JitModule* jm = nullptr;
     {
       std::lock_guard<std::mutex> lock(model->jit_mu);
-      auto it = model->jit_modules.find(pop->device);
-      if (it == model->jit_modules.end()) {
+      // closure walkers keep 64 landing times per lane; an occasion with more takes the build with the scan path in
+      const bool big = (d.eq_kind == PMX_EQ_ANALYTICAL || model->user_ode) && ds->max_lagb_per_list > 64;
+      if (big && model->jit_code_big.empty()) {
+        pmx::JitSpec sp = model->jit_spec;
+        sp.big_lists = true;
+        std::string log;
+        if (!pmx::jit_compile(sp, &model->jit_code_big, &log))
+          return fail(PMX_ERR_HIP, "hiprtc could not compile the big-lists build of the model:\n" + log);
+      }
+      auto& modules = big ? model->jit_modules_big : model->jit_modules;
+      auto it = modules.find(pop->device);
+      if (it == modules.end()) {
         pmx::JitModule mod;
-        const hipError_t le = pmx::jit_load(model->jit_code, &mod, d.eq_kind == PMX_EQ_ANALYTICAL ? pmx::JIT_ANALYTICAL
-                                                                   : (model->user_ode ? pmx::JIT_ODE_USER : pmx::JIT_ODE));
+        const hipError_t le = pmx::jit_load(big ? model->jit_code_big : model->jit_code, &mod,
+                                            d.eq_kind == PMX_EQ_ANALYTICAL ? pmx::JIT_ANALYTICAL
+                                                                           : (model->user_ode ? pmx::JIT_ODE_USER : pmx::JIT_ODE));
         if (le != hipSuccess) return fail(PMX_ERR_HIP, std::string("loading the compiled model: ") + hipGetErrorString(le));
-        it = model->jit_modules.emplace(pop->device, mod).first;
+        it = modules.emplace(pop->device, mod).first;
       }
       jm = &it->second;
     }
@@ -1341,13 +1363,17 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
     const int lag = (!ua && !model->user_ode && a.m.n_lag_slots > 0) ? 1 : 0, ll = a.ops.ll_obs != nullptr ? 1 : 0,
               ad = (!ua && a.adaptive) ? 1 : 0;
     const int mode = a.mode == pmx::MODE_GRID ? 0 : 1;
-    static const char* const kNames[2][2][2] = {
+    static const char* const kNames[3][2][2] = {
         {{"pmx_jit_ode_rk4_grid", "pmx_jit_ode_rk4_grid<lag>"}, {"pmx_jit_ode_rk4_pair", "pmx_jit_ode_rk4_pair<lag>"}},
-        {{"pmx_jit_ode_dopri5_grid", "pmx_jit_ode_dopri5_grid<lag>"}, {"pmx_jit_ode_dopri5_pair", "pmx_jit_ode_dopri5_pair<lag>"}}};
-    name = kNames[ad][mode][lag];
+        {{"pmx_jit_ode_dopri5_grid", "pmx_jit_ode_dopri5_grid<lag>"}, {"pmx_jit_ode_dopri5_pair", "pmx_jit_ode_dopri5_pair<lag>"}},
+        {{"pmx_jit_ode_ros2_grid", "pmx_jit_ode_ros2_grid<lag>"}, {"pmx_jit_ode_ros2_pair", "pmx_jit_ode_ros2_pair<lag>"}}};
+    const int sv = ad ? (a.m.ode_stiff ? 2 : 1) : 0;  // (the same compiled entry point serves both adaptive steppers)
+    name = kNames[sv][mode][lag];
     if (ua) name = mode == 0 ? "pmx_jit_analytical_grid" : "pmx_jit_analytical_pair";
-    if (model->user_ode) name = mode == 0 ? (ad ? "pmx_jit_ode_user_dopri5_grid" : "pmx_jit_ode_user_rk4_grid")
-                                          : (ad ? "pmx_jit_ode_user_dopri5_pair" : "pmx_jit_ode_user_rk4_pair");
+    static const char* const kUser[3][2] = {{"pmx_jit_ode_user_rk4_grid", "pmx_jit_ode_user_rk4_pair"},
+                                            {"pmx_jit_ode_user_dopri5_grid", "pmx_jit_ode_user_dopri5_pair"},
+                                            {"pmx_jit_ode_user_ros2_grid", "pmx_jit_ode_user_ros2_pair"}};
+    if (model->user_ode) name = kUser[sv][mode];
     if (a.S <= 0 || (a.P <= 0 && !a.batch)) {
       e = hipSuccess;
     } else if (mode == 0) {

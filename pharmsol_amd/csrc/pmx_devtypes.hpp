@@ -36,7 +36,9 @@ struct DevModel {
   int32_t out_vol_theta[PMX_MAX_OUT]; // theta index behind each output's volume when it is lane-constant (a primary
                                       // parameter, or a derived value without covariate factors: its base parameter); -1 = none
   double rk4_h_max;                   // ODE + lag: pieces split on the device recompute n = ceil(dt / h_max)
-  double ode_rtol, ode_atol;          // adaptive solver (PMX_SOLVER_DOPRI5)
+  double ode_rtol, ode_atol;          // adaptive solvers (PMX_SOLVER_DOPRI5, PMX_SOLVER_ROS2)
+  int32_t ode_stiff;                  // the adaptive step is ROS2 (PMX_SOLVER_ROS2) instead of DOPRI5
+  int32_t pad2_;
 };
 constexpr int kMaxLagSlots = 4;
 

@@ -23,6 +23,7 @@ struct JitSpec {
   bool ode_user = false;
   uint32_t fns = 0;
   pmx_model_desc desc{};
+  bool big_lists = false;  // closure walkers: compile the > 64-boluses-per-occasion path in (PMX_USER_BIG_LISTS, pmx_userlag.hpp)
 };
 enum JitKind { JIT_ODE = 0, JIT_ANALYTICAL = 1, JIT_ODE_USER = 2 };
 inline JitKind jit_kind(const JitSpec& s) { return s.analytical ? JIT_ANALYTICAL : (s.ode_user ? JIT_ODE_USER : JIT_ODE); }

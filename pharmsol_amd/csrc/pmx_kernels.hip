@@ -2011,12 +2011,14 @@ hipError_t launch_ode_v(const LaunchArgs& a, const char** name) {
   hipStream_t st = static_cast<hipStream_t>(a.stream);
   if (a.mode == MODE_GRID) {
     *name = ADAPT ? (LAG ? "pmx_ode_dopri5_grid<lag>" : "pmx_ode_dopri5_grid") : (LAG ? "pmx_ode_rk4_grid<lag>" : "pmx_ode_rk4_grid");
+    if (ADAPT && a.m.ode_stiff) *name = LAG ? "pmx_ode_ros2_grid<lag>" : "pmx_ode_ros2_grid";
     const int64_t n_chunks = (a.S + a.s_chunk - 1) / a.s_chunk;
     const int64_t blocks = n_chunks * a.n_ptiles;
     hipLaunchKernelGGL((pmx_ode_rk4_grid<MODEL, LAG, LL, ADAPT>), dim3(static_cast<uint32_t>(blocks)), dim3(grid_threads(a.P)), 0, st,
                        a.m, a.ops, a.theta, a.P, a.S, a.s_chunk, a.n_ptiles, a.pred, a.ld, a.status);
   } else {
     *name = ADAPT ? (LAG ? "pmx_ode_dopri5_pair<lag>" : "pmx_ode_dopri5_pair") : (LAG ? "pmx_ode_rk4_pair<lag>" : "pmx_ode_rk4_pair");
+    if (ADAPT && a.m.ode_stiff) *name = LAG ? "pmx_ode_ros2_pair<lag>" : "pmx_ode_ros2_pair";
     const int64_t n_pairs = a.batch ? a.S : a.S * a.P;
     const int64_t blocks = (n_pairs + kBlock - 1) / kBlock;
     hipLaunchKernelGGL((pmx_ode_rk4_pair<MODEL, LAG, LL, ADAPT>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlock), 0, st,

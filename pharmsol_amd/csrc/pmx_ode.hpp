@@ -111,6 +111,92 @@ __device__ __forceinline__ double dopri5_try(const DevModel& m, const OdeLane<M>
   return sqrt(acc / static_cast<double>(NS));
 }
 
+// ---- stiff: ROS2, a linearly implicit (Rosenbrock) method, PMX_SOLVER_ROS2 ------------------------------------------
+// The reference's default solver is diffsol's BDF - implicit, for stiff systems (ode/mod.rs:60-68); fast absorption or
+// distribution next to slow elimination makes the explicit steppers crawl (DOPRI5 is stability-bound at h ~ 3.3 / |lambda|).
+// ROS2 (Verwer, Spee, Blom, Hundsdorfer 1999), gamma = 1 + 1/sqrt(2), L-stable, second order for ANY approximation W of
+// the Jacobian:
+//     (I - gamma h J) k1 = f(t, y) + gamma h f_t
+//     (I - gamma h J) k2 = f(t + h, y + h k1) - gamma h f_t - 2 k1
+//     y+ = y + 3/2 h k1 + 1/2 h k2,     error estimate = y+ - (y + h k1) = h/2 (k1 + k2)   (the embedded first-order solution)
+// One lane = one system of NS <= 8 states: J and f_t by forward differences (NS + 1 extra right-hand sides; exact up to
+// rounding for the linear compartmental bodies), the NS x NS factorisation fully unrolled in registers WITHOUT pivoting
+// (I - gamma h J of a compartmental system is a column-diagonally-dominant M-matrix, for which elimination in the natural
+// order is stable).  Same try/advance contract as DOPRI5, error exponent -1/2.
+template <class M>
+__device__ __forceinline__ double ros2_try(const DevModel& m, const OdeLane<M>& L, const double (&x)[M::NS],
+                                           const double (&rs)[M::NR], double t, double h, double (&xn)[M::NS]) {
+  constexpr int NS = M::NS;
+  constexpr double kGamma = 1.7071067811865475;
+  constexpr double kSqrtEps = 1.4901161193847656e-08;
+  const double gh = kGamma * h;
+  double f0[NS], f1[NS], xt[NS], W[NS][NS], ft[NS], k1[NS], k2[NS];
+  ode_eval<M>(t, L, x, rs, f0);
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) xt[i] = x[i];
+    const double d = kSqrtEps * fmax(fabs(x[j]), 1.0);
+    xt[j] = x[j] + d;
+    ode_eval<M>(t, L, xt, rs, f1);
+    const double s = -gh / d;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) W[i][j] = (f1[i] - f0[i]) * s + ((i == j) ? 1.0 : 0.0);
+  }
+  {
+    const double dt = kSqrtEps * fmax(fabs(t), 1.0);
+    ode_eval<M>(t + dt, L, x, rs, f1);
+    const double s = gh / dt;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) ft[i] = (f1[i] - f0[i]) * s;
+  }
+  // W = L U in place (unit lower triangle below the diagonal), natural order
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const double inv = 1.0 / W[k][k];
+#pragma unroll
+    for (int i = k + 1; i < NS; ++i) {
+      const double l = W[i][k] * inv;
+      W[i][k] = l;
+#pragma unroll
+      for (int j = k + 1; j < NS; ++j) W[i][j] -= l * W[k][j];
+    }
+    W[k][k] = inv;  // (the diagonal keeps its reciprocal for the back substitutions)
+  }
+  auto solve = [&W](double (&b)[NS]) {
+#pragma unroll
+    for (int i = 1; i < NS; ++i) {
+#pragma unroll
+      for (int j = 0; j < i; ++j) b[i] -= W[i][j] * b[j];
+    }
+#pragma unroll
+    for (int i = NS - 1; i >= 0; --i) {
+#pragma unroll
+      for (int j = i + 1; j < NS; ++j) b[i] -= W[i][j] * b[j];
+      b[i] *= W[i][i];
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < NS; ++i) k1[i] = f0[i] + ft[i];
+  solve(k1);
+#pragma unroll
+  for (int i = 0; i < NS; ++i) xt[i] = x[i] + h * k1[i];
+  ode_eval<M>(t + h, L, xt, rs, f1);
+#pragma unroll
+  for (int i = 0; i < NS; ++i) k2[i] = f1[i] - ft[i] - 2.0 * k1[i];
+  solve(k2);
+  double acc = 0.0;
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    xn[i] = x[i] + h * (1.5 * k1[i] + 0.5 * k2[i]);
+    const double e = (0.5 * h) * (k1[i] + k2[i]);
+    const double sc = m.ode_atol + m.ode_rtol * fmax(fabs(x[i]), fabs(xn[i]));
+    const double q = e / sc;
+    acc += q * q;
+  }
+  return sqrt(acc / static_cast<double>(NS));
+}
+
 // Step-size controller state of a lane: `h` = the controller's current proposal (carried from piece to piece).
 struct AdaptState {
   double h;
@@ -130,10 +216,11 @@ __device__ __forceinline__ bool dopri5_advance(const DevModel& m, const OdeLane<
   const bool clipped = h >= left;
   if (clipped) h = left;
   double xn[NS];
-  const double err = dopri5_try<M>(m, L, x, rs, t, h, xn);
+  const bool stiff = m.ode_stiff != 0;  // (wave-uniform: PMX_SOLVER_ROS2)
+  const double err = stiff ? ros2_try<M>(m, L, x, rs, t, h, xn) : dopri5_try<M>(m, L, x, rs, t, h, xn);
   const bool ok = err <= 1.0;  // (false for NaN)
-  // factor 0.9 err^(-1/5) in [0.2, 5]; no growth right after a rejection
-  double fac = (err > 0.0) ? 0.9 * pow(err, -0.2) : 5.0;
+  // factor 0.9 err^(-1/(p+1)) in [0.2, 5], p = the order of the error estimate (4 | 1); no growth right after a rejection
+  double fac = (err > 0.0) ? 0.9 * pow(err, stiff ? -0.5 : -0.2) : 5.0;
   if (!(fac >= 0.2)) fac = 0.2;  // also catches NaN
   if (fac > 5.0) fac = 5.0;
   if (!ok && fac > 1.0) fac = 1.0;

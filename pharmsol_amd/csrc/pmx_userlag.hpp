@@ -41,6 +41,9 @@ __device__ __forceinline__ void user_cov_der(const DevOps& ops, int64_t occ, dou
   if constexpr (M::HAS_DERIVE) M::derive(t, p, c.v, d.v);
 }
 
+// (The scan below is compiled only into the PMX_USER_BIG_LISTS build of a model, which the library makes - lazily - for
+// populations that hold such an occasion: inlined into the ordinary build it cost the walker 26 vector registers, 142
+// instead of 116, i.e. three waves per SIMD instead of four, and the user-closure workload ran 3.4 -> 4.9 ms.)
 // The lane's view of the occasion's lagged boluses.  Up to kUserLagKept of them: landing times in a private array,
 // insertion-sorted, `idx` = position in the occasion's list.  A longer list (`big`) is not stored at all: the next
 // bolus to land is found by scanning the list for the smallest (landing time, position) after the last one taken -
@@ -108,13 +111,18 @@ __device__ __forceinline__ bool user_lag_open(const DevOps& ops, int64_t occ, co
   const int64_t n = ops.lagb_off[occ + 1] - L.base;
   L.n = static_cast<int32_t>(n);
   L.cur = 0;
-  L.big = n > kUserLagKept;
+  L.big = false;
   L.nxt_tau = __longlong_as_double(0x7ff0000000000000LL);
   L.nxt_idx = -1;
+#ifdef PMX_USER_BIG_LISTS
+  L.big = n > kUserLagKept;
   if (L.big) {
     user_lag_scan<M>(ops, occ, th, L, 0.0, -1, &ok);
     return ok;
   }
+#else
+  if (n > kUserLagKept) L.n = kUserLagKept;  // (never: the host launches the PMX_USER_BIG_LISTS build for such populations)
+#endif
 #pragma unroll 1
   for (int32_t j = 0; j < L.n; ++j) {
     const double tau = user_lag_landing<M>(ops, occ, th, L.base, j, &ok);
@@ -133,7 +141,9 @@ __device__ __forceinline__ bool user_lag_open(const DevOps& ops, int64_t occ, co
 
 // landing time of the next pending bolus (+inf: none)
 __device__ __forceinline__ double user_lag_next(const UserLag& L) {
+#ifdef PMX_USER_BIG_LISTS
   if (L.big) return L.nxt_tau;
+#endif
   return (L.cur < L.n) ? L.tau[L.cur] : __longlong_as_double(0x7ff0000000000000LL);
 }
 
@@ -142,12 +152,15 @@ template <class M>
 __device__ __forceinline__ void user_lag_take(const DevOps& ops, int64_t occ, const double* __restrict__ th, UserLag& L,
                                               double* tau, int* input, double* amount) {
   int32_t j;
+#ifdef PMX_USER_BIG_LISTS
   if (L.big) {
     j = L.nxt_idx;
     *tau = L.nxt_tau;
     bool ok = true;
     user_lag_scan<M>(ops, occ, th, L, *tau, j, &ok);
-  } else {
+  } else
+#endif
+  {
     j = L.idx[L.cur];
     *tau = L.tau[L.cur];
     L.cur += 1;

@@ -548,8 +548,11 @@ class ODE(Equation):
 
     def with_solver(self, solver: str) -> "ODE":
         """``ODE::with_solver`` (ode/mod.rs:134-150).  The reference's diffsol solvers are replaced: ``"rk4"`` = fixed
-        step (default), ``"dopri5"`` = adaptive Dormand-Prince 5(4) with per-lane step control."""
-        self.ode_solver = {"rk4": _abi.PMX_SOLVER_RK4, "dopri5": _abi.PMX_SOLVER_DOPRI5}[solver]
+        step (default), ``"dopri5"`` = adaptive Dormand-Prince 5(4) with per-lane step control (the role of
+        ``ExplicitRk(Tsit45)``), ``"ros2"`` (alias ``"stiff"``) = the L-stable Rosenbrock method ROS2 with the same step
+        control, for stiff systems (the role of ``Bdf`` / ``Sdirk``, ode/mod.rs:60-77)."""
+        self.ode_solver = {"rk4": _abi.PMX_SOLVER_RK4, "dopri5": _abi.PMX_SOLVER_DOPRI5, "ros2": _abi.PMX_SOLVER_ROS2,
+                           "stiff": _abi.PMX_SOLVER_ROS2}[solver]
         self._handle = None
         return self
 

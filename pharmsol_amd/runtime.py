@@ -134,12 +134,13 @@ class _PlacedBuffer:
             self.ptr = 0
 
 
-def place_predictions(model, pop: DevicePopulation, theta, search_gib: float = 48.0, exhaustive: bool = False):
+def place_predictions(model, pop: DevicePopulation, theta, search_gib: float = 48.0, exhaustive: bool = False, ld: int = 0):
     """A prediction matrix ``[n_observations, n_support]`` in a fast window of an arena of up to ``search_gib``
     (``pmx_prediction_buffer_create``: physical chunks mapped through the HIP virtual-memory API window by window, the
     real kernel timed into each; the search stops inside the first fast plateau, or - ``exhaustive`` - times every window
-    and keeps the best; everything outside the chosen window is returned to the device).  Returns a CUDA tensor; the
-    memory lives as long as the tensor (``tensor._pmx_owner``)."""
+    and keeps the best; everything outside the chosen window is returned to the device).  ``ld`` > n_support: rows that
+    many doubles apart (``pmx_prediction_buffer_create_pitched``), the tensor returned is the ``[:, :n_support]`` view.
+    Returns a CUDA tensor; the memory lives as long as the tensor (``tensor._pmx_owner``)."""
     import torch
 
     dev = torch.device("cuda", pop.device)
@@ -148,13 +149,18 @@ def place_predictions(model, pop: DevicePopulation, theta, search_gib: float = 4
     theta = theta.contiguous()
     P = int(theta.shape[0])
     out, ms = C.c_void_p(), C.c_double()
+    pitch = max(int(ld), P)
     with torch.cuda.device(dev):
-        _ffi.check(_ffi.lib().pmx_prediction_buffer_create(_as_model(model).handle, pop.handle, theta.data_ptr(), P,
-                                                           int(search_gib * (1 << 30)) * (-1 if exhaustive else 1),
-                                                           torch.cuda.current_stream(dev).cuda_stream, C.byref(out),
-                                                           C.byref(ms)))
-    owner = _PlacedBuffer(out.value, (pop.n_observations, P), ms.value)
-    t = torch.as_tensor(owner, device=dev)
+        _ffi.check(_ffi.lib().pmx_prediction_buffer_create_pitched(_as_model(model).handle, pop.handle, theta.data_ptr(), P, pitch,
+                                                                   int(search_gib * (1 << 30)) * (-1 if exhaustive else 1),
+                                                                   torch.cuda.current_stream(dev).cuda_stream, C.byref(out),
+                                                                   C.byref(ms)))
+    owner = _PlacedBuffer(out.value, (pop.n_observations, pitch), ms.value)
+    base = torch.as_tensor(owner, device=dev)
+    base._pmx_owner = owner
+    if pitch == P:
+        return base
+    t = base[:, :P]
     t._pmx_owner = owner
     return t
 
