@@ -1339,7 +1339,7 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
     {
       std::lock_guard<std::mutex> lock(model->jit_mu);
       // closure walkers keep 64 landing times per lane; an occasion with more takes the build with the scan path in
-      const bool big = (d.eq_kind == PMX_EQ_ANALYTICAL || model->user_ode) && ds->max_lagb_per_list > 64;
+      const bool big = (d.eq_kind == PMX_EQ_ANALYTICAL || model->user_ode) && ds->max_lagb_per_list > pmx::kUserLagKept;
       if (big && model->jit_code_big.empty()) {
         pmx::JitSpec sp = model->jit_spec;
         sp.big_lists = true;

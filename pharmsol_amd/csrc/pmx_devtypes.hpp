@@ -41,6 +41,12 @@ struct DevModel {
   int32_t pad2_;
 };
 constexpr int kMaxLagSlots = 4;
+// closure walkers (pmx_userlag.hpp): lagged boluses of one occasion whose landing times a lane keeps sorted in a private
+// array; an occasion with more takes the model's PMX_USER_BIG_LISTS build (compiled on demand, pmx_api.cpp)
+#ifndef PMX_USER_LAG_KEPT
+#define PMX_USER_LAG_KEPT 64
+#endif
+constexpr int kUserLagKept = PMX_USER_LAG_KEPT;
 
 // Device mirror of an OpStream (all pointers are device pointers).
 struct DevOps {

@@ -48,7 +48,6 @@ __device__ __forceinline__ void user_cov_der(const DevOps& ops, int64_t occ, dou
 // insertion-sorted, `idx` = position in the occasion's list.  A longer list (`big`) is not stored at all: the next
 // bolus to land is found by scanning the list for the smallest (landing time, position) after the last one taken -
 // n lag evaluations per bolus instead of one, no memory, no cap (a rare shape: > 64 boluses in ONE occasion).
-constexpr int kUserLagKept = 64;
 struct UserLag {
   double tau[kUserLagKept];
   uint16_t idx[kUserLagKept];
