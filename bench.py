@@ -319,13 +319,13 @@ def main():
         row_pitch = (ld if (ld is not None and not want_gather) else P) if not (batch or args.loglik) else None
         if ld is not None and not want_gather:
             # rows padded to a pitch (ld_pred of pmx_predict_device; the same bytes are written, the padding never is).
-            # N = 1: the first plain allocation of the process is what a caller's own buffer gets (`frac_first_allocation`);
+            # The first plain allocation of the process is what a caller's own buffer gets (`frac_first_allocation`);
             # --alloc-tries - 1 more are timed with the real kernel during set-up, all alive at once so that each sits on
             # different memory, and the fastest is kept (where the matrix lands in HBM moves the row-strided stream by up to
             # 25 %)
             pred = torch.empty((n_obs, ld), dtype=torch.float64, device=dev)[:, :P]
             placed = "one plain allocation, rows padded to %d doubles" % ld
-            if world == 1 and n_obs * P * 8 > (1 << 28) and args.alloc_tries > 1 and args.place_gib > 0:
+            if n_obs * P * 8 > (1 << 28) and args.alloc_tries > 1 and args.place_gib > 0:
                 spin_up(pred)
                 first_alloc_ms = best_ms = ms_into(pred)
                 held, n_plain = [pred], 1
@@ -343,17 +343,23 @@ def main():
                 cand = None
                 torch.cuda.empty_cache()
                 placed = "best of %d plain allocations, rows padded to %d doubles (pmx_recommended_ld)" % (n_plain, ld)
-                # ... and the best window of an arena the library maps chunk by chunk and times window by window
+                # ... and, at N = 1, the best window of an arena the library maps chunk by chunk and times window by window
                 # (pmx_prediction_buffer_create_pitched, exhaustive form): boxes exist where none of the plain allocations
-                # is of the fast kind (profiles/r03/bench_c3_box_without_a_fast_plain_allocation.json)
+                # is of the fast kind (profiles/r03/bench_c3_box_without_a_fast_plain_allocation.json).  (N > 1: ranks time
+                # their few plain candidates only - eight ranks each timing 100 GiB of arena windows would say more about the
+                # search than about the path)
                 free_b, _tot = torch.cuda.mem_get_info(dev)
                 gib = min(args.place_gib, 0.75 * free_b / (1 << 30))
                 try:
+                    if world > 1:
+                        raise StopIteration
                     cand = runtime.place_predictions(model, pop, d_theta, search_gib=gib, exhaustive=True, ld=ld)
                     if ms_into(cand) < best_ms:
                         pred = cand
                         placed = "best window of a %.0f GiB arena, rows padded to %d doubles (%.3f ms during the search)" % (
                             gib, ld, cand._pmx_owner.ms_per_pass)
+                except StopIteration:
+                    pass
                 except Exception as e:  # no virtual-memory API / not enough memory
                     placed += " (arena search failed: %s)" % type(e).__name__
                 cand = None
