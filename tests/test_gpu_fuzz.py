@@ -301,8 +301,13 @@ def test_random_covariate_model(seed):
         if rng.random() < 0.5:
             b = b.covariate("wt", float(rng.uniform(5, 30)), float(rng.uniform(45, 110)))
         b = b.bolus(0.0, float(rng.uniform(50, 300)), "dose")
-        if rng.random() < 0.5:
+        # (every third case: nobody is infused - the shape that sends the three-compartment structures to the matrix-free
+        # walker pmx_analytical_dyn3; a repeated segment length now and then exercises its kept segments)
+        if seed % 3 != 1 and rng.random() < 0.5:
             b = b.infusion(float(rng.uniform(0.5, 6)), float(rng.uniform(50, 200)), "iv", float(rng.uniform(0.5, 3)))
+        if seed % 3 == 1 and i % 2 == 0:
+            for t in (6.0, 12.0, 18.0, 24.0, 36.0):
+                b = b.missing_observation(t, "cp")
         for t in np.sort(rng.uniform(0.2, 40.0, int(rng.integers(2, 9)))):
             b = b.missing_observation(float(t), "cp")
         if rng.random() < 0.3:

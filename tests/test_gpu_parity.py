@@ -835,6 +835,37 @@ def test_placed_prediction_buffer(exhaustive):
     assert free0 - torch.cuda.mem_get_info()[0] < (8 << 20)
 
 
+def test_placed_prediction_buffer_with_a_row_pitch_and_the_write_ceiling():
+    """pmx_prediction_buffer_create_pitched + pmx_recommended_ld: rows 128-byte aligned, the padding never written;
+    pmx_measure_write_ceiling on the same allocation."""
+    import ctypes as C
+
+    import torch
+
+    from pharmsol_amd import _ffi
+
+    m, flat, theta = synth.config_c3(300, 70)
+    pop = runtime.DevicePopulation(flat, 0)
+    ld = runtime.recommended_ld(70)
+    assert ld == 80
+    pred = runtime.place_predictions(m, pop, theta, search_gib=0.25, exhaustive=True, ld=ld)
+    assert pred.shape == (flat.n_observations, 70) and pred.stride(0) == ld and pred._pmx_owner.ms_per_pass > 0
+    base = pred._base
+    base.fill_(-7.0)
+    out, st = runtime.predict(m, pop, theta, pred=pred)
+    torch.cuda.synchronize()
+    want, _ = oracle.predict(m, flat, theta)
+    assert rel_err(out.cpu().numpy(), want).max() < TOL_ANALYTICAL
+    assert bool((base[:, 70:] == -7.0).all())  # the padding columns were not touched
+    dense, _ = runtime.predict(m, pop, theta)
+    assert torch.equal(dense, out)  # same numbers bit for bit, whatever the pitch
+    big = torch.empty(1 << 24, dtype=torch.float64, device="cuda")
+    gbs = C.c_double()
+    _ffi.check(_ffi.lib().pmx_measure_write_ceiling(big.data_ptr(), big.numel(), 3, torch.cuda.current_stream().cuda_stream,
+                                                    C.byref(gbs)))
+    assert 500.0 < gbs.value < 8000.0 and bool((big == 0.0).all())
+
+
 @pytest.mark.parametrize("structure,n_support", [("two_compartments", 70), ("two_compartments", 9),
                                                   ("three_compartments", 70)])
 def test_a_failed_first_occasion_keeps_the_pair_failed(structure, n_support):
