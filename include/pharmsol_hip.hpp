@@ -586,7 +586,8 @@ class ODE : public Equation {
     m.has_init_ = has_init;
     return m;
   }
-  /// ODE::with_solver / with_tolerances (ode/mod.rs:134-166): PMX_SOLVER_RK4 (fixed step) | PMX_SOLVER_DOPRI5.
+  /// ODE::with_solver / with_tolerances (ode/mod.rs:134-166): PMX_SOLVER_RK4 (fixed step) | PMX_SOLVER_DOPRI5 (adaptive,
+  /// explicit) | PMX_SOLVER_ROS2 (adaptive, L-stable: the stiff option, the role of OdeSolver::Bdf / Sdirk).
   ODE& with_solver(int32_t solver) { desc_.ode_solver = solver; invalidate(); return *this; }
   ODE& with_tolerances(double rtol, double atol) { desc_.ode_rtol = rtol; desc_.ode_atol = atol; invalidate(); return *this; }
   ODE& with_step(double h_max) { desc_.rk4_h_max = h_max; invalidate(); return *this; }
