@@ -143,6 +143,7 @@ struct DeviceStream {
   int64_t max_lagb_per_list = 0;
   int32_t prop_cache_used = 0;        // LDS slots the stream's propagator-cache codes use
   bool no_rates = false;              // no PROP of the stream has an active infusion
+  bool eig_reuse = false;             // some PROP repeats the previous built segment's covariate factor row (bit 27)
   double prop_reuse_fraction = 0.0;   // share of PROP ops that take a kept propagator
   ~DeviceStream() {
     for (void* p : allocs) (void)hipFree(p);
@@ -952,6 +953,10 @@ int32_t get_stream(pmx_population* pop, const pmx::CompileKey& key_in, DeviceStr
   ds->no_rates = true;  // (analytical streams: a PROP's op_b is its rate)
   for (size_t o = 0; o < os.op_meta.size() && ds->no_rates; ++o)
     if ((os.op_meta[o] & 0xffu) == pmx::OP_PROP && os.op_b[o] != 0.0) ds->no_rates = false;
+  ds->eig_reuse = false;  // (covariate streams: bit 27 of a PROP = "same rate constants as the previous built segment")
+  if (key.prop_cache_slots > 0 && !os.op_fac.empty())
+    for (size_t o = 0; o < os.op_meta.size() && !ds->eig_reuse; ++o)
+      if ((os.op_meta[o] & 0xffu) == pmx::OP_PROP && (os.op_meta[o] & (1u << 27))) ds->eig_reuse = true;
   ds->prop_reuse_fraction = os.n_prop > 0 ? static_cast<double>(os.n_prop_reused) / static_cast<double>(os.n_prop) : 0.0;
   ds->dev.n_rate = key.n_rate;
   ds->dev.n_cov = 0;
@@ -1275,6 +1280,7 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
   // the stream's codes were written for key.prop_cache_slots slots; the kernel decodes them with the same number
   a.prop_slots = ds->prop_cache_used > 0 ? ds->key.prop_cache_slots : 0;
   a.no_rates = (ds->no_rates && d.eq_kind == PMX_EQ_ANALYTICAL && ds->dev.op_kfac != nullptr && std::getenv("PMX_DISABLE_DYN3") == nullptr) ? 1 : 0;
+  a.eig_reuse = ds->eig_reuse ? 1 : 0;
   a.dyn_tile = tunables().dyn_tile;  // (0 = the default tile; 64 and 256 measured the same with one slot)
   DeviceStream::LLCache* slot = nullptr;
   struct SlotGuard {  // the slot is released (event recorded on the stream) however this function leaves

@@ -469,6 +469,7 @@ int32_t compile_ops(const HostPopulation& hp, const CompileKey& key, OpStream* o
               next[i] = static_cast<int64_t>(j);
               break;
             }
+        int64_t last_built = -1;
         std::vector<int64_t> holder(static_cast<size_t>(NS_), -1);  // slot -> index of the PROP whose propagator it holds
         std::vector<int32_t> slot_of(n, -1);
         for (size_t i = 0; i < n; ++i) {
@@ -502,6 +503,15 @@ int32_t compile_ops(const HostPopulation& hp, const CompileKey& key, OpStream* o
             }
           }
           os->op_meta[props[i]] |= code << 24;
+          // bit 27: this PROP's covariate factor row equals the one of the occasion's previous BUILT PROP (a subject-constant
+          // covariate: every segment) - the rate constants, hence the eigenvalues, are the same and only the step length
+          // differs (pmx_analytical_dyn3 keeps the last eigenvalues in registers).  "Built" = not taken from a slot.
+          if (code <= static_cast<uint32_t>(NS_)) {
+            if (last_built >= 0 && std::memcmp(&os->op_fac[static_cast<size_t>(props[i]) * nfac],
+                                               &os->op_fac[static_cast<size_t>(last_built) * nfac], nfac * 8) == 0)
+              os->op_meta[props[i]] |= 1u << 27;
+            last_built = props[i];
+          }
         }
         seg0 = seg1;
       }

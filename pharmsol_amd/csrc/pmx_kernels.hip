@@ -425,7 +425,11 @@ __global__ __launch_bounds__(kBlock, (!LAG && LaneModel<KID>::NS <= 2) ? 4 : ((!
 #ifndef PMX_DYN3_WAVES
 #define PMX_DYN3_WAVES 3
 #endif
-template <int KID, bool LL>
+// EIGR: the stream marks segments whose rate constants equal those of the occasion's previous built segment (bit 27: a
+// subject-constant covariate) - the eigenvalues are kept in registers and only the divided differences are rebuilt
+// (C5 with one wt per subject 10.6 -> 9.5 ms).  Its own instantiation: carrying the six registers and the second copy of
+// the rebuild through the time-varying case cost that one 5 % (10.57 -> 11.09 ms).
+template <int KID, bool LL, bool EIGR>
 __global__ __launch_bounds__(kBlock, PMX_DYN3_WAVES) void pmx_analytical_dyn3(DevModel m, DevOps ops, const double* __restrict__ theta,
                                                                              int64_t P, int64_t S, int32_t s_chunk, int32_t n_ptiles,
                                                                              double* __restrict__ pred, int64_t ld,
@@ -497,6 +501,8 @@ __global__ __launch_bounds__(kBlock, PMX_DYN3_WAVES) void pmx_analytical_dyn3(De
 #pragma unroll
     for (int i = 0; i < NS; ++i) x[i] = 0.0;
     double ll_acc = 0.0;
+    double lprev[3] = {0.0, 0.0, 0.0};  // eigenvalues of the occasion's last built segment (bit 27 of a PROP reuses them)
+    bool okprev = true;
     uint8_t st = PMX_PAIR_OK;
     uint8_t st_sticky = PMX_PAIR_OK;  // first failure of an EARLIER occasion (the reference errors out for the whole subject)
     if (zero_status == 1 && status != nullptr) {  // (status protocol: pmx_analytical_grid)
@@ -537,7 +543,15 @@ __global__ __launch_bounds__(kBlock, PMX_DYN3_WAVES) void pmx_analytical_dyn3(De
 #pragma unroll
           for (int k = 0; k < ND0; ++k) keep[k] = prop_cache[((rc - 1u - n_slots) * ND0 + k) * tile + threadIdx.x];
         } else {
-          if (!LM::S::direct0_make(q, a, keep)) st = PMX_PAIR_COMPLEX_ROOTS;
+          // bit 27: same covariate factor row as the occasion's previous built segment - its eigenvalues still hold
+          bool ok;
+          if constexpr (EIGR) {
+            ok = (meta & (1u << 27)) ? LM::S::template direct0_make<true>(q, a, keep, lprev, okprev)
+                                     : LM::S::template direct0_make<false>(q, a, keep, lprev, okprev);
+          } else {
+            ok = LM::S::template direct0_make<false>(q, a, keep, lprev, okprev);
+          }
+          if (!ok) st = PMX_PAIR_COMPLEX_ROOTS;
           if (rc != 0u) {
 #pragma unroll
             for (int k = 0; k < ND0; ++k) prop_cache[((rc - 1u) * ND0 + k) * tile + threadIdx.x] = keep[k];
@@ -1975,12 +1989,15 @@ hipError_t launch_analytical(const LaunchArgs& a, const char** name) {
       if (a.no_rates && a.m.pm == 0) {  // three-compartment covariate model, no infusion anywhere: the matrix-free walker
         *name = (list != nullptr) ? *name : "pmx_analytical_dyn3";
         const size_t lds3 = (a.prop_slots > 0) ? static_cast<size_t>(a.prop_slots) * LaneModel<KID>::S::ND0 * sizeof(double) * threads : 0;
-        if (a.ops.ll_obs != nullptr)
-          hipLaunchKernelGGL((pmx_analytical_dyn3<KID, true>), dim3(static_cast<uint32_t>(blocks)), dim3(threads), lds3, st, a.m, a.ops,
-                             a.theta, a.P, n_walk, s_chunk, n_ptiles, a.pred, a.ld, a.status, list, a.cls.zero_status, a.prop_slots);
-        else
-          hipLaunchKernelGGL((pmx_analytical_dyn3<KID, false>), dim3(static_cast<uint32_t>(blocks)), dim3(threads), lds3, st, a.m, a.ops,
-                             a.theta, a.P, n_walk, s_chunk, n_ptiles, a.pred, a.ld, a.status, list, a.cls.zero_status, a.prop_slots);
+        const bool ll = a.ops.ll_obs != nullptr, er = a.eig_reuse != 0;
+        auto go = [&](auto kern) {
+          hipLaunchKernelGGL(kern, dim3(static_cast<uint32_t>(blocks)), dim3(threads), lds3, st, a.m, a.ops, a.theta, a.P, n_walk,
+                             s_chunk, n_ptiles, a.pred, a.ld, a.status, list, a.cls.zero_status, a.prop_slots);
+        };
+        if (ll && er) go(pmx_analytical_dyn3<KID, true, true>);
+        else if (ll) go(pmx_analytical_dyn3<KID, true, false>);
+        else if (er) go(pmx_analytical_dyn3<KID, false, true>);
+        else go(pmx_analytical_dyn3<KID, false, false>);
         return hipGetLastError();
       }
     }

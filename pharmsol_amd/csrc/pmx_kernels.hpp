@@ -78,6 +78,7 @@ struct LaunchArgs {
   int32_t prop_slots;   // DYN GRID: LDS slots for kept propagators (OpStream::prop_cache_used; 0 = none)
   int32_t dyn_tile;     // DYN GRID with kept propagators: support points per block (0 = the default tile)
   int32_t no_rates;     // the compiled stream holds no PROP with an active infusion (three-compartment DYN: matrix-free walker)
+  int32_t eig_reuse;    // ... and marks segments that repeat the previous built segment's rate constants (bit 27: the EIGR variant)
   int32_t tune_cpb;     // > 0: chunks per block of the classed kernel forced by PMX_TUNE_CPB (tuning experiments)
   int32_t tune_ll_old;  // != 0: PMX_TUNE_LL_OLD - the round-2 log-likelihood kernel for exact classes (A/B)
   DevClassPlan cls;

@@ -758,10 +758,25 @@ struct ThreeNewton {
   static constexpr int NC = ABS ? 4 : 3;
   static constexpr int NKEEP = 3 + NC + (ABS ? 1 : 0);
   // keep = {l0, l1, l2, c0.. (, exp(-ka dt): the gut decouples, its own step is that one product)}
+  // REUSE: the eigenvalues of the previous build are still valid (same rate constants, another step length): `lprev`
+  // (descending, as ThreeCore::eigen returns them) and `okprev` are read instead of solved for, and written otherwise
+  template <bool REUSE = false>
   __device__ __forceinline__ static bool make(double k10, double k12, double k13, double k21, double k31, double ka, double dt,
-                                              double (&keep)[NKEEP]) {
+                                              double (&keep)[NKEEP], double (&lprev)[3], bool& okprev) {
     double le[3];
-    const bool ok = ThreeCore::eigen(k10, k12, k13, k21, k31, le);
+    bool ok;
+    if constexpr (REUSE) {
+      le[0] = lprev[0];
+      le[1] = lprev[1];
+      le[2] = lprev[2];
+      ok = okprev;
+    } else {
+      ok = ThreeCore::eigen(k10, k12, k13, k21, k31, le);
+      lprev[0] = le[0];
+      lprev[1] = le[1];
+      lprev[2] = le[2];
+      okprev = ok;
+    }
     // nodes in ASCENDING order (eigen returns l0 >= l1 >= l2): the slowest mode first.  In f64 against an 80-bit evaluation
     // of the spectral sum, 3000 draws of the C5 parameter ranges: this order 1.8e-13 worst relative error (the partial-
     // fraction form 2.4e-13), descending order 4.3e-12.
@@ -866,8 +881,9 @@ struct Structure<S_THREE> {
   }
   // rate-free segment, matrix-free (ThreeNewton): what to keep for a repeat, and the step itself
   static constexpr int ND0 = ThreeNewton<false>::NKEEP;
-  __device__ __forceinline__ static bool direct0_make(const double* kp, double dt, double (&keep)[ND0]) {
-    return ThreeNewton<false>::make(kp[0], kp[1], kp[2], kp[3], kp[4], 0.0, dt, keep);
+  template <bool REUSE = false>
+  __device__ __forceinline__ static bool direct0_make(const double* kp, double dt, double (&keep)[ND0], double (&lprev)[3], bool& okprev) {
+    return ThreeNewton<false>::template make<REUSE>(kp[0], kp[1], kp[2], kp[3], kp[4], 0.0, dt, keep, lprev, okprev);
   }
   __device__ __forceinline__ static void direct0_apply(const double* kp, const double (&keep)[ND0], double (&x)[NS]) {
     double g_unused = 0.0;
@@ -948,8 +964,9 @@ struct Structure<S_THREE_ABS> {
     return three_direct<true, WITH_J>(kp[1], kp[2], kp[3], kp[4], kp[5], kp[0], dt, p.p, p.ea, p.g);
   }
   static constexpr int ND0 = ThreeNewton<true>::NKEEP;
-  __device__ __forceinline__ static bool direct0_make(const double* kp, double dt, double (&keep)[ND0]) {
-    return ThreeNewton<true>::make(kp[1], kp[2], kp[3], kp[4], kp[5], kp[0], dt, keep);
+  template <bool REUSE = false>
+  __device__ __forceinline__ static bool direct0_make(const double* kp, double dt, double (&keep)[ND0], double (&lprev)[3], bool& okprev) {
+    return ThreeNewton<true>::template make<REUSE>(kp[1], kp[2], kp[3], kp[4], kp[5], kp[0], dt, keep, lprev, okprev);
   }
   __device__ __forceinline__ static void direct0_apply(const double* kp, const double (&keep)[ND0], double (&x)[NS]) {
     ThreeNewton<true>::apply(kp[1], kp[2], kp[3], kp[4], kp[5], kp[0], keep, x[0], x[1], x[2], x[3]);
