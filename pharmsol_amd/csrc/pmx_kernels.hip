@@ -463,6 +463,8 @@ __global__ __launch_bounds__(kBlock, PMX_DYN3_WAVES) void pmx_analytical_dyn3(De
   // front of every rebuild the walker waited on the scalar cache more than it computed.  Without a subject list the
   // stream is walked in order, so the look-ahead runs across subjects (a subject's last op requests the next one's first).
   const bool chained = subj_list == nullptr;
+  const int64_t o_blk_end = chained ? c_subj_op_off[s_end] : 0;  // (the look-ahead never leaves the ops of this block's subjects:
+                                                                 // trailing subjects without ops would otherwise send it one past the stream)
   uint32_t meta_n = 0u;
   u32x16 rec_n = {};
   // ... and so does the subject's header {first op, end op, first row}: the next subject's end op and first row are
@@ -516,7 +518,7 @@ __global__ __launch_bounds__(kBlock, PMX_DYN3_WAVES) void pmx_analytical_dyn3(De
       asm volatile("" : "+s"(meta), "+s"(rec));  // (this op's words are in scalar registers from here on)
       {
         int64_t on = o + 1;
-        if (on >= o1 && (!chained || si + 1 >= s_end)) on = o;  // nothing follows: request this op again
+        if (on >= o1 && (!chained || on >= o_blk_end)) on = o;  // nothing follows (in this block's range of the stream): request this op again
         meta_n = sload_here<uint32_t>(ops.op_meta + on);
         rec_n = sload_here<u32x16>(ops.op_kfac + on * 8);
         __builtin_amdgcn_sched_barrier(0);

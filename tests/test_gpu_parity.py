@@ -219,6 +219,40 @@ def test_ragged_population_with_empty_and_doseless_subjects():
     assert_parity(m, flat, th_b, TOL_ANALYTICAL, batch=True, expect_kernel="pmx_analytical_pair")
 
 
+def test_matrix_free_covariate_walker_with_empty_subjects_and_occasions():
+    """pmx_analytical_dyn3 requests every op and every subject header one ahead, across subjects: subjects without events
+    in the middle and at the very end of the stream, several occasions, a subject-constant covariate beside interpolated ones
+    (the EIGR instantiation: kept eigenvalues), equal segment lengths (kept segments)."""
+    from pharmsol_amd import Pow, Scaled, analytical, bolus
+
+    rng = np.random.default_rng(808)
+    m = analytical(name="three_cmt_oral_wt", params=["ka", "k10_0", "k12", "k13", "k21", "k31", "v"],
+                   derived={"k10": Scaled("k10_0", (Pow("wt", 70.0, 0.75),))}, covariates=["wt"],
+                   structure="three_compartments_with_absorption", states=["gut", "central", "periph1", "periph2"],
+                   outputs=["cp"], routes=[bolus("oral", "gut")], out={"cp": Ratio("central", "v")})
+    subs = []
+    for i in range(60):
+        b = Subject.builder(f"s{i}").covariate("wt", 0.0, float(rng.uniform(50, 110)))
+        if i % 3:
+            b = b.covariate("wt", float(rng.uniform(6, 40)), float(rng.uniform(50, 110)))
+        b = b.bolus(0.0, float(rng.uniform(100, 500)), "oral")
+        for t in (1.0, 2.0, 4.0, 6.0, 8.0, 12.0, 24.0):
+            b = b.missing_observation(t, "cp")
+        if i % 4 == 0:
+            b = b.reset().covariate("wt", 0.0, float(rng.uniform(50, 110))).bolus(0.0, 100.0, "oral")
+            for t in (2.0, 4.0, 6.0, 30.0):
+                b = b.missing_observation(t, "cp")
+        subs.append(b.build())
+    # (a covariate model wants its covariate in every occasion, also in one without events: src/lib.rs:433-443)
+    subs.insert(5, Subject.builder("empty_mid").covariate("wt", 0.0, 70.0).build())
+    subs.append(Subject.builder("empty_last_but_one").covariate("wt", 0.0, 70.0).build())
+    subs.append(Subject.builder("empty_last").covariate("wt", 0.0, 70.0).build())
+    flat = m.flatten(Data(subs))
+    th = synth.theta_c5(70)
+    assert_parity(m, flat, th, TOL_ANALYTICAL, expect_kernel="pmx_analytical_dyn3")
+    assert_parity(m, flat, th[:5], TOL_ANALYTICAL, expect_kernel="pmx_analytical_pair")
+
+
 def test_support_point_counts_around_the_tile_edges():
     m, flat, _ = synth.config_c3(37, 8)
     for P in (31, 32, 33, 255, 256, 257, 1000):
