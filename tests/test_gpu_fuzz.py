@@ -227,8 +227,9 @@ def test_random_ode_configuration(seed):
         fa_col, cols = cols, cols + 1
     m = ODE.new(name, {0: Ratio(central, v_col)}, nparams=cols, lag={0: lag_col} if use_lag else None,
                 fa={0: fa_col} if use_fa else None, h_max=0.05).with_nstates(ns).with_ndrugs(1).with_nout(1)
+    stiff = adaptive and seed % 3 == 2  # (every third adaptive case: the L-stable stepper behind the same step control)
     if adaptive:
-        m = m.with_step(4.0).with_solver("dopri5").with_tolerances(1e-8, 1e-8)
+        m = m.with_step(4.0).with_solver("ros2" if stiff else "dopri5").with_tolerances(*((1e-6, 1e-7) if stiff else (1e-8, 1e-8)))
     subs = [models.random_subject(rng, multi_occasion=bool(rng.random() < 0.3)) for _ in range(int(rng.integers(3, 25)))]
     n = len(subs) if batch else n_support
     if mm:
@@ -244,7 +245,7 @@ def test_random_ode_configuration(seed):
     if use_fa:
         th.append(rng.uniform(0.3, 1.0, (n, 1)))
     theta = np.concatenate(th, axis=1)
-    recipe = dict(seed=seed, model=name, lag=use_lag, fa=use_fa, adaptive=adaptive, batch=batch, support=n_support)
+    recipe = dict(seed=seed, model=name, lag=use_lag, fa=use_fa, adaptive=adaptive, stiff=stiff, batch=batch, support=n_support)
     flat = m.flatten(Data(subs))
     pop = runtime.DevicePopulation(flat, 0)
     pred, st = runtime.predict(m, pop, np.ascontiguousarray(theta), batch=batch)
@@ -257,7 +258,9 @@ def test_random_ode_configuration(seed):
     if ok.any():
         scale = np.maximum(np.abs(want[ok]), 1e-3 * np.abs(want[ok]).max() + 1e-300)
         err = (np.abs(got[ok] - want[ok]) / scale).max()
-        assert err < (2e-6 if adaptive else 1e-9), (err, recipe, runtime.last_kernel_name())
+        # (adaptive: same method and tolerances on both sides; FMA contraction may move a step boundary, so agreement is at
+        # the solver's tolerance - ROS2's steps, sized by a first-order estimate, are many and each is accepted at <= rtol)
+        assert err < ((5e-5 if stiff else 2e-6) if adaptive else 1e-9), (err, recipe, runtime.last_kernel_name())
 
 
 STATE_NAMES = {1: ["central"], 2: ["central", "periph"], 3: ["central", "periph1", "periph2"]}
