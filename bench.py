@@ -347,13 +347,24 @@ def main():
                 # (pmx_prediction_buffer_create_pitched, exhaustive form): boxes exist where none of the plain allocations
                 # is of the fast kind (profiles/r03/bench_c3_box_without_a_fast_plain_allocation.json).  (N > 1: ranks time
                 # their few plain candidates only - eight ranks each timing 100 GiB of arena windows would say more about the
-                # search than about the path)
+                # search than about the path -)
                 free_b, _tot = torch.cuda.mem_get_info(dev)
                 gib = min(args.place_gib, 0.75 * free_b / (1 << 30))
                 try:
                     if world > 1:
-                        raise StopIteration
-                    cand = runtime.place_predictions(model, pop, d_theta, search_gib=gib, exhaustive=True, ld=ld)
+                        # ... unless the best of them is clearly of the slow kind: a flat fill of the same buffer gives this
+                        # device's write ceiling (pmx_measure_write_ceiling, ~5 ms), and a rank whose kernel stays below
+                        # 92 % of it runs the library's quick search (it stops inside the first fast plateau, ~0.1 s)
+                        import ctypes as C
+
+                        from pharmsol_amd import _ffi
+                        gbs = C.c_double()
+                        base = pred._base if getattr(pred, "_base", None) is not None else pred
+                        _ffi.check(_ffi.lib().pmx_measure_write_ceiling(base.data_ptr(), int(base.numel()), 3,
+                                                                        torch.cuda.current_stream(dev).cuda_stream, C.byref(gbs)))
+                        if 8.0 * n_obs * P / (best_ms * 1e-3) / 1e9 >= 0.92 * gbs.value:
+                            raise StopIteration
+                    cand = runtime.place_predictions(model, pop, d_theta, search_gib=gib, exhaustive=(world == 1), ld=ld)
                     if ms_into(cand) < best_ms:
                         pred = cand
                         placed = "best window of a %.0f GiB arena, rows padded to %d doubles (%.3f ms during the search)" % (
