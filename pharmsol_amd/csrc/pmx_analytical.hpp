@@ -143,9 +143,9 @@ __device__ __forceinline__ void user_walk_subject(const DevOps& ops, const doubl
   auto u64 = [](int64_t v) { return UNIFORM ? uniform64(v) : v; };
   auto u32 = [](uint32_t v) { return UNIFORM ? uniform32(v) : v; };
   auto uf = [](double v) { return UNIFORM ? uniformf64(v) : v; };
-  const int64_t o0 = u64(ops.subj_op_off[subj]);
-  const int64_t o1 = walk ? u64(ops.subj_op_off[subj + 1]) : o0;  // (GRID: idle lanes shadow the last support point, stores masked)
-  int64_t row = u64(ops.subj_obs_off[subj]);
+  const int64_t o0 = u64(as_const(ops.subj_op_off)[subj]);
+  const int64_t o1 = walk ? u64(as_const(ops.subj_op_off)[subj + 1]) : o0;  // (GRID: idle lanes shadow the last support point, stores masked)
+  int64_t row = u64(as_const(ops.subj_obs_off)[subj]);
 
   Coef coef;
   bool lane_cplx = false;
@@ -180,21 +180,21 @@ __device__ __forceinline__ void user_walk_subject(const DevOps& ops, const doubl
 
 #pragma unroll 1
   for (int64_t o = o0; o < o1; ++o) {
-    const uint32_t meta = u32(ops.op_meta[o]);
+    const uint32_t meta = u32(as_const(ops.op_meta)[o]);
     const uint32_t kind = meta & 0xffu;
     const int io = static_cast<int>((meta >> 8) & 0xffffu);
-    const double a = uf(ops.op_a[o]);
+    const double a = uf(as_const(ops.op_a)[o]);
     if (kind == OP_PROP) {
       double rate[M::NIN];
 #pragma unroll
       for (int i = 0; i < M::NIN; ++i) rate[i] = 0.0;
       if constexpr (M::KID >= 0) {
-        rate[M::RATE_INPUT] = uf(ops.op_b[o]);
+        rate[M::RATE_INPUT] = uf(as_const(ops.op_b)[o]);
       } else {
 #pragma unroll
-        for (int i = 0; i < M::NIN; ++i) rate[i] = (i < ops.n_rate) ? uf(ops.op_rate[o * ops.n_rate + i]) : 0.0;
+        for (int i = 0; i < M::NIN; ++i) rate[i] = (i < ops.n_rate) ? uf(as_const(ops.op_rate)[o * ops.n_rate + i]) : 0.0;
       }
-      const double t0 = uf(ops.op_t0[o]), t1 = uf(ops.op_t1[o]);
+      const double t0 = uf(as_const(ops.op_t0)[o]), t1 = uf(as_const(ops.op_t1)[o]);
       if (((meta >> 24) & 1u) == 0u) s.fresh = true;  // first sub-segment of a solve
       double t = t0;
       if constexpr (M::HAS_LAG) {
@@ -245,7 +245,7 @@ __device__ __forceinline__ void user_walk_subject(const DevOps& ops, const doubl
       }
       ++row;
     } else if (kind == OP_BOLUS) {
-      user_bolus<M>(ops, occ, th, s, uf(ops.op_b[o]), io, a);
+      user_bolus<M>(ops, occ, th, s, uf(as_const(ops.op_b)[o]), io, a);
       s.fresh = true;
     } else {  // OP_RESET: initial_state (analytical/mod.rs:409-426), then this lane's view of the lagged boluses
       occ = static_cast<int64_t>(a);
@@ -263,7 +263,7 @@ __device__ __forceinline__ void user_walk_subject(const DevOps& ops, const doubl
       if constexpr (M::HAS_LAG) {
         if (!user_lag_open<M>(ops, occ, th, lagst)) bad_lag = true;
         // boluses landing before the occasion's first remaining event open the occasion; no infusion can be active yet
-        const double t_first = uf(ops.op_t0[o]);
+        const double t_first = uf(as_const(ops.op_t0)[o]);
         bool started = false;
         double t = 0.0;
 #pragma unroll 1
@@ -321,7 +321,7 @@ __device__ __forceinline__ void user_pair_body(const DevModel& m, const DevOps& 
   const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const bool lane_ok = i < n_pairs;
   const int64_t ic = lane_ok ? i : (n_pairs - 1);
-  const int64_t s = ops.subj_order[batch ? ic : (ic / P)];
+  const int64_t s = as_const(ops.subj_order)[batch ? ic : (ic / P)];
   const int64_t p = batch ? 0 : (ic % P);
   const double* __restrict__ th = theta + (batch ? s : p) * m.nparams;
   user_walk_subject<M, false, LL>(ops, th, s, lane_ok, lane_ok, pred, ld, p, LL ? (ops.ll_out + (batch ? s : (s * ops.ll_ld + p))) : nullptr,

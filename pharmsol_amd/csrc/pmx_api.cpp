@@ -18,6 +18,7 @@
 #include "../../include/pmx.h"
 #include "pmx_compile.hpp"
 #include "pmx_jit.hpp"
+#include <dlfcn.h>
 #include "pmx_kernels.hpp"
 #include "pmx_structures.hpp"  // kernel_nparams()
 
@@ -1380,7 +1381,23 @@ int32_t enqueue(const pmx_model* model, pmx_population* pop, const double* d_the
                                             {"pmx_jit_ode_user_dopri5_grid", "pmx_jit_ode_user_dopri5_pair"},
                                             {"pmx_jit_ode_user_ros2_grid", "pmx_jit_ode_user_ros2_pair"}};
     if (model->user_ode) name = kUser[sv][mode];
-    if (a.S <= 0 || (a.P <= 0 && !a.batch)) {
+    // (experiment hook, tools/experiments/user_static: PMX_DEBUG_STATIC_SO names a shared object holding the SAME translation
+    // unit compiled ahead of time by hipcc, with a launcher for its GRID prediction entry point)
+    typedef int (*static_launch_t)(const void*, const void*, const double*, int64_t, int64_t, int32_t, int32_t, double*, int64_t,
+                                   uint8_t*, uint32_t, uint32_t, void*);
+    static static_launch_t s_static = []() -> static_launch_t {
+      const char* so = std::getenv("PMX_DEBUG_STATIC_SO");
+      if (!so) return nullptr;
+      void* h = dlopen(so, RTLD_NOW | RTLD_LOCAL);
+      return h ? reinterpret_cast<static_launch_t>(dlsym(h, "pmx_static_launch")) : nullptr;
+    }();
+    if (s_static && mode == 0 && !ll && a.S > 0 && a.P > 0) {
+      const int64_t n_chunks = (a.S + a.s_chunk - 1) / a.s_chunk;
+      const int rc_s = s_static(&a.m, &a.ops, a.theta, a.P, a.S, a.s_chunk, a.n_ptiles, a.pred, a.ld, a.status,
+                                static_cast<uint32_t>(n_chunks * a.n_ptiles), a.P <= 64 ? 64u : (a.P <= 128 ? 128u : 256u), stream);
+      e = rc_s == 0 ? hipSuccess : hipErrorUnknown;
+      name = "pmx_static_agrid";
+    } else if (a.S <= 0 || (a.P <= 0 && !a.batch)) {
       e = hipSuccess;
     } else if (mode == 0) {
       const int64_t n_chunks = (a.S + a.s_chunk - 1) / a.s_chunk;

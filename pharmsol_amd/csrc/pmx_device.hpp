@@ -59,12 +59,12 @@ __device__ __forceinline__ double select_state(const double (&x)[N], int idx) {
 // segment is open-ended.  NaN when nothing matches (the reference's MissingSegments error).
 __device__ __forceinline__ double cov_at(const DevOps& ops, int64_t occ, int c, double t) {
   const int64_t cell = occ * ops.n_cov + c;
-  const int64_t s0 = ops.cov_seg_off[cell], s1 = ops.cov_seg_off[cell + 1];
-  if (t < ops.cov_first_t[cell]) return ops.cov_first_v[cell];
+  const int64_t s0 = as_const(ops.cov_seg_off)[cell], s1 = as_const(ops.cov_seg_off)[cell + 1];
+  if (t < as_const(ops.cov_first_t)[cell]) return as_const(ops.cov_first_v)[cell];
   double v = __longlong_as_double(0x7ff8000000000000LL);
   for (int64_t sg = s0; sg < s1; ++sg) {
-    if (ops.seg_from[sg] <= t && t < ops.seg_to[sg]) {
-      const double sl = ops.seg_slope[sg], ic = ops.seg_icpt[sg];
+    if (as_const(ops.seg_from)[sg] <= t && t < as_const(ops.seg_to)[sg]) {
+      const double sl = as_const(ops.seg_slope)[sg], ic = as_const(ops.seg_icpt)[sg];
       v = (sl != sl) ? ic : __dadd_rn(__dmul_rn(sl, t), ic);
       break;
     }
@@ -114,7 +114,7 @@ __device__ __forceinline__ double lag_next(const DevModel& m, const DevOps& ops,
 #pragma unroll
   for (int k = 0; k < kMaxLagSlots; ++k) {
     if (k < m.n_lag_slots && ls.cur[k] < ls.end[k]) {
-      const double tk = ops.lagb_time[ls.cur[k]] + ls.lag[k];
+      const double tk = as_const(ops.lagb_time)[ls.cur[k]] + ls.lag[k];
       if (tk < tau) {
         tau = tk;
         which = k;
@@ -155,7 +155,7 @@ __device__ __forceinline__ void lag_apply_bolus(const DevModel& m, const DevOps&
       ls.cur[k] += 1;
     }
   }
-  const double amt = ops.lagb_amount[idx] * fa_of(m, th, input);
+  const double amt = as_const(ops.lagb_amount)[idx] * fa_of(m, th, input);
 #pragma unroll
   for (int i = 0; i < NS; ++i) x[i] += (i == dest) ? amt : 0.0;
 }

@@ -401,8 +401,8 @@ __device__ __forceinline__ double ode_lag_open_occasion(const DevModel& m, const
 #pragma unroll
   for (int k = 0; k < kMaxLagSlots; ++k) {
     if (k < m.n_lag_slots) {
-      ls.cur[k] = static_cast<int32_t>(ops.lagb_off[occ * m.n_lag_slots + k]);
-      ls.end[k] = static_cast<int32_t>(ops.lagb_off[occ * m.n_lag_slots + k + 1]);
+      ls.cur[k] = static_cast<int32_t>(as_const(ops.lagb_off)[occ * m.n_lag_slots + k]);
+      ls.end[k] = static_cast<int32_t>(as_const(ops.lagb_off)[occ * m.n_lag_slots + k + 1]);
     } else {
       ls.cur[k] = ls.end[k] = 0;
     }
@@ -490,9 +490,9 @@ __device__ __forceinline__ void ode_grid_body(const DevModel& m, const DevOps& o
   const int64_t s_begin = chunk * s_chunk;
   const int64_t s_end = (s_begin + s_chunk < S) ? (s_begin + s_chunk) : S;
   for (int64_t s = s_begin; s < s_end; ++s) {
-    const int64_t o0 = uniform64(ops.subj_op_off[s]);
-    const int64_t o1 = uniform64(ops.subj_op_off[s + 1]);
-    int64_t row = uniform64(ops.subj_obs_off[s]);
+    const int64_t o0 = uniform64(as_const(ops.subj_op_off)[s]);
+    const int64_t o1 = uniform64(as_const(ops.subj_op_off)[s + 1]);
+    int64_t row = uniform64(as_const(ops.subj_obs_off)[s]);
     double x[NS];
 #pragma unroll
     for (int i = 0; i < NS; ++i) x[i] = 0.0;
@@ -503,24 +503,24 @@ __device__ __forceinline__ void ode_grid_body(const DevModel& m, const DevOps& o
     as.failed = 0;
     double clk = 0.0;  // LAG: the lane's solver clock (see ode_lag_open_occasion)
     for (int64_t o = o0; o < o1; ++o) {
-      const uint32_t meta = uniform32(ops.op_meta[o]);
+      const uint32_t meta = uniform32(as_const(ops.op_meta)[o]);
       const uint32_t kind = meta & 0xffu;
       const int io = static_cast<int>((meta >> 8) & 0xffffu);
-      const double a = uniformf64(ops.op_a[o]);
+      const double a = uniformf64(as_const(ops.op_a)[o]);
       if (kind == OP_PROP) {
         double rs[M::NR];
         ode_rates<M>(m, ops.op_rate, o, ops.n_rate, rs);
         if constexpr (LAG) {
-          const double t0 = uniformf64(ops.op_t0[o]), t1 = uniformf64(ops.op_t1[o]);
+          const double t0 = uniformf64(as_const(ops.op_t0)[o]), t1 = uniformf64(as_const(ops.op_t1)[o]);
           ode_lag_prop<M, ADAPT>(m, ops, ls, (clk > t0) ? clk : t0, t1, L, rs, th, x, as);
           if (t1 > clk) clk = t1;
         } else if constexpr (ADAPT) {
-          ode_piece<M, true>(m, L, x, rs, uniformf64(ops.op_t0[o]), uniformf64(ops.op_t1[o]), as);
+          ode_piece<M, true>(m, L, x, rs, uniformf64(as_const(ops.op_t0)[o]), uniformf64(as_const(ops.op_t1)[o]), as);
         } else {
-          const double h = uniformf64(ops.op_b[o]);
-          const int32_t n = static_cast<int32_t>(uniform32(static_cast<uint32_t>(ops.op_n[o])));
+          const double h = uniformf64(as_const(ops.op_b)[o]);
+          const int32_t n = static_cast<int32_t>(uniform32(static_cast<uint32_t>(as_const(ops.op_n)[o])));
           double t0 = 0.0;  // only a custom (possibly non-autonomous) body reads the time
-          if constexpr (M::CUSTOM) t0 = uniformf64(ops.op_t0[o]);
+          if constexpr (M::CUSTOM) t0 = uniformf64(as_const(ops.op_t0)[o]);
           for (int32_t k = 0; k < n; ++k) rk4_step<M>(L, x, rs, t0 + static_cast<double>(k) * h, h);
         }
       } else if (kind == OP_OBS) {
@@ -547,8 +547,8 @@ __device__ __forceinline__ void ode_grid_body(const DevModel& m, const DevOps& o
         L.occ = static_cast<int64_t>(a);
         ode_reset<M>(L, io, x);
         if constexpr (LAG)
-          clk = ode_lag_open_occasion<M, ADAPT>(m, ops, ls, static_cast<int64_t>(a), uniformf64(ops.op_t0[o]),
-                                                (meta >> 25) & 3u, uniformf64(ops.op_b[o]), L, th, x, as);
+          clk = ode_lag_open_occasion<M, ADAPT>(m, ops, ls, static_cast<int64_t>(a), uniformf64(as_const(ops.op_t0)[o]),
+                                                (meta >> 25) & 3u, uniformf64(as_const(ops.op_b)[o]), L, th, x, as);
       }
     }
     if constexpr (LL) {
@@ -572,7 +572,7 @@ __device__ __forceinline__ void ode_pair_body(const DevModel& m, const DevOps& o
   const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const bool lane_ok = i < n_pairs;
   const int64_t ic = lane_ok ? i : (n_pairs - 1);
-  const int64_t s = ops.subj_order[batch ? ic : (ic / P)];
+  const int64_t s = as_const(ops.subj_order)[batch ? ic : (ic / P)];
   const int64_t p = batch ? 0 : (ic % P);
   const double* __restrict__ th = theta + (batch ? s : p) * m.nparams;
   OdeLane<M> L;
@@ -595,9 +595,9 @@ __device__ __forceinline__ void ode_pair_body(const DevModel& m, const DevOps& o
   const double nanv = __longlong_as_double(0x7ff8000000000000LL);
   const double inf = __longlong_as_double(0x7ff0000000000000LL);
 
-  int64_t o = ops.subj_op_off[s];
-  const int64_t o1 = lane_ok ? ops.subj_op_off[s + 1] : o;
-  int64_t row = ops.subj_obs_off[s];
+  int64_t o = as_const(ops.subj_op_off)[s];
+  const int64_t o1 = lane_ok ? as_const(ops.subj_op_off)[s + 1] : o;
+  int64_t row = as_const(ops.subj_obs_off)[s];
   // The lane's next ops wait in LDS: a ring of kRing packed records per lane (DevOps::op_rec), topped up for EVERY
   // lane of the wave whenever one lane runs dry.  Lanes consume their ops at their own pace, so without the ring
   // nearly every trip had some lane waiting for a gather from HBM/L2 (~0.7 us with one wave per SIMD) and the whole
@@ -776,8 +776,8 @@ __device__ __forceinline__ void ode_pair_body(const DevModel& m, const DevOps& o
   #pragma unroll
             for (int k = 0; k < kMaxLagSlots; ++k) {
               if (k < m.n_lag_slots) {
-                ls.cur[k] = static_cast<int32_t>(ops.lagb_off[occ * m.n_lag_slots + k]);
-                ls.end[k] = static_cast<int32_t>(ops.lagb_off[occ * m.n_lag_slots + k + 1]);
+                ls.cur[k] = static_cast<int32_t>(as_const(ops.lagb_off)[occ * m.n_lag_slots + k]);
+                ls.end[k] = static_cast<int32_t>(as_const(ops.lagb_off)[occ * m.n_lag_slots + k + 1]);
               }
             }
             // boluses landing before the occasion's first remaining event open the occasion (zero rates there).  The

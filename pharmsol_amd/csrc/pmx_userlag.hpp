@@ -62,8 +62,8 @@ struct UserLag {
 template <class M>
 __device__ __forceinline__ double user_lag_landing(const DevOps& ops, int64_t occ, const double* __restrict__ th,
                                                    int64_t base, int32_t j, bool* ok) {
-  const double t = ops.lagb_time[base + j];
-  const int input = ops.lagb_input[base + j];
+  const double t = as_const(ops.lagb_time)[base + j];
+  const int input = as_const(ops.lagb_input)[base + j];
   UserCov<M> cov;
   UserDer<M> der;
   user_cov_der<M>(ops, occ, t, th, cov, der);
@@ -106,8 +106,8 @@ __device__ __forceinline__ void user_lag_scan(const DevOps& ops, int64_t occ, co
 template <class M>
 __device__ __forceinline__ bool user_lag_open(const DevOps& ops, int64_t occ, const double* __restrict__ th, UserLag& L) {
   bool ok = true;
-  L.base = ops.lagb_off[occ];
-  const int64_t n = ops.lagb_off[occ + 1] - L.base;
+  L.base = as_const(ops.lagb_off)[occ];
+  const int64_t n = as_const(ops.lagb_off)[occ + 1] - L.base;
   L.n = static_cast<int32_t>(n);
   L.cur = 0;
   L.big = false;
@@ -164,8 +164,8 @@ __device__ __forceinline__ void user_lag_take(const DevOps& ops, int64_t occ, co
     *tau = L.tau[L.cur];
     L.cur += 1;
   }
-  *input = ops.lagb_input[L.base + j];
-  *amount = ops.lagb_amount[L.base + j];
+  *input = as_const(ops.lagb_input)[L.base + j];
+  *amount = as_const(ops.lagb_amount)[L.base + j];
 }
 
 }  // namespace
